@@ -1,0 +1,179 @@
+"""Seeded synthetic latents and rolled galleries with PLANTED MATES.
+
+A random (non-mate) rolled template scores exactly 0 against any latent because the geometric-consistency
+filters reject every correspondence, so a gallery without planted mates has a degenerate 100k-way tie.  Each
+latent therefore gets one true mate and a few partial mates: a translated copy of a subset of its minutiae and
+texture points with descriptor noise, texture codes = PQ-encode(latent texture descriptors + noise).
+
+Two products:
+  * FPTemplate objects / .dat bytes for small cases (tests, CLI);
+  * a PackedGallery (concatenated SoA arrays + CSR offsets) for large galleries, which is what
+    afis_gallery_add_packed() takes without a per-template Python loop.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .templates import (DESCRIPTOR_NORM, Codebook, FPTemplate, MinutiaeTemplate, TextureTemplate)
+
+IMG_W, IMG_H = 768, 800
+BLK_W, BLK_H = 45, 47        # texture block grid ((px-24)/16)
+
+
+def _unit(d: np.ndarray) -> np.ndarray:
+    return (d / np.linalg.norm(d, axis=-1, keepdims=True) * DESCRIPTOR_NORM).astype(np.float32)
+
+
+def make_latent(rng: np.random.Generator, n_minu_tpl: int = 28, n_tex_lo: int = 400, n_tex_hi: int = 1000,
+                n_minu_lo: int = 20, n_minu_hi: int = 60) -> FPTemplate:
+    """28 minutiae templates (7 minutiae sets x 4 images in the reference, extraction_latent.py:117-181) that
+    are noisy views of one base pool, plus one texture template with two orientations per grid point
+    (extraction_latent.py:187-212)."""
+    pool = n_minu_hi
+    bx = rng.integers(60, IMG_W - 60, pool); by = rng.integers(60, IMG_H - 60, pool)
+    bo = rng.uniform(-np.pi, np.pi, pool).astype(np.float32)
+    bd = _unit(rng.standard_normal((pool, 96)))
+    t = FPTemplate()
+    for _ in range(n_minu_tpl):
+        n = int(rng.integers(n_minu_lo, n_minu_hi + 1))
+        sel = np.sort(rng.permutation(pool)[:n])
+        des = _unit(bd[sel] + rng.standard_normal((n, 96)) * 0.02)
+        t.minu.append(MinutiaeTemplate(bx[sel].astype(np.int16), by[sel].astype(np.int16), bo[sel].copy(), des))
+    n_tex = int(rng.integers(n_tex_lo, n_tex_hi + 1))
+    n_grid = max(1, n_tex // 2)
+    cells = rng.permutation(BLK_W * BLK_H)[:n_grid]
+    gx = (cells % BLK_W).astype(np.int16); gy = (cells // BLK_W).astype(np.int16)
+    go = rng.uniform(-np.pi / 2, np.pi / 2, n_grid).astype(np.float32)
+    tx = np.concatenate([gx, gx]); ty = np.concatenate([gy, gy])
+    to = np.concatenate([go, go + np.float32(np.pi)]).astype(np.float32)
+    td = _unit(rng.standard_normal((2 * n_grid, 96)))
+    t.tex.append(TextureTemplate(tx, ty, to, des=td))
+    t._pool = (bx, by, bo, bd)    # generator-private: lets make_mate plant consistent minutiae
+    return t
+
+
+def make_rolled(rng: np.random.Generator, cb: Codebook, n_minu: Optional[int] = None, n_tex: Optional[int] = None) -> FPTemplate:
+    """Random non-mate rolled template: 1 minutiae template + 1 PQ texture template (extraction_rolled.py:105-141)."""
+    if n_minu is None:
+        n_minu = int(np.clip(round(rng.normal(80, 15)), 20, 200))
+    if n_tex is None:
+        n_tex = int(rng.integers(600, 1001))
+    t = FPTemplate()
+    t.minu.append(MinutiaeTemplate(rng.integers(0, IMG_W, n_minu).astype(np.int16), rng.integers(0, IMG_H, n_minu).astype(np.int16),
+                                   rng.uniform(-np.pi, np.pi, n_minu).astype(np.float32), _unit(rng.standard_normal((n_minu, 96)))))
+    t.tex.append(TextureTemplate(rng.integers(0, BLK_W, n_tex).astype(np.int16), rng.integers(0, BLK_H, n_tex).astype(np.int16),
+                                 rng.uniform(-np.pi / 2, np.pi / 2, n_tex).astype(np.float32),
+                                 codes=rng.integers(0, cb.K, (n_tex, cb.M)).astype(np.uint8)))
+    return t
+
+
+def make_mate(rng: np.random.Generator, cb: Codebook, latent: FPTemplate, frac: float = 0.75, sigma: float = 0.08,
+              n_minu: Optional[int] = None, n_tex: Optional[int] = None) -> FPTemplate:
+    """Rolled template that shares `frac` of the latent's minutiae pool and texture grid, translated rigidly
+    (pixels for minutiae, whole blocks for texture) with descriptor noise `sigma`."""
+    t = make_rolled(rng, cb, n_minu, n_tex)
+    bx, by, bo, bd = latent._pool
+    m = t.minu[0]
+    k = min(int(len(bx) * frac), m.n)
+    sel = rng.permutation(len(bx))[:k]
+    dx, dy = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+    m.x[:k] = np.clip(bx[sel] + dx, 0, IMG_W - 1); m.y[:k] = np.clip(by[sel] + dy, 0, IMG_H - 1)
+    m.ori[:k] = bo[sel]
+    m.des[:k] = _unit(bd[sel] + rng.standard_normal((k, 96)) * sigma)
+    lt = latent.tex[0]; rt = t.tex[0]
+    half = lt.n // 2                                        # one orientation per grid point in a rolled print
+    kt = min(int(half * frac), rt.n)
+    selt = rng.permutation(half)[:kt]
+    bdx, bdy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+    rt.x[:kt] = np.clip(lt.x[selt] + bdx, 0, BLK_W - 1); rt.y[:kt] = np.clip(lt.y[selt] + bdy, 0, BLK_H - 1)
+    rt.ori[:kt] = lt.ori[selt]
+    rt.codes[:kt] = cb.encode(lt.des[selt] + rng.standard_normal((kt, 96)).astype(np.float32) * (sigma * 0.5))
+    return t
+
+
+@dataclass
+class PackedGallery:
+    """Concatenated SoA gallery (one minutiae + one texture template per entry), CSR offsets."""
+    minu_off: np.ndarray   # int64 [G+1]
+    minu_x: np.ndarray     # int16 [sum n]
+    minu_y: np.ndarray
+    minu_ori: np.ndarray   # float32
+    minu_des: np.ndarray   # float32 [sum n, 96]
+    tex_off: np.ndarray    # int64 [G+1]
+    tex_x: np.ndarray      # int16
+    tex_y: np.ndarray
+    tex_ori: np.ndarray
+    tex_codes: np.ndarray  # uint8 [sum n, 16]
+
+    @property
+    def G(self) -> int: return len(self.minu_off) - 1
+
+    def template(self, g: int) -> FPTemplate:
+        a, b = int(self.minu_off[g]), int(self.minu_off[g + 1])
+        c, d = int(self.tex_off[g]), int(self.tex_off[g + 1])
+        t = FPTemplate()
+        if b > a:
+            t.minu.append(MinutiaeTemplate(self.minu_x[a:b].copy(), self.minu_y[a:b].copy(), self.minu_ori[a:b].copy(), self.minu_des[a:b].copy()))
+        if d > c:
+            t.tex.append(TextureTemplate(self.tex_x[c:d].copy(), self.tex_y[c:d].copy(), self.tex_ori[c:d].copy(), codes=self.tex_codes[c:d].copy()))
+        return t
+
+    def set_template(self, g: int, t: FPTemplate) -> None:
+        """Overwrite entry g in place (counts must match) — used to plant mates."""
+        a, b = int(self.minu_off[g]), int(self.minu_off[g + 1])
+        c, d = int(self.tex_off[g]), int(self.tex_off[g + 1])
+        m, x = t.minu[0], t.tex[0]
+        assert m.n == b - a and x.n == d - c
+        self.minu_x[a:b] = m.x; self.minu_y[a:b] = m.y; self.minu_ori[a:b] = m.ori; self.minu_des[a:b] = m.des
+        self.tex_x[c:d] = x.x; self.tex_y[c:d] = x.y; self.tex_ori[c:d] = x.ori; self.tex_codes[c:d] = x.codes
+
+    def slice(self, lo: int, hi: int) -> "PackedGallery":
+        """Contiguous shard [lo, hi) with offsets rebased (gallery sharding)."""
+        a, b = int(self.minu_off[lo]), int(self.minu_off[hi])
+        c, d = int(self.tex_off[lo]), int(self.tex_off[hi])
+        return PackedGallery(self.minu_off[lo:hi + 1] - a, self.minu_x[a:b], self.minu_y[a:b], self.minu_ori[a:b], self.minu_des[a:b],
+                             self.tex_off[lo:hi + 1] - c, self.tex_x[c:d], self.tex_y[c:d], self.tex_ori[c:d], self.tex_codes[c:d])
+
+
+def make_packed_gallery(seed: int, G: int, cb: Codebook, n_minu_mean: float = 80, n_tex_lo: int = 600, n_tex_hi: int = 1000) -> PackedGallery:
+    """Vectorised random (non-mate) gallery; plant mates afterwards with plant_mates()."""
+    rng = np.random.default_rng(seed)
+    nm = np.clip(np.rint(rng.normal(n_minu_mean, 15, G)), 20, 200).astype(np.int64)
+    nt = rng.integers(n_tex_lo, n_tex_hi + 1, G).astype(np.int64)
+    mo = np.concatenate([[0], np.cumsum(nm)]); to = np.concatenate([[0], np.cumsum(nt)])
+    NM, NT = int(mo[-1]), int(to[-1])
+    des = np.empty((NM, 96), dtype=np.float32)
+    step = 1 << 18
+    for s in range(0, NM, step):                       # chunked: bounds peak host memory
+        e = min(NM, s + step)
+        des[s:e] = _unit(rng.standard_normal((e - s, 96), dtype=np.float32))
+    return PackedGallery(
+        mo, rng.integers(0, IMG_W, NM).astype(np.int16), rng.integers(0, IMG_H, NM).astype(np.int16),
+        rng.uniform(-np.pi, np.pi, NM).astype(np.float32), des,
+        to, rng.integers(0, BLK_W, NT).astype(np.int16), rng.integers(0, BLK_H, NT).astype(np.int16),
+        rng.uniform(-np.pi / 2, np.pi / 2, NT).astype(np.float32),
+        rng.integers(0, cb.K, (NT, cb.M), dtype=np.uint8))
+
+
+def plant_mates(seed: int, gal: PackedGallery, cb: Codebook, latents: List[FPTemplate], n_partial: int = 3) -> Dict[int, List[Tuple[int, float]]]:
+    """For each latent overwrite 1 + n_partial gallery entries (chosen without collisions) with mates of
+    decreasing overlap.  Returns {latent index: [(gallery index, frac), ...]} — the expected rank order."""
+    rng = np.random.default_rng(seed)
+    need = len(latents) * (1 + n_partial)
+    if need > gal.G:
+        n_partial = max(0, gal.G // max(1, len(latents)) - 1)
+        need = len(latents) * (1 + n_partial)
+    slots = rng.permutation(gal.G)[:need].reshape(len(latents), 1 + n_partial) if need else np.zeros((len(latents), 0), int)
+    planted: Dict[int, List[Tuple[int, float]]] = {}
+    fracs = [0.8, 0.5, 0.35, 0.25, 0.2, 0.15][:1 + n_partial]
+    for q, L in enumerate(latents):
+        planted[q] = []
+        for s, frac in zip(slots[q], fracs):
+            g = int(s)
+            nm = int(gal.minu_off[g + 1] - gal.minu_off[g]); nt = int(gal.tex_off[g + 1] - gal.tex_off[g])
+            gal.set_template(g, make_mate(rng, cb, L, frac=frac, sigma=0.08, n_minu=nm, n_tex=nt))
+            planted[q].append((g, frac))
+    return planted
