@@ -1,0 +1,151 @@
+/* afis_matcher.h — C ABI of the MI355X-native latent-vs-gallery matcher (libafis_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of prip-lab/MSU-LatentAFIS `matching/`: the body of the
+ * reference's OpenMP gallery loop (matching/matcher.cpp:168-190 == :273-295), i.e. everything reached from
+ * PQ::Matcher::One2One_matching_selected_templates (matcher.h:43) for every (latent, rolled) pair, plus the
+ * score fusion at matcher.cpp:188/:293.  The reference has no plugin/FFI interface of its own; a maintainer
+ * replaces the loop body with one afis_search() call (see INTEGRATION.md for the exact patch).
+ *
+ * Conventions: plain C types only, no exceptions cross the boundary, every function returns 0 on success or a
+ * negative AFIS_E* code (afis_last_error() gives the text).  A context is bound to ONE HIP device and is used
+ * by one host thread at a time (PQ::Matcher is not re-entrant either).  All pointers are HOST pointers; the
+ * library copies what it needs, the caller keeps ownership.  There is no CPU fallback: without a usable
+ * gfx950 device afis_create() fails.
+ */
+#ifndef AFIS_MATCHER_H
+#define AFIS_MATCHER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFIS_OK            0
+#define AFIS_EINVAL       -1   /* bad argument / unsupported shape                     */
+#define AFIS_EDEVICE      -2   /* HIP error, no device, out of device memory            */
+#define AFIS_ESTATE       -3   /* call order (search before commit, add after commit)   */
+#define AFIS_EFORMAT      -4   /* malformed template / codebook bytes                   */
+
+/* Per-query status, mirrors One2One_matching_selected_templates' return (matcher.cpp:383-391). */
+#define AFIS_QUERY_OK            0
+#define AFIS_QUERY_LATENT_EMPTY  1   /* whole query skipped, its scores are left at -1 (matcher.cpp:191-194) */
+
+typedef struct afis_ctx afis_ctx;   /* opaque; owns all device memory */
+
+/* One minutiae template (reference: MinutiaeTemplate, matching/include.h:203-252).  x,y in pixels. */
+typedef struct afis_minutiae_view {
+    int32_t        n;        /* number of minutiae (> 0; n <= 0 templates are dropped, matcher.cpp:835-836) */
+    const int16_t* x;        /* [n] */
+    const int16_t* y;        /* [n] */
+    const float*   ori;      /* [n] radians */
+    int32_t        des_len;  /* descriptor length, must be 96 on this path */
+    const float*   des;      /* [n][des_len] row-major fp32 */
+} afis_minutiae_view;
+
+/* One texture (virtual-minutiae) template.  x,y in BLOCK units ((px-24)/16).
+ * Latent (LatentTextureTemplate, include.h:298-364): des = fp32 [n][96], codes = NULL.
+ * Rolled (RolledTextureTemplatePQ, include.h:366-485): codes = u8 [n][16] PQ codes, des = NULL. */
+typedef struct afis_texture_view {
+    int32_t        n;
+    const int16_t* x;
+    const int16_t* y;
+    const float*   ori;
+    int32_t        des_len;  /* 96 (latent) or 16 (rolled) */
+    const float*   des;
+    const uint8_t* codes;
+} afis_texture_view;
+
+/* A whole fingerprint template (LatentFPTemplate / RolledFPTemplate, include.h:519-558), already stripped of
+ * zero-minutiae templates exactly as Matcher::load_FP_template does (indices are post-strip indices). */
+typedef struct afis_template_view {
+    int32_t                   n_minu;
+    const afis_minutiae_view* minu;
+    int32_t                   n_tex;
+    const afis_texture_view*  tex;
+} afis_template_view;
+
+/* Per-stage device time of the last afis_search call, milliseconds, from HIP events on the context's stream. */
+typedef struct afis_timing {
+    float   lut_ms;        /* S4  per-query LUT build                                  */
+    float   adc_ms;        /* S5+S6 texture ADC similarity + row arg-max (dominant)     */
+    float   tex_tail_ms;   /* S7+S8b+S9 on the texture correspondences                  */
+    float   minu_ms;       /* S1-S3+S8a+S9 for the three selected minutiae templates    */
+    float   fuse_ms;       /* S10 fusion                                                */
+    float   total_ms;      /* first kernel start .. last kernel end                     */
+    int32_t adc_launches;  /* number of ADC kernel launches in the call                 */
+    int64_t adc_lookups;   /* LUT look-ups performed by those launches                  */
+    int64_t pairs;         /* (query, gallery template) pairs scored                    */
+} afis_timing;
+
+/* Replaces PQ::Matcher::Matcher(code_file) (matcher.cpp:31-94).  codewords = [M][K][dsub] fp32 exactly as stored
+ * in the codebook .dat after its 3 x int16 header.  Only M=16, K=256, dsub=6 is supported. */
+int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, int device_id);
+/* Same, from the bytes of a codebook .dat file (3 x int16 header + floats). */
+int afis_create_from_codebook(afis_ctx** out, const void* codebook_bytes, size_t len, int device_id);
+void afis_destroy(afis_ctx* ctx);
+const char* afis_last_error(const afis_ctx* ctx);   /* ctx may be NULL: last afis_create failure */
+
+/* Gallery build: replaces the per-pair load_FP_template(rolled) at matcher.cpp:173/:278 — parse once, keep the
+ * gallery resident in HBM.  Only minutiae template 0 and texture template 0 of a rolled template are ever used
+ * by the reference (matcher.cpp:406,:413).  Templates keep insertion order; index = position. */
+int afis_gallery_add(afis_ctx* ctx, const afis_template_view* templates, int n);
+/* Parse one rolled .dat (layout of Matcher::load_FP_template(string, RolledFPTemplate&), matcher.cpp:886-983).
+ * *load_rc receives the reference's return code (0 ok, 1 empty file, 2, 4, -1); an entry is ALWAYS appended so
+ * indices stay aligned with the caller's file list (empty entry => score -1, matcher.cpp:184-187). */
+int afis_gallery_add_dat(afis_ctx* ctx, const void* bytes, size_t len, int* load_rc);
+/* Bulk add of n templates with exactly one minutiae and one texture template each, as concatenated arrays with
+ * CSR offsets (off[n+1], in points).  A zero-length range means "template absent". */
+int afis_gallery_add_packed(afis_ctx* ctx, int64_t n,
+                            const int64_t* minu_off, const int16_t* minu_x, const int16_t* minu_y,
+                            const float* minu_ori, const float* minu_des /* [sum][96] */,
+                            const int64_t* tex_off, const int16_t* tex_x, const int16_t* tex_y,
+                            const float* tex_ori, const uint8_t* tex_codes /* [sum][16] */);
+/* SoA-pack and upload.  index_base is added to every index afis_search reports (gallery sharding: each rank
+ * commits its contiguous shard with the shard's global offset). */
+int afis_gallery_commit(afis_ctx* ctx, int64_t index_base);
+int64_t afis_gallery_size(const afis_ctx* ctx);
+
+/* The hot path.  Replaces the body of the OpenMP loop of One2List_matching / List2List_matching
+ * (matcher.cpp:168-190, :273-295) for n_q latents at once.
+ *   scores      [n_q][G] or NULL : final fused score per gallery template, -1 where the rolled template is empty
+ *                                  (or for every entry of a latent-empty query)
+ *   parts       [n_q][G][4] or NULL : s0, s1, s2 (latent minutiae templates 26, 2, 11) and the texture score
+ *   status      [n_q] or NULL    : AFIS_QUERY_*
+ *   k, topk_idx [n_q][k], topk_score [n_q][k] : rank list, score descending, ties by ascending index
+ *                                  (the reference's tie order is unspecified, matcher.cpp:306-309); padded with
+ *                                  idx -1 when k > G.  k = 0 skips it. */
+int afis_search(afis_ctx* ctx, const afis_template_view* queries, int n_q,
+                float* scores, float* parts, int32_t* status,
+                int k, int64_t* topk_idx, float* topk_score);
+/* Same with the queries given as latent .dat bytes (Matcher::load_FP_template(string, LatentFPTemplate&),
+ * matcher.cpp:785-884). */
+int afis_search_dat(afis_ctx* ctx, const void* const* latent_bytes, const size_t* lens, int n_q,
+                    float* scores, float* parts, int32_t* status,
+                    int k, int64_t* topk_idx, float* topk_score);
+
+/* Queries resident in HBM before the timed region (bench): upload once, search many times. */
+typedef struct afis_queries afis_queries;
+int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_q, afis_queries** out);
+int afis_search_resident(afis_ctx* ctx, afis_queries* q,
+                         float* scores, float* parts, int32_t* status,
+                         int k, int64_t* topk_idx, float* topk_score);
+void afis_queries_free(afis_ctx* ctx, afis_queries* q);
+
+int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
+/* Tunables: "adc_variant" (0 = baseline LDS gather, 1 = phase-rotated), "query_batch" (latents per launch
+ * group), "chunk" (gallery templates per workgroup).  Returns AFIS_EINVAL for unknown names. */
+int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
+
+/* Parity-test taps (stage intermediates; not needed by a production caller). */
+/* S4: the per-query LUT of queries[0].tex[0], out = [n][16][256] in the reference's m_dist_codewords layout. */
+int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, int32_t* n_rows);
+/* S5+S6: row maxima / first arg-max of latent texture 0 vs gallery template g (g is shard-local). */
+int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, int64_t g,
+                              float* val, int32_t* arg, int32_t* n_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFIS_MATCHER_H */

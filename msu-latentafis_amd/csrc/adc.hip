@@ -1,0 +1,247 @@
+// adc.hip — S4 (per-query PQ look-up table) and S5+S6 (ADC similarity + per-row max / first arg-max).
+//
+// Reference: LatentTextureTemplate::compute_dist_to_codewords (matching/include.h:327-359) and
+// Matcher::One2One_texture_matching method 1 + row arg-max (matching/matcher.cpp:563-595, :723-735).
+//
+// S5 is fp32 add/sub only; with the reference's 4-accumulator order kept and FMA contraction off
+// (-ffp-contract=off) the results are bit-identical to the CPU.
+//
+// Work decomposition (MI355X): one workgroup keeps the LUT of kTileRows = 8 latent texture rows in LDS
+// (8 x 16 KB = 128 KB of the CU's 160 KB) and streams a chunk of gallery templates through it; every wave of
+// the workgroup owns whole gallery templates (lane <-> rolled texture point), so the per-row (max, argmax)
+// reduction is intra-wave only.  Blocks that share a gallery chunk are consecutive on one XCD (block b runs on
+// XCD b % 8) so the chunk's PQ codes are fetched from HBM once per XCD and re-read from that XCD's L2.
+#include "afis_device.h"
+
+namespace afis {
+
+// ---------------------------------------------------------------------------------------------------------------
+// S4.  lut[i][m][k] = sum_{d<6} (des[i][6m+d] - cw[m][k][d])^2, d ascending, product and sum rounded separately.
+// Tile layouts (float index inside the 32768-float tile of rows r = 0..7, rq = r/4, r4 = r%4):
+//   variant 0 : ((rq*16 + m)*256 + k)*4 + r4
+//   variant 1 : (((mg*256 + k)*4 + c)*2 + rq)*4 + r4   with m = 4*mg + c   (chain-major: bank slot depends on (c,rq))
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lut_entry(const float* __restrict__ des6, const float* __restrict__ cw6)
+{
+    float dist = 0.0f;
+#pragma unroll
+    for (int d = 0; d < kDsub; ++d) {
+        float t = des6[d] - cw6[d];
+        float t2 = t * t;
+        dist += t2;
+    }
+    return dist;
+}
+
+__global__ __launch_bounds__(256) void k_lut_build(QueryDev q, const float* __restrict__ codewords, float* __restrict__ lut_tiles, int variant)
+{
+    const int tile = blockIdx.x >> 4;                       // 16 blocks of 256 threads per tile = 4096 (m,k) entries
+    const int mk = ((blockIdx.x & 15) << 8) | threadIdx.x;
+    const int m = mk >> 8, k = mk & 255;
+    int qi = 0;
+    while (qi + 1 < q.nq && tile >= q.tile_off[qi + 1]) ++qi;
+    const int row0 = (tile - q.tile_off[qi]) * kTileRows;
+    const int base = q.lt_off[qi], n = q.lt_off[qi + 1] - base;
+    float cw6[kDsub];
+#pragma unroll
+    for (int d = 0; d < kDsub; ++d) cw6[d] = codewords[(m * kK + k) * kDsub + d];
+    float v[kTileRows];
+#pragma unroll
+    for (int r = 0; r < kTileRows; ++r) {
+        int row = row0 + r; if (row >= n) row = n - 1;       // padding rows duplicate the last row; never read back
+        const float* d6 = q.lt_des + (size_t)(base + row) * kDes + m * kDsub;
+        float des6[kDsub];
+#pragma unroll
+        for (int d = 0; d < kDsub; ++d) des6[d] = d6[d];
+        v[r] = lut_entry(des6, cw6);
+    }
+    float4* t4 = reinterpret_cast<float4*>(lut_tiles + (size_t)tile * kTileFloats);
+    if (variant == 0) {
+        t4[(0 * 16 + m) * 256 + k] = make_float4(v[0], v[1], v[2], v[3]);
+        t4[(1 * 16 + m) * 256 + k] = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        const int mg = m >> 2, c = m & 3;
+        t4[((mg * 256 + k) * 4 + c) * 2 + 0] = make_float4(v[0], v[1], v[2], v[3]);
+        t4[((mg * 256 + k) * 4 + c) * 2 + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lut_reference_layout(const float* __restrict__ des, int n, const float* __restrict__ codewords, float* __restrict__ out)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (i, m, k)
+    if (idx >= n * kM * kK) return;
+    const int i = idx / (kM * kK), mk = idx % (kM * kK), m = mk >> 8;
+    float des6[kDsub], cw6[kDsub];
+#pragma unroll
+    for (int d = 0; d < kDsub; ++d) { des6[d] = des[(size_t)i * kDes + m * kDsub + d]; cw6[d] = codewords[mk * kDsub + d]; }
+    out[idx] = lut_entry(des6, cw6);
+}
+
+hipError_t launch_lut_build(const QueryDev& q, const float* codewords, float* lut_tiles, int variant, hipStream_t stream)
+{
+    if (q.n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lut_build, dim3(q.n_tiles * 16), dim3(256), 0, stream, q, codewords, lut_tiles, variant);
+    return hipGetLastError();
+}
+
+hipError_t launch_lut_reference_layout(const float* des, int n, const float* codewords, float* out, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lut_reference_layout, dim3((n * kM * kK + 255) / 256), dim3(256), 0, stream, des, n, codewords, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// S5 + S6
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kAdcThreads = 512;       // 8 waves: 2 per SIMD
+constexpr int kAdcWaves = kAdcThreads / 64;
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i)
+{
+    // max value; on equal values the smaller point index (std::max_element returns the FIRST maximum)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        const bool take = (ov > v) || (ov == v && oi < i);
+        v = take ? ov : v;
+        i = take ? oi : i;
+    }
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
+                                                            int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
+{
+    __shared__ float4 s_lut[kTileFloats / 4];                 // 128 KB
+
+    // XCD-aware mapping: blocks with the same (b % 8) run on one XCD; walk all LUT tiles of one gallery chunk
+    // back-to-back there so the chunk's codes stay in that XCD's L2.
+    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
+    const int tile = seq % q.n_tiles;
+    const int chunk_id = (seq / q.n_tiles) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
+
+    int qi = 0;
+    while (qi + 1 < q.nq && tile >= q.tile_off[qi + 1]) ++qi;
+    const int row0 = (tile - q.tile_off[qi]) * kTileRows;
+    const int n_lt = q.lt_off[qi + 1] - q.lt_off[qi];
+
+    {   // stage the LUT tile: 128 KB, 16-byte coalesced
+        const float4* src = reinterpret_cast<const float4*>(lut_tiles + (size_t)tile * kTileFloats);
+        for (int i = threadIdx.x; i < kTileFloats / 4; i += kAdcThreads) s_lut[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g_lo = chunk_id * chunk;
+    const int g_hi = min(g.G, g_lo + chunk);
+
+    // variant 1: per-lane phase.  Lane phase (pc, pr) rotates which (chain, row-quad) the lane touches at each
+    // unrolled step, so the 16 lanes a ds_read_b128 services together spread over 8 distinct bank-slot classes.
+    const int pc = (lane >> 1) & 3, pr = lane & 1;
+    int sh[4], off8[8];
+    float init[4];
+    if (VARIANT == 1) {
+        const int perm[4] = {0, 2, 1, 3};                      // physical slot order (d1,d3,d2,d4): the final
+#pragma unroll                                                 // (P0+P2)+(P1+P3) is then rotation-invariant
+        for (int c = 0; c < 4; ++c) {
+            const int chain = perm[(c + pc) & 3];
+            sh[c] = 8 * chain;
+            init[c] = chain == 0 ? 6.0f : 0.0f;
+#pragma unroll
+            for (int rq = 0; rq < 2; ++rq) off8[c * 2 + rq] = chain * 2 + (rq ^ pr);
+        }
+    }
+
+    for (int gi = g_lo + wave; gi < g_hi; gi += kAdcWaves) {
+        const int p0 = g.tex_off[gi], n_pts = g.tex_off[gi + 1] - p0;
+        if (n_pts <= 0) continue;
+        float best[kTileRows];
+        int bidx[kTileRows];
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; }
+
+        for (int p = lane; p < n_pts; p += 64) {
+            const uint4 cw = g.tex_codes[p0 + p];
+            const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+            float acc[4][kTileRows];
+            if (VARIANT == 0) {
+#pragma unroll
+                for (int r = 0; r < kTileRows; ++r) { acc[0][r] = 6.0f; acc[1][r] = 0.0f; acc[2][r] = 0.0f; acc[3][r] = 0.0f; }  // matcher.cpp:571-574
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {              // chain c sees m = c, c+4, c+8, c+12 in this order (matcher.cpp:577-591)
+                        const int m = mg * 4 + c;
+                        const uint32_t code = (w[mg] >> (8 * c)) & 255u;
+                        const float4 a = s_lut[(0 * 16 + m) * 256 + code];
+                        const float4 bb = s_lut[(1 * 16 + m) * 256 + code];
+                        acc[c][0] -= a.x; acc[c][1] -= a.y; acc[c][2] -= a.z; acc[c][3] -= a.w;
+                        acc[c][4] -= bb.x; acc[c][5] -= bb.y; acc[c][6] -= bb.z; acc[c][7] -= bb.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < kTileRows; ++r) acc[c][r] = init[c];
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t code = __builtin_amdgcn_ubfe(w[mg], sh[c], 8);
+                        const int e = mg * 2048 + (int)code * 8;
+                        const float4 a = s_lut[e + off8[c * 2 + 0]];
+                        const float4 bb = s_lut[e + off8[c * 2 + 1]];
+                        acc[c][0] -= a.x; acc[c][1] -= a.y; acc[c][2] -= a.z; acc[c][3] -= a.w;
+                        acc[c][4] -= bb.x; acc[c][5] -= bb.y; acc[c][6] -= bb.z; acc[c][7] -= bb.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kTileRows; ++r) {
+                float s;
+                if (VARIANT == 0) s = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);                         // matcher.cpp:592
+                else s = (acc[0][r] + acc[2][r]) + (acc[1][r] + acc[3][r]);   // physical order (d1,d3,d2,d4) rotated: same two pair sums
+                if (s > best[r]) { best[r] = s; bidx[r] = p; }
+            }
+        }
+        if (VARIANT == 1 && pr) {                              // this lane kept rows 4..7 in slots 0..3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tv = best[r]; best[r] = best[r + 4]; best[r + 4] = tv;
+                int ti = bidx[r]; bidx[r] = bidx[r + 4]; bidx[r + 4] = ti;
+            }
+        }
+        float outv = 0.f; int outi = 0;
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) {
+            wave_argmax(best[r], bidx[r]);
+            if (lane == r) { outv = best[r]; outi = bidx[r]; }
+        }
+        if (lane < kTileRows && row0 + lane < n_lt) {
+            const size_t o = ((size_t)qi * g.G + gi) * q.lt_pad + row0 + lane;
+            rm_val[o] = outv;
+            rm_arg[o] = outi;
+        }
+    }
+}
+
+hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
+                             float* rm_val, int32_t* rm_arg, hipStream_t stream)
+{
+    if (q.n_tiles <= 0 || g.G <= 0) return hipSuccess;
+    const int n_chunks = (g.G + chunk - 1) / chunk;
+    const long long blocks = (long long)((n_chunks + 7) / 8) * 8 * q.n_tiles;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (variant == 0)
+        hipLaunchKernelGGL(k_adc_rowmax<0>, dim3((unsigned)blocks), dim3(kAdcThreads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg);
+    else
+        hipLaunchKernelGGL(k_adc_rowmax<1>, dim3((unsigned)blocks), dim3(kAdcThreads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg);
+    return hipGetLastError();
+}
+
+}  // namespace afis

@@ -1,0 +1,567 @@
+// afis_api.cpp — implementation of the C ABI in include/afis_matcher.h: gallery packing (SoA), upload, query
+// grouping and the launch sequence of the HIP kernels.  Host C++ only; device code lives in adc.hip / tail.hip.
+#include "../../include/afis_matcher.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "afis_device.h"
+#include "template_io.h"
+
+using namespace afis;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct HostGallery {
+    std::vector<int64_t> minu_off{0}, tex_off{0};
+    std::vector<int16_t> mx, my, tx, ty;
+    std::vector<float> mori, mdes, tori;
+    std::vector<uint8_t> tcodes;
+    std::vector<uint8_t> empty;
+    int64_t size() const { return (int64_t)empty.size(); }
+};
+
+}  // namespace
+
+// One group of latents resident on the device.
+struct QueryGroup {
+    QueryDev dev;
+    DevBuf lm_off, lm_xy, lm_ori, lm_des, lt_off, lt_xy, lt_ori, lt_des, tile_off, tex_slot, status;
+    int nq = 0; int max_nL = 0; int64_t lut_rows_x_tiles = 0;
+    std::vector<int32_t> h_lt_n;
+    void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
+                     lt_des.release(); tile_off.release(); tex_slot.release(); status.release(); }
+};
+
+struct afis_queries {
+    std::vector<QueryGroup> groups;
+    std::vector<int32_t> status;     // per query
+    int n_q = 0;
+};
+
+struct afis_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    std::string err;
+    DevBuf codewords, table;
+    HostGallery hg;
+    bool committed = false;
+    int64_t index_base = 0;
+    GalleryDev gal;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_empty;
+    int max_nR = 0;
+    int64_t total_tex_points = 0;
+    DevBuf lut, rm_val, rm_arg, parts, scores, scratch;
+    std::vector<float> h_scores, h_parts;
+    int adc_variant = 1;
+    int query_batch = 8;
+    int chunk = 64;
+    int64_t rowmax_budget_bytes = 24ll << 30;
+    afis_timing timing = {};
+};
+
+namespace {
+
+int fail(afis_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg; else g_create_error = msg;
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                                       \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                          \
+        return fail(ctx, AFIS_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+template <class T>
+hipError_t upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
+{
+    hipError_t e = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    return e;
+}
+
+void append_entry(HostGallery& hg, const afis_minutiae_view* m, const afis_texture_view* t)
+{
+    if (m && m->n > 0) {
+        hg.mx.insert(hg.mx.end(), m->x, m->x + m->n); hg.my.insert(hg.my.end(), m->y, m->y + m->n);
+        hg.mori.insert(hg.mori.end(), m->ori, m->ori + m->n);
+        hg.mdes.insert(hg.mdes.end(), m->des, m->des + (size_t)m->n * kDes);
+    }
+    hg.minu_off.push_back((int64_t)hg.mx.size());
+    if (t && t->n > 0) {
+        const int n = std::min(t->n, kTexMax);                              // matcher.cpp:546-547
+        hg.tx.insert(hg.tx.end(), t->x, t->x + n); hg.ty.insert(hg.ty.end(), t->y, t->y + n);
+        hg.tori.insert(hg.tori.end(), t->ori, t->ori + n);
+        hg.tcodes.insert(hg.tcodes.end(), t->codes, t->codes + (size_t)n * kM);
+    }
+    hg.tex_off.push_back((int64_t)hg.tx.size());
+    hg.empty.push_back((!(m && m->n > 0) && !(t && t->n > 0)) ? 1 : 0);
+}
+
+int check_rolled(afis_ctx* ctx, const afis_template_view& t)
+{
+    if (t.n_minu < 0 || t.n_tex < 0 || (t.n_minu > 0 && !t.minu) || (t.n_tex > 0 && !t.tex)) return fail(ctx, AFIS_EINVAL, "rolled template: bad view");
+    if (t.n_minu > 0) {
+        const afis_minutiae_view& m = t.minu[0];
+        if (m.n <= 0 || m.n > 2000 || !m.x || !m.y || !m.ori || !m.des) return fail(ctx, AFIS_EINVAL, "rolled minutiae template: bad view (n must be 1..2000)");
+        if (m.des_len != kDes) return fail(ctx, AFIS_EINVAL, "rolled minutiae template: des_len must be 96");
+    }
+    if (t.n_tex > 0) {
+        const afis_texture_view& x = t.tex[0];
+        if (x.n <= 0 || x.n > 2000 || !x.x || !x.y || !x.ori || !x.codes) return fail(ctx, AFIS_EINVAL, "rolled texture template: bad view (n must be 1..2000, codes required)");
+        if (x.des_len != kM) return fail(ctx, AFIS_EINVAL, "rolled texture template: des_len must be 16 (PQ codes)");
+    }
+    return AFIS_OK;
+}
+
+void views_of(const HostTemplate& t, std::vector<afis_minutiae_view>& mv, std::vector<afis_texture_view>& tv, afis_template_view& out)
+{
+    mv.clear(); tv.clear();
+    for (const HostMinutiae& m : t.minu) mv.push_back({m.n(), m.x.data(), m.y.data(), m.ori.data(), m.des_len, m.des.data()});
+    for (const HostTexture& x : t.tex) tv.push_back({x.n(), x.x.data(), x.y.data(), x.ori.data(), x.des_len, x.des.empty() ? nullptr : x.des.data(), x.codes.empty() ? nullptr : x.codes.data()});
+    out.n_minu = (int)mv.size(); out.minu = mv.data(); out.n_tex = (int)tv.size(); out.tex = tv.data();
+}
+
+void free_gallery_dev(afis_ctx* c)
+{
+    c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release();
+    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_empty.release();
+}
+
+}  // namespace
+
+extern "C" {
+
+int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, int device_id)
+{
+    if (!out || !codewords) return fail(nullptr, AFIS_EINVAL, "afis_create: null argument");
+    *out = nullptr;
+    if (M != kM || K != kK || dsub != kDsub) return fail(nullptr, AFIS_EINVAL, "afis_create: only the M=16, K=256, dsub=6 codebook geometry is supported");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(nullptr, AFIS_EDEVICE, "afis_create: no HIP device (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= n_dev) return fail(nullptr, AFIS_EINVAL, "afis_create: device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, AFIS_EDEVICE, "afis_create: hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, AFIS_EDEVICE, std::string("afis_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+    afis_ctx* c = new afis_ctx();
+    c->device = device_id;
+#define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); afis_destroy(c); return AFIS_EDEVICE; } } while (0)
+    CRCHK(hipSetDevice(device_id));
+    CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) CRCHK(hipEventCreate(&e));
+    std::vector<float> cw(codewords, codewords + (size_t)M * K * dsub);
+    CRCHK(upload(c->codewords, cw, c->stream));
+    std::vector<float> table((size_t)kDistN * kDistN);                     // matcher.cpp:45-56
+    for (int i = 0; i < kDistN; ++i)
+        for (int j = i; j < kDistN; ++j) {
+            table[i * kDistN + j] = (float)sqrt((i * 16.0) * (i * 16.0) + (j * 16.0) * (j * 16.0));
+            table[j * kDistN + i] = table[i * kDistN + j];
+        }
+    CRCHK(upload(c->table, table, c->stream));
+    CRCHK(hipStreamSynchronize(c->stream));
+#undef CRCHK
+    *out = c;
+    return AFIS_OK;
+}
+
+int afis_create_from_codebook(afis_ctx** out, const void* bytes, size_t len, int device_id)
+{
+    HostCodebook cb;
+    if (!bytes || !parse_codebook(bytes, len, cb)) return fail(nullptr, AFIS_EFORMAT, "codebook is empty!");
+    return afis_create(out, cb.words.data(), cb.M, cb.K, cb.dsub, device_id);
+}
+
+void afis_destroy(afis_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_gallery_dev(c);
+    c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
+    c->parts.release(); c->scores.release(); c->scratch.release();
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* afis_last_error(const afis_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int afis_gallery_add(afis_ctx* ctx, const afis_template_view* t, int n)
+{
+    if (!ctx || (n > 0 && !t)) return fail(ctx, AFIS_EINVAL, "afis_gallery_add: null argument");
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add: gallery already committed");
+    for (int i = 0; i < n; ++i) { int rc = check_rolled(ctx, t[i]); if (rc) return rc; }
+    for (int i = 0; i < n; ++i)
+        append_entry(ctx->hg, t[i].n_minu > 0 ? &t[i].minu[0] : nullptr, t[i].n_tex > 0 ? &t[i].tex[0] : nullptr);
+    return AFIS_OK;
+}
+
+int afis_gallery_add_dat(afis_ctx* ctx, const void* bytes, size_t len, int* load_rc)
+{
+    if (!ctx) return AFIS_EINVAL;
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add_dat: gallery already committed");
+    HostTemplate t;
+    int rc = parse_rolled_dat(bytes, len, t);
+    if (rc < 0) { t.minu.clear(); t.tex.clear(); }                          // matcher.cpp:173-177
+    if (load_rc) *load_rc = rc;
+    std::vector<afis_minutiae_view> mv; std::vector<afis_texture_view> tv; afis_template_view v;
+    views_of(t, mv, tv, v);
+    int ok = check_rolled(ctx, v);
+    if (ok != AFIS_OK) return ok;
+    append_entry(ctx->hg, v.n_minu > 0 ? &v.minu[0] : nullptr, v.n_tex > 0 ? &v.tex[0] : nullptr);
+    return AFIS_OK;
+}
+
+int afis_gallery_add_packed(afis_ctx* ctx, int64_t n, const int64_t* minu_off, const int16_t* minu_x, const int16_t* minu_y,
+                            const float* minu_ori, const float* minu_des, const int64_t* tex_off, const int16_t* tex_x,
+                            const int16_t* tex_y, const float* tex_ori, const uint8_t* tex_codes)
+{
+    if (!ctx || n < 0 || !minu_off || !tex_off) return fail(ctx, AFIS_EINVAL, "afis_gallery_add_packed: null argument");
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add_packed: gallery already committed");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t nm = minu_off[i + 1] - minu_off[i], nt = tex_off[i + 1] - tex_off[i];
+        if (nm < 0 || nm > 2000 || nt < 0 || nt > 2000) return fail(ctx, AFIS_EINVAL, "afis_gallery_add_packed: template point count must be 0..2000");
+    }
+    HostGallery& hg = ctx->hg;
+    const int64_t m0 = minu_off[0], m1 = minu_off[n], t0 = tex_off[0];
+    hg.mx.insert(hg.mx.end(), minu_x + m0, minu_x + m1); hg.my.insert(hg.my.end(), minu_y + m0, minu_y + m1);
+    hg.mori.insert(hg.mori.end(), minu_ori + m0, minu_ori + m1);
+    hg.mdes.insert(hg.mdes.end(), minu_des + m0 * kDes, minu_des + m1 * kDes);
+    const int64_t mbase = hg.minu_off.back() - m0;
+    for (int64_t i = 0; i < n; ++i) {
+        hg.minu_off.push_back(minu_off[i + 1] + mbase);
+        const int64_t a = tex_off[i], nt = std::min<int64_t>(tex_off[i + 1] - a, kTexMax);
+        hg.tx.insert(hg.tx.end(), tex_x + a, tex_x + a + nt); hg.ty.insert(hg.ty.end(), tex_y + a, tex_y + a + nt);
+        hg.tori.insert(hg.tori.end(), tex_ori + a, tex_ori + a + nt);
+        hg.tcodes.insert(hg.tcodes.end(), tex_codes + a * kM, tex_codes + (a + nt) * kM);
+        hg.tex_off.push_back((int64_t)hg.tx.size());
+        hg.empty.push_back((minu_off[i + 1] == minu_off[i] && nt == 0) ? 1 : 0);
+    }
+    (void)t0;
+    return AFIS_OK;
+}
+
+int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
+{
+    if (!ctx) return AFIS_EINVAL;
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_commit: already committed");
+    HostGallery& hg = ctx->hg;
+    const int64_t G = hg.size();
+    if (G > 0x7fffffff / 8 || hg.mx.size() > 0x7fffffffull || hg.tx.size() > 0x7fffffffull)
+        return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for 32-bit point offsets; split the gallery into more shards");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> mo(G + 1), to(G + 1);
+    int max_nR = 0;
+    for (int64_t i = 0; i <= G; ++i) { mo[i] = (int32_t)hg.minu_off[i]; to[i] = (int32_t)hg.tex_off[i]; }
+    for (int64_t i = 0; i < G; ++i) max_nR = std::max(max_nR, mo[i + 1] - mo[i]);
+    std::vector<short2> mxy(hg.mx.size()), txy(hg.tx.size());
+    for (size_t i = 0; i < mxy.size(); ++i) mxy[i] = make_short2(hg.mx[i], hg.my[i]);
+    for (size_t i = 0; i < txy.size(); ++i) txy[i] = make_short2(hg.tx[i], hg.ty[i]);
+    HIPCHK(ctx, upload(ctx->g_minu_off, mo, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_minu_xy, mxy, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_minu_ori, hg.mori, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_minu_des, hg.mdes, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_tex_off, to, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_tex_codes, hg.tcodes, ctx->stream));
+    HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    GalleryDev& g = ctx->gal;
+    g.G = (int32_t)G;
+    g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
+    g.minu_des = ctx->g_minu_des.as<float>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
+    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.empty = ctx->g_empty.as<uint8_t>();
+    ctx->max_nR = max_nR;
+    ctx->total_tex_points = (int64_t)hg.tx.size();
+    ctx->index_base = index_base;
+    ctx->committed = true;
+    // the host staging copy is no longer needed
+    HostGallery keep; keep.empty = hg.empty; keep.minu_off.clear(); keep.tex_off.clear();
+    std::vector<uint8_t> e = hg.empty;
+    ctx->hg = HostGallery(); ctx->hg.empty = std::move(e);
+    return AFIS_OK;
+}
+
+int64_t afis_gallery_size(const afis_ctx* ctx) { return ctx ? (int64_t)ctx->hg.empty.size() : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, QueryGroup& grp, std::vector<int32_t>& status_out)
+{
+    static const int sel[3] = {27 - 1, 3 - 1, 12 - 1};                     // matcher.cpp:380
+    std::vector<int32_t> lm_off{0}, lt_off{0}, tile_off{0}, tex_slot, status;
+    std::vector<short2> lm_xy, lt_xy; std::vector<float> lm_ori, lm_des, lt_ori, lt_des;
+    int max_nL = 0, lt_max = 0;
+    for (int i = 0; i < nq; ++i) {
+        const afis_template_view& t = qs[i];
+        if (t.n_minu < 0 || t.n_tex < 0 || (t.n_minu > 0 && !t.minu) || (t.n_tex > 0 && !t.tex)) return fail(ctx, AFIS_EINVAL, "latent template: bad view");
+        const bool latent_empty = (t.n_minu <= sel[0] && t.n_tex <= 0);     // matcher.cpp:383-386
+        status.push_back(latent_empty ? AFIS_QUERY_LATENT_EMPTY : AFIS_QUERY_OK);
+        for (int s = 0; s < 3; ++s) {
+            if (!latent_empty && t.n_minu > sel[s]) {
+                const afis_minutiae_view& m = t.minu[sel[s]];
+                if (m.n <= 0 || m.n > 2000 || !m.x || !m.y || !m.ori || !m.des) return fail(ctx, AFIS_EINVAL, "latent minutiae template: bad view (n must be 1..2000)");
+                if (m.des_len != kDes) return fail(ctx, AFIS_EINVAL, "latent minutiae template: des_len must be 96 (the reference asserts equal descriptor lengths, matcher.cpp:433)");
+                for (int k = 0; k < m.n; ++k) lm_xy.push_back(make_short2(m.x[k], m.y[k]));
+                lm_ori.insert(lm_ori.end(), m.ori, m.ori + m.n);
+                lm_des.insert(lm_des.end(), m.des, m.des + (size_t)m.n * kDes);
+                max_nL = std::max(max_nL, m.n);
+            }
+            lm_off.push_back((int32_t)lm_xy.size());
+        }
+        int n_lt = 0;
+        if (!latent_empty && t.n_tex > 0) {
+            const afis_texture_view& x = t.tex[0];
+            if (x.n <= 0 || x.n > 2000 || !x.x || !x.y || !x.ori || !x.des) return fail(ctx, AFIS_EINVAL, "latent texture template: bad view (n must be 1..2000, des required)");
+            if (x.des_len != kDes) return fail(ctx, AFIS_EINVAL, "latent texture template: des_len must be 96");
+            n_lt = std::min(x.n, kTexMax);                                   // matcher.cpp:544-545
+            for (int k = 0; k < n_lt; ++k) lt_xy.push_back(make_short2(x.x[k], x.y[k]));
+            lt_ori.insert(lt_ori.end(), x.ori, x.ori + n_lt);
+            lt_des.insert(lt_des.end(), x.des, x.des + (size_t)n_lt * kDes);
+        }
+        lt_off.push_back((int32_t)lt_xy.size());
+        tile_off.push_back(tile_off.back() + (n_lt + kTileRows - 1) / kTileRows);
+        tex_slot.push_back(t.n_tex > 0 ? t.n_minu : -1);
+        lt_max = std::max(lt_max, n_lt);
+        grp.h_lt_n.push_back(n_lt);
+    }
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, upload(grp.lm_off, lm_off, s)); HIPCHK(ctx, upload(grp.lm_xy, lm_xy, s)); HIPCHK(ctx, upload(grp.lm_ori, lm_ori, s));
+    HIPCHK(ctx, upload(grp.lm_des, lm_des, s)); HIPCHK(ctx, upload(grp.lt_off, lt_off, s)); HIPCHK(ctx, upload(grp.lt_xy, lt_xy, s));
+    HIPCHK(ctx, upload(grp.lt_ori, lt_ori, s)); HIPCHK(ctx, upload(grp.lt_des, lt_des, s)); HIPCHK(ctx, upload(grp.tile_off, tile_off, s));
+    HIPCHK(ctx, upload(grp.tex_slot, tex_slot, s)); HIPCHK(ctx, upload(grp.status, status, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    QueryDev& d = grp.dev;
+    d.nq = nq;
+    d.lm_off = grp.lm_off.as<int32_t>(); d.lm_xy = grp.lm_xy.as<short2>(); d.lm_ori = grp.lm_ori.as<float>(); d.lm_des = grp.lm_des.as<float>();
+    d.lt_off = grp.lt_off.as<int32_t>(); d.lt_xy = grp.lt_xy.as<short2>(); d.lt_ori = grp.lt_ori.as<float>(); d.lt_des = grp.lt_des.as<float>();
+    d.tile_off = grp.tile_off.as<int32_t>(); d.tex_slot = grp.tex_slot.as<int32_t>(); d.status = grp.status.as<int32_t>();
+    d.n_tiles = tile_off.back();
+    d.lt_pad = std::max(kTileRows, (lt_max + kTileRows - 1) / kTileRows * kTileRows);
+    grp.nq = nq; grp.max_nL = max_nL;
+    status_out.insert(status_out.end(), status.begin(), status.end());
+    return AFIS_OK;
+}
+
+int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_q, afis_queries** out)
+{
+    if (!ctx || !out || n_q < 0 || (n_q > 0 && !queries)) return fail(ctx, AFIS_EINVAL, "afis_queries_upload: bad argument");
+    if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_queries_upload: commit the gallery first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // group size: bounded by the option and by the rowmax buffer budget (nq * G * 1000 rows * 8 B)
+    const int64_t G = std::max<int64_t>(1, ctx->gal.G);
+    int64_t by_mem = ctx->rowmax_budget_bytes / (G * kTexMax * 8);
+    int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch, by_mem));
+    afis_queries* q = new afis_queries();
+    q->n_q = n_q;
+    for (int i = 0; i < n_q; i += per) {
+        q->groups.emplace_back();
+        int rc = build_group(ctx, queries + i, std::min(per, n_q - i), q->groups.back(), q->status);
+        if (rc != AFIS_OK) { afis_queries_free(ctx, q); return rc; }
+    }
+    *out = q;
+    return AFIS_OK;
+}
+
+void afis_queries_free(afis_ctx* ctx, afis_queries* q)
+{
+    if (!q) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (QueryGroup& g : q->groups) g.release();
+    delete q;
+}
+
+int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* parts, int32_t* status,
+                         int k, int64_t* topk_idx, float* topk_score)
+{
+    if (!ctx || !q) return fail(ctx, AFIS_EINVAL, "afis_search_resident: null argument");
+    if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_search: commit the gallery first");
+    if (k < 0 || (k > 0 && (!topk_idx || !topk_score))) return fail(ctx, AFIS_EINVAL, "afis_search: k > 0 needs topk_idx and topk_score");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const GalleryDev& g = ctx->gal;
+    const int64_t G = g.G;
+    afis_timing tm = {};
+    if (status) for (int i = 0; i < q->n_q; ++i) status[i] = q->status[i];
+    int q0 = 0;
+    for (QueryGroup& grp : q->groups) {
+        const QueryDev& d = grp.dev;
+        const int nq = grp.nq;
+        if (G > 0) {
+            const size_t n_pairs = (size_t)nq * G;
+            HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));
+            HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
+            HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
+            HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
+            HIPCHK(ctx, ctx->scores.ensure(n_pairs * 4));
+            // minutiae scratch: simi + keys per workgroup
+            size_t per_wg = 2 * (size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR);
+            per_wg = (per_wg + 63) / 64 * 64;
+            int n_wg = 1024;
+            while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
+            HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
+            hipStream_t s = ctx->stream;
+            HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+            HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+            HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), ctx->chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+            HIPCHK(ctx, launch_texture_tail(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+            HIPCHK(ctx, launch_minutiae(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->parts.as<float>(), s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+            HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
+            HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
+            ctx->h_scores.resize(n_pairs);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_scores.data(), ctx->scores.p, n_pairs * 4, hipMemcpyDeviceToHost, s));
+            if (parts) HIPCHK(ctx, hipMemcpyAsync(parts + (size_t)q0 * G * 4, ctx->parts.p, n_pairs * 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipStreamSynchronize(s));
+            float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
+            for (int i = 0; i < 5; ++i) HIPCHK(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+            HIPCHK(ctx, hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[5]));
+            tm.lut_ms += ms[0]; tm.adc_ms += ms[1]; tm.tex_tail_ms += ms[2]; tm.minu_ms += ms[3]; tm.fuse_ms += ms[4]; tm.total_ms += tot;
+            if (d.n_tiles > 0) {
+                tm.adc_launches += 1;
+                int64_t rows = 0; for (int n : grp.h_lt_n) rows += (n + kTileRows - 1) / kTileRows * kTileRows;
+                tm.adc_lookups += rows * ctx->total_tex_points * kM;
+            }
+            tm.pairs += (int64_t)n_pairs;
+            if (scores) memcpy(scores + (size_t)q0 * G, ctx->h_scores.data(), n_pairs * 4);
+        }
+        // rank lists (matcher.cpp:306-309; ties by ascending index)
+        if (k > 0) {
+            std::vector<int32_t> ind((size_t)G);
+            for (int i = 0; i < nq; ++i) {
+                const float* sc = ctx->h_scores.data() + (size_t)i * G;
+                std::iota(ind.begin(), ind.end(), 0);
+                const int kk = (int)std::min<int64_t>(k, G);
+                std::partial_sort(ind.begin(), ind.begin() + kk, ind.end(), [sc](int a, int b) { return sc[a] > sc[b] || (sc[a] == sc[b] && a < b); });
+                for (int r = 0; r < k; ++r) {
+                    const size_t o = (size_t)(q0 + i) * k + r;
+                    if (r < kk) { topk_idx[o] = ctx->index_base + ind[r]; topk_score[o] = sc[ind[r]]; }
+                    else { topk_idx[o] = -1; topk_score[o] = -INFINITY; }
+                }
+            }
+        }
+        q0 += nq;
+    }
+    ctx->timing = tm;
+    return AFIS_OK;
+}
+
+int afis_search(afis_ctx* ctx, const afis_template_view* queries, int n_q, float* scores, float* parts, int32_t* status,
+                int k, int64_t* topk_idx, float* topk_score)
+{
+    afis_queries* q = nullptr;
+    int rc = afis_queries_upload(ctx, queries, n_q, &q);
+    if (rc != AFIS_OK) return rc;
+    rc = afis_search_resident(ctx, q, scores, parts, status, k, topk_idx, topk_score);
+    afis_queries_free(ctx, q);
+    return rc;
+}
+
+int afis_search_dat(afis_ctx* ctx, const void* const* latent_bytes, const size_t* lens, int n_q, float* scores, float* parts,
+                    int32_t* status, int k, int64_t* topk_idx, float* topk_score)
+{
+    if (!ctx || n_q < 0 || (n_q > 0 && (!latent_bytes || !lens))) return fail(ctx, AFIS_EINVAL, "afis_search_dat: bad argument");
+    std::vector<HostTemplate> ts(n_q);
+    std::vector<std::vector<afis_minutiae_view>> mv(n_q);
+    std::vector<std::vector<afis_texture_view>> tv(n_q);
+    std::vector<afis_template_view> views(n_q);
+    for (int i = 0; i < n_q; ++i) {
+        (void)parse_latent_dat(latent_bytes[i], lens[i], ts[i]);           // the reference ignores this return code (matcher.cpp:150)
+        views_of(ts[i], mv[i], tv[i], views[i]);
+    }
+    return afis_search(ctx, views.data(), n_q, scores, parts, status, k, topk_idx, topk_score);
+}
+
+int afis_get_timing(const afis_ctx* ctx, afis_timing* out)
+{
+    if (!ctx || !out) return AFIS_EINVAL;
+    *out = ctx->timing;
+    return AFIS_OK;
+}
+
+int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
+{
+    if (!ctx || !name) return AFIS_EINVAL;
+    const std::string n(name);
+    if (n == "adc_variant") { if (value < 0 || value > 1) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0 or 1"); ctx->adc_variant = (int)value; }
+    else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
+    else if (n == "chunk") { if (value < 1 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 1..65536"); ctx->chunk = (int)value; }
+    else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
+    else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
+    return AFIS_OK;
+}
+
+int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, int32_t* n_rows)
+{
+    if (!ctx || !query || !out) return fail(ctx, AFIS_EINVAL, "afis_debug_lut: null argument");
+    if (query->n_tex <= 0) { if (n_rows) *n_rows = 0; return AFIS_OK; }
+    const afis_texture_view& x = query->tex[0];
+    if (x.des_len != kDes || !x.des) return fail(ctx, AFIS_EINVAL, "afis_debug_lut: latent texture template needs fp32 descriptors of length 96");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf des, lut;
+    std::vector<float> h(x.des, x.des + (size_t)x.n * kDes);
+    HIPCHK(ctx, upload(des, h, ctx->stream));
+    HIPCHK(ctx, lut.ensure((size_t)x.n * kM * kK * 4));
+    HIPCHK(ctx, launch_lut_reference_layout(des.as<float>(), x.n, ctx->codewords.as<float>(), lut.as<float>(), ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out, lut.p, (size_t)x.n * kM * kK * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    des.release(); lut.release();
+    if (n_rows) *n_rows = x.n;
+    return AFIS_OK;
+}
+
+int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, int64_t gidx, float* val, int32_t* arg, int32_t* n_rows)
+{
+    if (!ctx || !query || !val || !arg) return fail(ctx, AFIS_EINVAL, "afis_debug_texture_rowmax: null argument");
+    if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_debug_texture_rowmax: commit the gallery first");
+    if (gidx < 0 || gidx >= ctx->gal.G) return fail(ctx, AFIS_EINVAL, "afis_debug_texture_rowmax: gallery index out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    QueryGroup grp; std::vector<int32_t> st;
+    int rc = build_group(ctx, query, 1, grp, st);
+    if (rc != AFIS_OK) { grp.release(); return rc; }
+    const QueryDev& d = grp.dev;
+    const int n_lt = grp.h_lt_n[0];
+    if (n_rows) *n_rows = n_lt;
+    if (n_lt > 0) {
+        const size_t n_pairs = (size_t)ctx->gal.G;
+        HIPCHK(ctx, ctx->lut.ensure((size_t)d.n_tiles * kTileFloats * 4));
+        HIPCHK(ctx, ctx->rm_val.ensure(n_pairs * d.lt_pad * 4));
+        HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * d.lt_pad * 4));
+        HIPCHK(ctx, hipMemsetAsync(ctx->rm_val.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->rm_arg.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
+        HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, ctx->stream));
+        HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(val, ctx->rm_val.as<float>() + (size_t)gidx * d.lt_pad, (size_t)n_lt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(arg, ctx->rm_arg.as<int32_t>() + (size_t)gidx * d.lt_pad, (size_t)n_lt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    grp.release();
+    return AFIS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// afis_device.h — device-side data layout and kernel launchers shared by the HIP translation units.
+// gfx950 (MI355X / CDNA4) only; wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afis {
+
+constexpr int kM = 16;            // PQ sub-quantizers         (codebook header, matcher.cpp:74)
+constexpr int kK = 256;           // codewords per sub-quantizer
+constexpr int kDsub = 6;          // dims per sub-quantizer
+constexpr int kDes = 96;          // descriptor length
+constexpr int kTexMax = 1000;     // MaxNRolledMinu / MaxNLatentMinu, matcher.h:31-32
+constexpr int kTopTex = 200;      // Matcher::N, matcher.cpp:33
+constexpr int kTopMinu = 120;     // topN, matcher.cpp:479
+constexpr int kDistN = 50;        // dist_N, matcher.cpp:45
+constexpr int kTileRows = 8;      // latent texture rows whose LUT one workgroup keeps in LDS (8*16 KB = 128 KB)
+constexpr int kTileFloats = kTileRows * kM * kK;   // 32768 floats per LUT tile
+
+// Rolled gallery shard, SoA in HBM.  Points of all templates are concatenated; *_off are CSR offsets.
+struct GalleryDev {
+    int32_t G = 0;
+    const int32_t* minu_off = nullptr;   // [G+1]
+    const short2*  minu_xy = nullptr;    // [NM]   pixel coords
+    const float*   minu_ori = nullptr;   // [NM]
+    const float*   minu_des = nullptr;   // [NM][96]
+    const int32_t* tex_off = nullptr;    // [G+1]  (counts already clamped to 1000)
+    const short2*  tex_xy = nullptr;     // [NT]   block coords
+    const float*   tex_ori = nullptr;    // [NT]
+    const uint4*   tex_codes = nullptr;  // [NT]   16 PQ code bytes per point, byte m = sub-quantizer m
+    const uint8_t* empty = nullptr;      // [G] 1 = rolled template has neither minutiae nor texture (score -1)
+};
+
+// A group of latents resident on the device (selected minutiae templates 26, 2, 11 + texture template 0).
+struct QueryDev {
+    int32_t nq = 0;
+    const int32_t* lm_off = nullptr;     // [nq*3+1] minutiae points of (query, selected template s); empty range = absent
+    const short2*  lm_xy = nullptr;
+    const float*   lm_ori = nullptr;
+    const float*   lm_des = nullptr;     // [NLM][96]
+    const int32_t* lt_off = nullptr;     // [nq+1] texture rows (clamped to 1000)
+    const short2*  lt_xy = nullptr;
+    const float*   lt_ori = nullptr;
+    const float*   lt_des = nullptr;     // [NLT][96]
+    const int32_t* tile_off = nullptr;   // [nq+1] LUT tiles (8 rows each) per query
+    const int32_t* tex_slot = nullptr;   // [nq] index of the texture score in the reference's score vector (= #latent minutiae templates), -1 = no texture
+    const int32_t* status = nullptr;     // [nq] AFIS_QUERY_*
+    int32_t n_tiles = 0;
+    int32_t lt_pad = 0;                  // row stride of the rowmax buffers (max rows over the group, multiple of 8)
+};
+
+// ---- launchers (each enqueues on `stream`, returns hipGetLastError()) ------------------------------------------
+// S4: LUT tiles.  variant selects the in-tile layout the ADC kernel of the same variant reads.
+hipError_t launch_lut_build(const QueryDev& q, const float* codewords, float* lut_tiles, int variant, hipStream_t stream);
+// S5+S6: ADC similarity + per-row (max, first argmax) for queries [q0, q0+nq) against gallery templates.
+hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
+                             float* rm_val, int32_t* rm_arg, hipStream_t stream);
+// S7+S8b+S9: texture tail -> parts[(q*G+g)*4+3]
+hipError_t launch_texture_tail(const QueryDev& q, const GalleryDev& g, const float* table_dist,
+                               const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream);
+// S1-S3+S8a+S9 for the three selected latent minutiae templates -> parts[(q*G+g)*4+{0,1,2}]
+hipError_t launch_minutiae(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
+                           float* parts, hipStream_t stream);
+// S10: fusion -> scores[q*G+g]
+hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
+
+// debug tap: LUT in the reference layout [n][16][256]
+hipError_t launch_lut_reference_layout(const float* des, int n, const float* codewords, float* out, hipStream_t stream);
+
+}  // namespace afis

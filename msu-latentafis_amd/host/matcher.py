@@ -1,0 +1,276 @@
+"""ctypes binding of libafis_hip.so (include/afis_matcher.h) with the reference's `PQ::Matcher` surface.
+
+Mirrors matching/matcher.h:35-51: Matcher(code_file), One2List_matching, List2List_matching, plus the in-memory
+calls the C ABI adds (gallery add/commit, batched search).  There is NO CPU fallback: if the HIP library is missing
+or no gfx950 device is present, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import glob
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .templates import Codebook, FPTemplate, read_latent, read_rolled
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libafis_hip.so")
+
+
+class AfisError(RuntimeError):
+    pass
+
+
+class MinutiaeView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.POINTER(C.c_int16)), ("y", C.POINTER(C.c_int16)), ("ori", C.POINTER(C.c_float)),
+                ("des_len", C.c_int32), ("des", C.POINTER(C.c_float))]
+
+
+class TextureView(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", C.POINTER(C.c_int16)), ("y", C.POINTER(C.c_int16)), ("ori", C.POINTER(C.c_float)),
+                ("des_len", C.c_int32), ("des", C.POINTER(C.c_float)), ("codes", C.POINTER(C.c_uint8))]
+
+
+class TemplateView(C.Structure):
+    _fields_ = [("n_minu", C.c_int32), ("minu", C.POINTER(MinutiaeView)), ("n_tex", C.c_int32), ("tex", C.POINTER(TextureView))]
+
+
+class Timing(C.Structure):
+    _fields_ = [("lut_ms", C.c_float), ("adc_ms", C.c_float), ("tex_tail_ms", C.c_float), ("minu_ms", C.c_float), ("fuse_ms", C.c_float),
+                ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64)]
+
+
+EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
+           "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_search", "afis_search_dat", "afis_queries_upload",
+           "afis_search_resident", "afis_queries_free", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax"]
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise AfisError(f"{path} not found: build it with `make -C msu-latentafis_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32p, i64p, fp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    lib.afis_create.argtypes = [C.POINTER(vp), fp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.afis_create_from_codebook.argtypes = [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_int]
+    lib.afis_destroy.argtypes = [vp]; lib.afis_destroy.restype = None
+    lib.afis_last_error.argtypes = [vp]; lib.afis_last_error.restype = C.c_char_p
+    lib.afis_gallery_add.argtypes = [vp, C.POINTER(TemplateView), C.c_int]
+    lib.afis_gallery_add_dat.argtypes = [vp, C.c_char_p, C.c_size_t, i32p]
+    lib.afis_gallery_add_packed.argtypes = [vp, C.c_int64, i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, fp,
+                                            i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, C.POINTER(C.c_uint8)]
+    lib.afis_gallery_commit.argtypes = [vp, C.c_int64]
+    lib.afis_gallery_size.argtypes = [vp]; lib.afis_gallery_size.restype = C.c_int64
+    lib.afis_search.argtypes = [vp, C.POINTER(TemplateView), C.c_int, fp, fp, i32p, C.c_int, i64p, fp]
+    lib.afis_search_dat.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, fp, fp, i32p, C.c_int, i64p, fp]
+    lib.afis_queries_upload.argtypes = [vp, C.POINTER(TemplateView), C.c_int, C.POINTER(vp)]
+    lib.afis_search_resident.argtypes = [vp, vp, fp, fp, i32p, C.c_int, i64p, fp]
+    lib.afis_queries_free.argtypes = [vp, vp]; lib.afis_queries_free.restype = None
+    lib.afis_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.afis_debug_lut.argtypes = [vp, C.POINTER(TemplateView), fp, i32p]
+    lib.afis_debug_texture_rowmax.argtypes = [vp, C.POINTER(TemplateView), C.c_int64, fp, i32p, i32p]
+    return lib
+
+
+def _ptr(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class _Views:
+    """Builds afis_template_view arrays from FPTemplate objects and keeps every backing array alive."""
+
+    def __init__(self, templates: Sequence[FPTemplate]):
+        self.keep = []
+        self.arr = (TemplateView * max(1, len(templates)))()
+        for i, t in enumerate(templates):
+            mv = (MinutiaeView * max(1, len(t.minu)))()
+            for j, m in enumerate(t.minu):
+                x = np.ascontiguousarray(m.x, np.int16); y = np.ascontiguousarray(m.y, np.int16)
+                o = np.ascontiguousarray(m.ori, np.float32); d = np.ascontiguousarray(m.des, np.float32)
+                self.keep += [x, y, o, d]
+                mv[j] = MinutiaeView(len(x), _ptr(x, C.c_int16), _ptr(y, C.c_int16), _ptr(o, C.c_float), d.shape[1] if d.ndim == 2 else 0, _ptr(d, C.c_float))
+            tv = (TextureView * max(1, len(t.tex)))()
+            for j, s in enumerate(t.tex):
+                x = np.ascontiguousarray(s.x, np.int16); y = np.ascontiguousarray(s.y, np.int16); o = np.ascontiguousarray(s.ori, np.float32)
+                self.keep += [x, y, o]
+                des_p, codes_p, dl = None, None, 0
+                if s.des is not None:
+                    d = np.ascontiguousarray(s.des, np.float32); self.keep.append(d); des_p = _ptr(d, C.c_float); dl = d.shape[1]
+                if s.codes is not None:
+                    c = np.ascontiguousarray(s.codes, np.uint8); self.keep.append(c); codes_p = _ptr(c, C.c_uint8); dl = c.shape[1]
+                tv[j] = TextureView(len(x), _ptr(x, C.c_int16), _ptr(y, C.c_int16), _ptr(o, C.c_float), dl, des_p, codes_p)
+            self.keep += [mv, tv]
+            self.arr[i] = TemplateView(len(t.minu), mv, len(t.tex), tv)
+        self.n = len(templates)
+
+
+class Matcher:
+    """`PQ::Matcher` (matching/matcher.h:35) on one MI355X.  One instance = one device = one gallery shard."""
+
+    def __init__(self, code_file, device: int = 0, lib_path: str = LIB_PATH):
+        self.lib = load_library(lib_path)
+        if isinstance(code_file, Codebook):
+            buf = code_file.to_bytes()
+        elif isinstance(code_file, (bytes, bytearray)):
+            buf = bytes(code_file)
+        else:
+            with open(code_file, "rb") as f:
+                buf = f.read()
+        self.ctx = C.c_void_p()
+        rc = self.lib.afis_create_from_codebook(C.byref(self.ctx), buf, len(buf), device)
+        if rc != 0:
+            self.ctx = None
+            raise AfisError(f"afis_create failed ({rc}): {self.lib.afis_last_error(None).decode()}")
+        self.gallery_files: List[str] = []
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.afis_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise AfisError(f"afis error {rc}: {self.lib.afis_last_error(self.ctx).decode()}")
+
+    # ---- gallery ----------------------------------------------------------------------------------------------
+    def gallery_add(self, templates: Sequence[FPTemplate]):
+        v = _Views(templates)
+        self._chk(self.lib.afis_gallery_add(self.ctx, v.arr, v.n))
+
+    def gallery_add_dat(self, buf: bytes) -> int:
+        rc = C.c_int32(0)
+        self._chk(self.lib.afis_gallery_add_dat(self.ctx, buf, len(buf), C.byref(rc)))
+        return rc.value
+
+    def gallery_add_packed(self, g):
+        mo = np.ascontiguousarray(g.minu_off, np.int64); to = np.ascontiguousarray(g.tex_off, np.int64)
+        a = [np.ascontiguousarray(g.minu_x, np.int16), np.ascontiguousarray(g.minu_y, np.int16), np.ascontiguousarray(g.minu_ori, np.float32),
+             np.ascontiguousarray(g.minu_des, np.float32), np.ascontiguousarray(g.tex_x, np.int16), np.ascontiguousarray(g.tex_y, np.int16),
+             np.ascontiguousarray(g.tex_ori, np.float32), np.ascontiguousarray(g.tex_codes, np.uint8)]
+        self._chk(self.lib.afis_gallery_add_packed(self.ctx, len(mo) - 1, _ptr(mo, C.c_int64), _ptr(a[0], C.c_int16), _ptr(a[1], C.c_int16),
+                                                   _ptr(a[2], C.c_float), _ptr(a[3], C.c_float), _ptr(to, C.c_int64), _ptr(a[4], C.c_int16),
+                                                   _ptr(a[5], C.c_int16), _ptr(a[6], C.c_float), _ptr(a[7], C.c_uint8)))
+
+    def gallery_commit(self, index_base: int = 0):
+        self._chk(self.lib.afis_gallery_commit(self.ctx, index_base))
+
+    @property
+    def gallery_size(self) -> int:
+        return int(self.lib.afis_gallery_size(self.ctx))
+
+    def set_option(self, name: str, value: int):
+        self._chk(self.lib.afis_set_option(self.ctx, name.encode(), value))
+
+    # ---- search -----------------------------------------------------------------------------------------------
+    def _alloc(self, nq, k, want_scores, want_parts):
+        G = self.gallery_size
+        scores = np.empty((nq, G), np.float32) if want_scores else None
+        parts = np.empty((nq, G, 4), np.float32) if want_parts else None
+        status = np.zeros(nq, np.int32)
+        ti = np.empty((nq, k), np.int64) if k > 0 else None
+        ts = np.empty((nq, k), np.float32) if k > 0 else None
+        args = (_ptr(scores, C.c_float) if want_scores else None, _ptr(parts, C.c_float) if want_parts else None, _ptr(status, C.c_int32), k,
+                _ptr(ti, C.c_int64) if k > 0 else None, _ptr(ts, C.c_float) if k > 0 else None)
+        return scores, parts, status, ti, ts, args
+
+    def search(self, latents: Sequence[FPTemplate], k: int = 24, want_scores: bool = True, want_parts: bool = False):
+        v = _Views(latents)
+        scores, parts, status, ti, ts, args = self._alloc(v.n, k, want_scores, want_parts)
+        self._chk(self.lib.afis_search(self.ctx, v.arr, v.n, *args))
+        return {"scores": scores, "parts": parts, "status": status, "topk_idx": ti, "topk_score": ts}
+
+    def search_dat(self, bufs: Sequence[bytes], k: int = 24, want_scores: bool = True, want_parts: bool = False):
+        n = len(bufs)
+        arr = (C.c_char_p * max(1, n))(*bufs)
+        lens = (C.c_size_t * max(1, n))(*[len(b) for b in bufs])
+        scores, parts, status, ti, ts, args = self._alloc(n, k, want_scores, want_parts)
+        self._chk(self.lib.afis_search_dat(self.ctx, arr, lens, n, *args))
+        return {"scores": scores, "parts": parts, "status": status, "topk_idx": ti, "topk_score": ts}
+
+    def upload_queries(self, latents: Sequence[FPTemplate]):
+        v = _Views(latents)
+        h = C.c_void_p()
+        self._chk(self.lib.afis_queries_upload(self.ctx, v.arr, v.n, C.byref(h)))
+        return (h, v.n)
+
+    def search_resident(self, handle, k: int = 24, want_scores: bool = False, want_parts: bool = False):
+        h, n = handle
+        scores, parts, status, ti, ts, args = self._alloc(n, k, want_scores, want_parts)
+        self._chk(self.lib.afis_search_resident(self.ctx, h, *args))
+        return {"scores": scores, "parts": parts, "status": status, "topk_idx": ti, "topk_score": ts}
+
+    def free_queries(self, handle):
+        self.lib.afis_queries_free(self.ctx, handle[0])
+
+    def timing(self) -> dict:
+        t = Timing()
+        self._chk(self.lib.afis_get_timing(self.ctx, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+    # ---- parity taps ------------------------------------------------------------------------------------------
+    def debug_lut(self, latent: FPTemplate) -> np.ndarray:
+        v = _Views([latent])
+        n = latent.tex[0].n if latent.tex else 0
+        out = np.empty((max(n, 1), 16, 256), np.float32); nr = C.c_int32(0)
+        self._chk(self.lib.afis_debug_lut(self.ctx, v.arr, _ptr(out, C.c_float), C.byref(nr)))
+        return out[:nr.value]
+
+    def debug_texture_rowmax(self, latent: FPTemplate, g: int):
+        v = _Views([latent])
+        val = np.zeros(1000, np.float32); arg = np.zeros(1000, np.int32); nr = C.c_int32(0)
+        self._chk(self.lib.afis_debug_texture_rowmax(self.ctx, v.arr, g, _ptr(val, C.c_float), _ptr(arg, C.c_int32), C.byref(nr)))
+        return val[:nr.value], arg[:nr.value]
+
+    # ---- the reference's drivers (matching/matcher.cpp:96-337) ---------------------------------------------------
+    def load_gallery_dir(self, rolled_path: str) -> List[str]:
+        """Directory scan for *.dat as One2List/List2List do (matcher.cpp:120-130, directory order)."""
+        files = [os.path.join(rolled_path, f) for f in os.listdir(rolled_path) if os.path.splitext(f)[1] == ".dat"]
+        for f in files:
+            with open(f, "rb") as fh:
+                self.gallery_add_dat(fh.read())
+        self.gallery_files = files
+        self.gallery_commit(0)
+        return files
+
+    def One2List_matching(self, latent_template_file: str, score_path: str, top: int = 24) -> int:
+        """matcher.cpp:216-337: rank list of the top 24 as `<rank>"<path>",<score>` under a `filename,score` header."""
+        with open(latent_template_file, "rb") as f:
+            r = self.search_dat([f.read()], k=min(top, max(1, self.gallery_size)))
+        if r["status"][0] == 1:
+            return 1
+        stem = os.path.splitext(os.path.basename(latent_template_file))[0]
+        with open(score_path + stem + ".csv", "w") as out:
+            out.write("filename,score\n")
+            for j in range(min(top, self.gallery_size)):
+                g = int(r["topk_idx"][0, j])
+                out.write(f'{j + 1}"{self.gallery_files[g]}",{_cxx_float(r["topk_score"][0, j])}\n')
+        return 0
+
+    def List2List_matching(self, latent_path: str, score_path: str) -> int:
+        """matcher.cpp:96-214: one CSV per latent, one `"path",%.3f` line per gallery file."""
+        files = [os.path.join(latent_path, f) for f in os.listdir(latent_path) if os.path.splitext(f)[1] == ".dat"]
+        if not files:
+            return -1
+        bufs = [open(f, "rb").read() for f in files]
+        r = self.search_dat(bufs, k=0)
+        for i, f in enumerate(files):
+            if r["status"][i] == 1:
+                continue
+            stem = os.path.splitext(os.path.basename(f))[0]
+            with open(score_path + stem + ".csv", "w") as out:
+                for j, gf in enumerate(self.gallery_files):
+                    out.write(f'"{gf}",{r["scores"][i, j]:.3f}\n')
+        return 0
+
+
+def _cxx_float(v: float) -> str:
+    """`ostream << float` with default formatting (6 significant digits, %g style)."""
+    return "%g" % float(v)
