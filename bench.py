@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py — latent queries/s against a resident rolled gallery on N MI355X (one process per GPU).
+
+A "step" = one pass of the hot path: Q latents scored against the whole G-template gallery (LUT build, PQ-ADC row-max,
+texture tail, minutiae scorer, fusion, per-shard top-24) plus the one exchange step (RCCL all_gather of the per-shard
+rank lists) and the merge.  Gallery and queries are resident in HBM before the timed region; scores/rank lists come back
+to the host inside it.  Default workload = BASELINE.json configs[2]: batch 100 latents vs a 100k synthetic gallery.
+The gallery is FIXED at G as N grows (gallery shards across ranks): "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+T = importlib.import_module("msu-latentafis_amd.host.templates")
+S = importlib.import_module("msu-latentafis_amd.host.synth")
+M = importlib.import_module("msu-latentafis_amd.host.matcher")
+SH = importlib.import_module("msu-latentafis_amd.host.sharding")
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDS_PEAK_LOOKUPS = 256 * 64 * 2.4e9   # 256 CUs x 256 B/clk (ds_read_b128) / 4 B x 2.4 GHz (MI355X_MICROARCH.md §LDS)
+BYTES_PER_TEX_POINT = 2 + 2 + 4 + 16  # x, y, ori, 16 PQ code bytes per rolled texture point
+BYTES_PER_MINUTIA = 2 + 2 + 4 + 96 * 4
+
+
+def cpu_baseline(cb_bytes, lats, gal, lo, budget_s=15.0):
+    """Oracle (CPU restatement, OpenMP) timed on a bounded sample of the same workload: a few latents x a slice of the gallery."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    orc = Oracle()
+    ocb = orc.codebook(cb_bytes)
+    cores = orc.lib.orc_num_threads()
+    n_lat = min(2, len(lats))
+    # size the sample from a probe of 2*cores pairs
+    hl = [orc.latent(ocb, T.write_latent(L))[0] for L in lats[:n_lat]]
+    probe = [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(min(gal.G, 2 * cores))]
+    t0 = time.perf_counter(); orc.search(ocb, hl[0], probe, tie_mode=1, threads=cores); dt = time.perf_counter() - t0
+    per_pair_wall = dt / max(1, len(probe))
+    n_gal = int(min(gal.G, max(len(probe), budget_s / n_lat / max(per_pair_wall, 1e-6))))
+    hr = probe + [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(len(probe), n_gal)]
+    t0 = time.perf_counter()
+    for h in hl:
+        orc.search(ocb, h, hr, tie_mode=1, threads=cores)
+    wall = time.perf_counter() - t0
+    t1 = time.perf_counter(); orc.search(ocb, hl[0], hr[:min(len(hr), 400)], tie_mode=1, threads=0); wall8 = time.perf_counter() - t1
+    pairs_per_s = n_lat * n_gal / wall
+    return pairs_per_s, cores, f"{n_lat} latents x {n_gal} gallery templates (templates {lo}..{lo + n_gal} of the bench gallery), all {cores} host threads", \
+        min(len(hr), 400) / wall8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gallery", type=int, default=100000)
+    ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--k", type=int, default=24)
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--query-batch", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    with open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb") as f:
+        cb_bytes = f.read()
+    cb = T.Codebook.from_bytes(cb_bytes)
+    G, Q = a.gallery, a.queries
+
+    # ---- synthetic workload (seeded; every rank generates only its own shard) -------------------------------------
+    t_gen = time.perf_counter()
+    nm_all, nt_all = S.gallery_counts(a.seed, G)
+    bounds = SH.shard_bounds(nt_all, world)                # balanced by rolled texture points, the cost driver
+    lo, hi = bounds[rank]
+    lats = S.make_latents(a.seed, Q)
+    gal = S.make_packed_gallery(a.seed, G, cb, lo, hi)
+    planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
+    t_gen = time.perf_counter() - t_gen
+
+    m = M.Matcher(cb_bytes, device=local)
+    if a.variant >= 0: m.set_option("adc_variant", a.variant)
+    if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
+    if a.chunk > 0: m.set_option("chunk", a.chunk)
+    t_up = time.perf_counter()
+    m.gallery_add_packed(gal)
+    m.gallery_commit(lo)
+    qh = m.upload_queries(lats)
+    t_up = time.perf_counter() - t_up
+
+    def step():
+        r = m.search_resident(qh, k=a.k)
+        idx, sc = SH.gather_topk(r["topk_idx"], r["topk_score"], a.k, device=dev)
+        return idx, sc
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    tm_acc = None
+    for _ in range(a.steps):
+        idx, sc = step()
+        tm = m.timing()
+        tm_acc = tm if tm_acc is None else {k_: tm_acc[k_] + v for k_, v in tm.items()}
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1000.0 / max(1, a.steps)
+    value = Q / (ms_per_step / 1000.0)
+
+    # ---- rank-list sanity: the planted true mate must be rank 1 ------------------------------------------------------
+    hits = sum(1 for q in range(Q) if int(idx[q, 0]) == planted[q][0][0])
+
+    out = None
+    if rank == 0:
+        # roofline of the dominant kernel (PQ-ADC row-max): algorithmic bytes per launch / average launch duration, where the
+        # duration comes from HIP events on the stream the kernel runs on (afis_get_timing).
+        launches = max(1, tm_acc["adc_launches"])
+        adc_ms_avg = tm_acc["adc_ms"] / launches
+        q_per_launch = Q * a.steps / launches
+        shard_tex_points = int(nt_all[lo:hi].sum())
+        alg_bytes_launch = q_per_launch * shard_tex_points * BYTES_PER_TEX_POINT
+        achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
+        lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "adc_hbm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+            except Exception:
+                traffic = None
+        pipeline_bytes = Q * (int(nt_all.sum()) * BYTES_PER_TEX_POINT + int(nm_all.sum()) * BYTES_PER_MINUTIA)
+        out = {
+            "metric": "latent queries/sec vs 100k rolled gallery", "value": round(value, 4), "unit": "queries/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"batch {Q} latents vs {G}-template synthetic rolled gallery (BASELINE.json configs[2]); planted mates; "
+                                   f"top-{a.k} rank lists", "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
+                       "adc_variant": a.variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
+                       "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
+            "roofline": {"bound": "hbm", "kernel": "k_adc_rowmax", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),
+                         "lds_lookups_per_s": lookups_per_s, "lds_peak_lookups_per_s": LDS_PEAK_LOOKUPS,
+                         "lds_frac": round(lookups_per_s / LDS_PEAK_LOOKUPS, 4),
+                         "pipeline_achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / 1.0, 3)},
+            "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
+            "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            pps, cores, sample, pps8 = cpu_baseline(cb_bytes, lats, gal, lo)
+            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": cores, "kind": "port", "sample": sample,
+                                   "pairs_per_s": round(pps, 1), "reference_setting_8_threads_static16_queries_per_s": round(pps8 / G, 6)}
+            out["speedup_vs_cpu_baseline"] = round(value / (pps / G), 1)
+        print(json.dumps(out), flush=True)
+    m.free_queries(qh)
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

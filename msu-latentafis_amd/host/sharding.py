@@ -1,0 +1,62 @@
+"""Gallery sharding and rank-list merge.  Pure host logic: numpy for the arithmetic, torch.distributed only for
+the one exchange step (all_gather of the per-shard top-k; backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests).
+
+Gallery templates are independent units: partition them into one contiguous shard per rank, balanced by the cost driver
+(number of rolled texture points); every rank scores all queries against its shard and reports its local top-k with GLOBAL
+gallery indices; the merged list is the top-k of the union, score descending, ties by ascending global index.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+
+def shard_bounds(cost: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) per rank with ~equal total cost.  Every rank gets a (possibly empty) range; ranges tile [0, G)."""
+    G = len(cost)
+    if world <= 1:
+        return [(0, G)]
+    c = np.concatenate([[0], np.cumsum(np.asarray(cost, dtype=np.float64))])
+    total = c[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(c, target, side="left"))
+        k = min(max(k, cuts[-1]), G)
+        cuts.append(k)
+    cuts.append(G)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def merge_topk(idx: np.ndarray, score: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """idx, score: [R, Q, kk] per-shard rank lists (idx -1 = padding).  Returns the merged [Q, k] list."""
+    R, Q, kk = idx.shape
+    fi = np.transpose(idx, (1, 0, 2)).reshape(Q, R * kk)
+    fs = np.transpose(score, (1, 0, 2)).reshape(Q, R * kk).astype(np.float32)
+    out_i = np.full((Q, k), -1, np.int64); out_s = np.full((Q, k), -np.inf, np.float32)
+    for q in range(Q):
+        valid = fi[q] >= 0
+        vi, vs = fi[q][valid], fs[q][valid]
+        order = np.lexsort((vi, -vs.astype(np.float64)))[:k]      # score descending, then global index ascending
+        out_i[q, :len(order)] = vi[order]; out_s[q, :len(order)] = vs[order]
+    return out_i, out_s
+
+
+def gather_topk(idx: np.ndarray, score: np.ndarray, k: int, device=None):
+    """The one exchange step: all_gather of [Q, kk] (int64 idx, f32 score) from every rank, then merge on every rank.
+    Messages are tiny (24 x 12 B per query per rank); this is latency-, not bandwidth-bound."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return merge_topk(idx[None], score[None], k)
+    world = dist.get_world_size()
+    dev = device if device is not None else "cpu"
+    ti = torch.from_numpy(np.ascontiguousarray(idx)).to(dev)
+    ts = torch.from_numpy(np.ascontiguousarray(score)).to(dev)
+    gi = [torch.empty_like(ti) for _ in range(world)]
+    gs = [torch.empty_like(ts) for _ in range(world)]
+    dist.all_gather(gi, ti)
+    dist.all_gather(gs, ts)
+    ai = torch.stack(gi).cpu().numpy(); as_ = torch.stack(gs).cpu().numpy()
+    return merge_topk(ai, as_, k)

@@ -24,7 +24,9 @@ BLK_W, BLK_H = 45, 47        # texture block grid ((px-24)/16)
 
 
 def _unit(d: np.ndarray) -> np.ndarray:
-    return (d / np.linalg.norm(d, axis=-1, keepdims=True) * DESCRIPTOR_NORM).astype(np.float32)
+    d = np.asarray(d, dtype=np.float32)
+    n2 = np.einsum("...i,...i->...", d, d)
+    return (d * (np.float32(DESCRIPTOR_NORM) / np.sqrt(n2))[..., None]).astype(np.float32)
 
 
 def make_latent(rng: np.random.Generator, n_minu_tpl: int = 28, n_tex_lo: int = 400, n_tex_hi: int = 1000,
@@ -138,42 +140,85 @@ class PackedGallery:
                              self.tex_off[lo:hi + 1] - c, self.tex_x[c:d], self.tex_y[c:d], self.tex_ori[c:d], self.tex_codes[c:d])
 
 
-def make_packed_gallery(seed: int, G: int, cb: Codebook, n_minu_mean: float = 80, n_tex_lo: int = 600, n_tex_hi: int = 1000) -> PackedGallery:
-    """Vectorised random (non-mate) gallery; plant mates afterwards with plant_mates()."""
-    rng = np.random.default_rng(seed)
+GEN_BLOCK = 1024   # templates per independently seeded block: any shard can be generated without the rest
+
+
+def gallery_counts(seed: int, G: int, n_minu_mean: float = 80, n_tex_lo: int = 600, n_tex_hi: int = 1000):
+    """Per-template point counts of the synthetic gallery (cheap; every rank computes all of them to place shard bounds)."""
+    rng = np.random.default_rng([seed, 0xC0])
     nm = np.clip(np.rint(rng.normal(n_minu_mean, 15, G)), 20, 200).astype(np.int64)
     nt = rng.integers(n_tex_lo, n_tex_hi + 1, G).astype(np.int64)
+    return nm, nt
+
+
+def make_packed_gallery(seed: int, G: int, cb: Codebook, lo: int = 0, hi: Optional[int] = None, n_minu_mean: float = 80,
+                        n_tex_lo: int = 600, n_tex_hi: int = 1000) -> PackedGallery:
+    """Vectorised random (non-mate) gallery, templates [lo, hi) of a G-template gallery; plant mates afterwards with
+    plant_mates().  Content depends only on (seed, G, template index), not on the shard bounds."""
+    hi = G if hi is None else hi
+    nm_all, nt_all = gallery_counts(seed, G, n_minu_mean, n_tex_lo, n_tex_hi)
+    nm, nt = nm_all[lo:hi], nt_all[lo:hi]
     mo = np.concatenate([[0], np.cumsum(nm)]); to = np.concatenate([[0], np.cumsum(nt)])
     NM, NT = int(mo[-1]), int(to[-1])
-    des = np.empty((NM, 96), dtype=np.float32)
-    step = 1 << 18
-    for s in range(0, NM, step):                       # chunked: bounds peak host memory
-        e = min(NM, s + step)
-        des[s:e] = _unit(rng.standard_normal((e - s, 96), dtype=np.float32))
-    return PackedGallery(
-        mo, rng.integers(0, IMG_W, NM).astype(np.int16), rng.integers(0, IMG_H, NM).astype(np.int16),
-        rng.uniform(-np.pi, np.pi, NM).astype(np.float32), des,
-        to, rng.integers(0, BLK_W, NT).astype(np.int16), rng.integers(0, BLK_H, NT).astype(np.int16),
-        rng.uniform(-np.pi / 2, np.pi / 2, NT).astype(np.float32),
-        rng.integers(0, cb.K, (NT, cb.M), dtype=np.uint8))
+    mx = np.empty(NM, np.int16); my = np.empty(NM, np.int16); mori = np.empty(NM, np.float32); des = np.empty((NM, 96), np.float32)
+    tx = np.empty(NT, np.int16); ty = np.empty(NT, np.int16); tori = np.empty(NT, np.float32); codes = np.empty((NT, cb.M), np.uint8)
+    for b in range(lo // GEN_BLOCK, (max(hi, 1) - 1) // GEN_BLOCK + 1):
+        b_lo, b_hi = b * GEN_BLOCK, min(G, (b + 1) * GEN_BLOCK)
+        rng = np.random.default_rng([seed, 1, b])
+        bm, bt = int(nm_all[b_lo:b_hi].sum()), int(nt_all[b_lo:b_hi].sum())
+        bmx = rng.integers(0, IMG_W, bm).astype(np.int16); bmy = rng.integers(0, IMG_H, bm).astype(np.int16)
+        bmo = rng.uniform(-np.pi, np.pi, bm).astype(np.float32)
+        bd = _unit(rng.random((bm, 96), dtype=np.float32) - np.float32(0.5))   # uniform cube directions: 5x cheaper than Gaussians at 10^7 rows
+        btx = rng.integers(0, BLK_W, bt).astype(np.int16); bty = rng.integers(0, BLK_H, bt).astype(np.int16)
+        bto = rng.uniform(-np.pi / 2, np.pi / 2, bt).astype(np.float32)
+        bc = (np.frombuffer(rng.bytes(bt * cb.M), np.uint8).reshape(bt, cb.M) if cb.K == 256 else rng.integers(0, cb.K, (bt, cb.M)).astype(np.uint8))
+        # intersect the block with [lo, hi)
+        s_lo, s_hi = max(lo, b_lo), min(hi, b_hi)
+        if s_hi <= s_lo:
+            continue
+        m_skip = int(nm_all[b_lo:s_lo].sum()); m_take = int(nm_all[s_lo:s_hi].sum())
+        t_skip = int(nt_all[b_lo:s_lo].sum()); t_take = int(nt_all[s_lo:s_hi].sum())
+        md = int(mo[s_lo - lo]); td = int(to[s_lo - lo])
+        mx[md:md + m_take] = bmx[m_skip:m_skip + m_take]; my[md:md + m_take] = bmy[m_skip:m_skip + m_take]
+        mori[md:md + m_take] = bmo[m_skip:m_skip + m_take]; des[md:md + m_take] = bd[m_skip:m_skip + m_take]
+        tx[td:td + t_take] = btx[t_skip:t_skip + t_take]; ty[td:td + t_take] = bty[t_skip:t_skip + t_take]
+        tori[td:td + t_take] = bto[t_skip:t_skip + t_take]; codes[td:td + t_take] = bc[t_skip:t_skip + t_take]
+    return PackedGallery(mo, mx, my, mori, des, to, tx, ty, tori, codes)
 
 
-def plant_mates(seed: int, gal: PackedGallery, cb: Codebook, latents: List[FPTemplate], n_partial: int = 3) -> Dict[int, List[Tuple[int, float]]]:
-    """For each latent overwrite 1 + n_partial gallery entries (chosen without collisions) with mates of
-    decreasing overlap.  Returns {latent index: [(gallery index, frac), ...]} — the expected rank order."""
-    rng = np.random.default_rng(seed)
-    need = len(latents) * (1 + n_partial)
-    if need > gal.G:
-        n_partial = max(0, gal.G // max(1, len(latents)) - 1)
-        need = len(latents) * (1 + n_partial)
-    slots = rng.permutation(gal.G)[:need].reshape(len(latents), 1 + n_partial) if need else np.zeros((len(latents), 0), int)
+def mate_slots(seed: int, G: int, n_latents: int, n_partial: int = 3):
+    """Global gallery indices that carry the planted mates of each latent: [n_latents, 1 + n_partial], no collisions."""
+    rng = np.random.default_rng([seed, 0xA7])
+    per = 1 + n_partial
+    if n_latents * per > G:
+        per = max(1, G // max(1, n_latents))
+    return rng.permutation(G)[:n_latents * per].reshape(n_latents, per)
+
+
+MATE_FRACS = [0.8, 0.5, 0.35, 0.25, 0.2, 0.15]
+
+
+def plant_mates(seed: int, gal: PackedGallery, cb: Codebook, latents: List[FPTemplate], G: Optional[int] = None, lo: int = 0,
+                n_partial: int = 3) -> Dict[int, List[Tuple[int, float]]]:
+    """For each latent overwrite 1 + n_partial gallery entries with mates of decreasing overlap.  `gal` holds templates
+    [lo, lo + gal.G) of a G-template gallery; only the slots inside that range are written, and a mate's content depends only on
+    (seed, latent index, slot rank), so every shard plants the same mates.  Returns {latent: [(GLOBAL gallery index, frac), ...]}."""
+    G = gal.G if G is None else G
+    slots = mate_slots(seed, G, len(latents), n_partial)
     planted: Dict[int, List[Tuple[int, float]]] = {}
-    fracs = [0.8, 0.5, 0.35, 0.25, 0.2, 0.15][:1 + n_partial]
     for q, L in enumerate(latents):
         planted[q] = []
-        for s, frac in zip(slots[q], fracs):
-            g = int(s)
-            nm = int(gal.minu_off[g + 1] - gal.minu_off[g]); nt = int(gal.tex_off[g + 1] - gal.tex_off[g])
-            gal.set_template(g, make_mate(rng, cb, L, frac=frac, sigma=0.08, n_minu=nm, n_tex=nt))
+        for r, s_ in enumerate(slots[q]):
+            g = int(s_); frac = MATE_FRACS[min(r, len(MATE_FRACS) - 1)]
             planted[q].append((g, frac))
+            if not (lo <= g < lo + gal.G):
+                continue
+            k = g - lo
+            nm = int(gal.minu_off[k + 1] - gal.minu_off[k]); nt = int(gal.tex_off[k + 1] - gal.tex_off[k])
+            rng = np.random.default_rng([seed, 2, q, r])
+            gal.set_template(k, make_mate(rng, cb, L, frac=frac, sigma=0.08, n_minu=nm, n_tex=nt))
     return planted
+
+
+def make_latents(seed: int, n: int, **kw) -> List[FPTemplate]:
+    return [make_latent(np.random.default_rng([seed, 3, i]), **kw) for i in range(n)]
