@@ -145,6 +145,10 @@ int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, i
 int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, int64_t g,
                               float* val, int32_t* arg, int32_t* n_rows);
 
+/* In-kernel phase timers (only when the library is built with PHASE_TIMING=1; all zeros otherwise): 32 cycle counters
+ * accumulated since the last reset.  Development aid. */
+int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -417,8 +417,8 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
             HIPCHK(ctx, ctx->scores.ensure(n_pairs * 4));
             // minutiae scratch: simi + keys per workgroup
-            size_t per_wg = 2 * (size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR);
-            per_wg = (per_wg + 63) / 64 * 64;
+            // per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs too large for the LDS fast path use it)
+            size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
             int n_wg = 1024;
             while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
@@ -513,6 +513,15 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "chunk") { if (value < 1 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 1..65536"); ctx->chunk = (int)value; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
+    return AFIS_OK;
+}
+
+int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset)
+{
+    if (!ctx || !out32) return AFIS_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, read_phase_cycles(out32, reset != 0));
     return AFIS_OK;
 }
 

@@ -64,6 +64,9 @@ hipError_t launch_minutiae(const QueryDev& q, const GalleryDev& g, float* scratc
 // S10: fusion -> scores[q*G+g]
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 
+// optional in-kernel phase timers (build with PHASE_TIMING=1); zeros otherwise
+hipError_t read_phase_cycles(unsigned long long* out32, bool reset);
+
 // debug tap: LUT in the reference layout [n][16][256]
 hipError_t launch_lut_reference_layout(const float* des, int n, const float* codewords, float* out, hipStream_t stream);
 

@@ -30,6 +30,16 @@ constexpr int kTailWaves = kTailThreads / 64;
 
 typedef unsigned long long u64;
 
+// Optional in-kernel phase timers (make PHASE_TIMING=1): thread 0 of every workgroup accumulates s_memtime deltas per phase.
+#ifdef AFIS_PHASE_TIMING
+__device__ u64 g_phase_cycles[32];
+#define PHASE_INIT() u64 ph_t0 = __builtin_readcyclecounter()
+#define PHASE(i) do { if (threadIdx.x == 0) { const u64 ph_t1 = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], ph_t1 - ph_t0); ph_t0 = ph_t1; } } while (0)
+#else
+#define PHASE_INIT() do {} while (0)
+#define PHASE(i) do {} while (0)
+#endif
+
 // ---- small helpers ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ord_f32(float v)
 {
@@ -56,22 +66,23 @@ __device__ __forceinline__ int wg_count(int local, int* s_slots /*[2][kTailWaves
     return tot;
 }
 
-// ---- correspondence list shared by the graph stages ------------------------------------------------------------------
-template <int NMAX>
-struct Cands {
+// ---- correspondence list and scratch shared by the graph stages ------------------------------------------------------
+// The compatibility matrix H of the distance graph (200x200 fp32 would be 160 KB) is never stored: LDS keeps only the
+// bitmask of its NON-ZERO entries (5.6 KB); values are recomputed on demand from the packed point coordinates and cached
+// per row in a small stash for the later power iterations.  H*b only ever adds h*b[k] terms, and a zero entry adds
+// +0.0f, so skipping the zero entries is exact.  This keeps a task at ~45 KB of LDS (3 workgroups per CU).
+template <int NMAX, int CACHE>
+struct __attribute__((aligned(16))) GraphSmem {
+    static constexpr int W = (NMAX + 31) / 32;
+    static constexpr int N4 = (NMAX + 3) / 4 * 4;
+    float b[N4];                           // 16-byte aligned: read as float4 broadcasts
+    float cc[N4];
     float sim[NMAX];
     short li[NMAX], ri[NMAX];
-    short lx[NMAX], ly[NMAX], rx[NMAX], ry[NMAX];
+    int2 xy[NMAX];                         // .x = lx | ly << 16 (latent point), .y = rx | ry << 16 (rolled point)
     float lo[NMAX], ro[NMAX];
-};
-
-template <int NMAX>
-struct __attribute__((aligned(16))) GraphSmem {
-    float b[(NMAX + 3) / 4 * 4];           // 16-byte aligned: read as float4 broadcasts
-    float cc[(NMAX + 3) / 4 * 4];
-    Cands<NMAX> c;
-    float H[NMAX * (NMAX - 1) / 2];        // strict upper triangle of the symmetric compatibility matrix
-    uint32_t hb[NMAX][(NMAX + 31) / 32];   // boolean angle-compatibility matrix, bit rows
+    uint32_t hb[NMAX][W];                  // bit rows: non-zero pattern of H (distance stage), then the boolean H of the angle stage
+    float stash[CACHE * NMAX];             // [n][t]: value of the n-th non-zero of row t
     u64 keys[256];
     short order[256];                      // rank -> candidate index
     short sel[NMAX];
@@ -80,19 +91,9 @@ struct __attribute__((aligned(16))) GraphSmem {
     int counter;
 };
 
-__device__ __forceinline__ int tri_off(int i, int num) { return i * (2 * num - i - 1) / 2; }
-__device__ __forceinline__ int tri(int i, int j, int num) { return tri_off(i, num) + (j - i - 1); }   // i < j
-// inverse of tri(): pair number p -> (i, j), i < j
-__device__ __forceinline__ void tri_inv(int p, int num, int& i, int& j)
-{
-    const float fn = (float)(2 * num - 1);
-    int r = (int)((fn - __fsqrt_rn(fn * fn - 8.0f * (float)p)) * 0.5f);    // within +-1 of the row for num <= 256
-    r = max(0, min(r, num - 2));
-    r -= (tri_off(r, num) > p);                    // branch-free fix-up
-    r += (tri_off(r + 1, num) <= p);
-    r -= (tri_off(r, num) > p);
-    i = r; j = p - tri_off(r, num) + r + 1;
-}
+__device__ __forceinline__ int2 pack_xy(int lx, int ly, int rx, int ry) { return make_int2((lx & 0xffff) | (ly << 16), (rx & 0xffff) | (ry << 16)); }
+struct Pt { int lx, ly, rx, ry; };
+__device__ __forceinline__ Pt unpack_xy(int2 v) { Pt p; p.lx = (int)(short)v.x; p.ly = v.x >> 16; p.rx = (int)(short)v.y; p.ry = v.y >> 16; return p; }
 
 // Rank (0 = largest) of this thread's key among keys[0..n); keys are unique.  Caller syncs before (keys written) and after.
 __device__ __forceinline__ int rank_of(const u64* keys, int n, u64 mine)
@@ -104,8 +105,8 @@ __device__ __forceinline__ int rank_of(const u64* keys, int n, u64 mine)
 }
 
 // sort the candidates by score (descending, ties by index): order[rank] = index.
-template <int NMAX>
-__device__ __forceinline__ void sort_scores(GraphSmem<NMAX>& sm, int num)
+template <class SM>
+__device__ __forceinline__ void sort_scores(SM& sm, int num)
 {
     const int t = threadIdx.x;
     u64 mine = 0;
@@ -119,8 +120,8 @@ __device__ __forceinline__ void sort_scores(GraphSmem<NMAX>& sm, int num)
 // skip a candidate whose latent or rolled point is already used or that is incompatible with ANY accepted one.
 // Wave 0 holds the candidates in rank order (lane l: ranks l, l+64, ...).  Each round accepts the first alive candidate and
 // kills every later one that conflicts with it.  Accepted indices go to sm.sel[0..nsel) in acceptance (= rank) order.
-template <int NMAX, class Compat>
-__device__ void greedy(GraphSmem<NMAX>& sm, int num, double thr, Compat compatible)
+template <int NMAX, class SM, class Compat>
+__device__ void greedy(SM& sm, int num, double thr, Compat compatible)
 {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -133,7 +134,7 @@ __device__ void greedy(GraphSmem<NMAX>& sm, int num, double thr, Compat compatib
             idx[u] = 0; li[u] = -1; ri[u] = -1; alive[u] = false;
             if (p < num) {
                 idx[u] = sm.order[p];
-                li[u] = sm.c.li[idx[u]]; ri[u] = sm.c.ri[idx[u]];
+                li[u] = sm.li[idx[u]]; ri[u] = sm.ri[idx[u]];
                 alive[u] = !((double)sm.b[idx[u]] < thr);          // sorted descending: everything after the first S < thr is < thr too
             }
         }
@@ -166,29 +167,25 @@ __device__ void greedy(GraphSmem<NMAX>& sm, int num, double thr, Compat compatib
 }
 
 // keep only the accepted correspondences, in acceptance order
-template <int NMAX>
-__device__ int compact(GraphSmem<NMAX>& sm)
+template <class SM>
+__device__ int compact(SM& sm)
 {
     const int n = sm.nsel;
     const int t = threadIdx.x;
-    float sim = 0, lo = 0, ro = 0; short li = 0, ri = 0, lx = 0, ly = 0, rx = 0, ry = 0;
+    float sim = 0, lo = 0, ro = 0; short li = 0, ri = 0; int2 xy = make_int2(0, 0);
     if (t < n) {
         const int s = sm.sel[t];
-        sim = sm.c.sim[s]; li = sm.c.li[s]; ri = sm.c.ri[s]; lx = sm.c.lx[s]; ly = sm.c.ly[s]; rx = sm.c.rx[s]; ry = sm.c.ry[s];
-        lo = sm.c.lo[s]; ro = sm.c.ro[s];
+        sim = sm.sim[s]; li = sm.li[s]; ri = sm.ri[s]; xy = sm.xy[s]; lo = sm.lo[s]; ro = sm.ro[s];
     }
     __syncthreads();
-    if (t < n) {
-        sm.c.sim[t] = sim; sm.c.li[t] = li; sm.c.ri[t] = ri; sm.c.lx[t] = lx; sm.c.ly[t] = ly; sm.c.rx[t] = rx; sm.c.ry[t] = ry;
-        sm.c.lo[t] = lo; sm.c.ro[t] = ro;
-    }
+    if (t < n) { sm.sim[t] = sim; sm.li[t] = li; sm.ri[t] = ri; sm.xy[t] = xy; sm.lo[t] = lo; sm.ro[t] = ro; }
     __syncthreads();
     return n;
 }
 
 // sum of cc[0..num) in ascending order; cc is zero-padded to a multiple of 4 (x + 0.0f == x)
-template <int NMAX>
-__device__ __forceinline__ float seq_sum(const GraphSmem<NMAX>& sm, int num)
+template <class SM>
+__device__ __forceinline__ float seq_sum(const SM& sm, int num)
 {
     float sum = 0.0f;
     const float4* c4 = reinterpret_cast<const float4*>(sm.cc);
@@ -197,61 +194,95 @@ __device__ __forceinline__ float seq_sum(const GraphSmem<NMAX>& sm, int num)
     return sum;
 }
 
-// S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).
-template <int NMAX, bool LOOKUP, int ITERS>
-__device__ int dist_filter(GraphSmem<NMAX>& sm, int num, const float* s_table)
+// |dist_latent - dist_rolled| of a correspondence pair; false when the pair is out of the look-up table's range (H = 0).
+// LOOKUP: matcher.cpp:1246-1264 (block coordinates, table_dist).  else: :1372-1385 (pixels, sqrtf).
+template <bool LOOKUP>
+__device__ __forceinline__ bool pair_dist(const Pt& a, const Pt& o, const float* s_table, float& dist)
 {
-    const int t = threadIdx.x;
-    // compatibility matrix, matcher.cpp:1237-1275 / :1363-1397
-    const int n_pairs = num * (num - 1) / 2;
-#pragma unroll 2
-    for (int p = t; p < n_pairs; p += kTailThreads) {
-        int i, j; tri_inv(p, num, i, j);
-        float h = 0.0f;
-        float d1, d2; bool ok = true;
-        if (LOOKUP) {
-            const int dx1 = abs(sm.c.lx[i] - sm.c.lx[j]), dx2 = abs(sm.c.rx[i] - sm.c.rx[j]);
-            const int dy1 = abs(sm.c.ly[i] - sm.c.ly[j]), dy2 = abs(sm.c.ry[i] - sm.c.ry[j]);
-            ok = !((dx1 >= kDistN) | (dx2 >= kDistN) | (dy1 >= kDistN) | (dy2 >= kDistN));      // :1257
-            d1 = ok ? s_table[dx1 * kDistN + dy1] : 0.f;
-            d2 = ok ? s_table[dx2 * kDistN + dy2] : 0.f;
-        } else {
-            const float dx1 = (float)(sm.c.lx[i] - sm.c.lx[j]), dx2 = (float)(sm.c.rx[i] - sm.c.rx[j]);
-            const float dy1 = (float)(sm.c.ly[i] - sm.c.ly[j]), dy2 = (float)(sm.c.ry[i] - sm.c.ry[j]);
-            const float a = dx1 * dx1, b = dy1 * dy1, c = dx2 * dx2, d = dy2 * dy2;
-            d1 = __fsqrt_rn(a + b);                                                               // :1380-1384, correctly rounded
-            d2 = __fsqrt_rn(c + d);
-        }
-        const float dist = fabsf(d1 - d2);
-        if (ok && !(dist > 30.0f)) {
-            // (30-dist)/(25.0): float numerator, double divide, float store (:1268/:1389).  A correctly rounded
-            // fp32 divide gives the same float (double rounding through 53 bits is innocuous for a quotient of two
-            // 24-bit values, 53 >= 2*24+2); __fdiv_rn is correctly rounded.
-            h = __fdiv_rn(30.0f - dist, 25.0f);
-            if (h > 1.0f) h = 1.0f; else if (h < 0.0f) h = 0.0f;
-        }
-        sm.H[p] = h;
+    float d1, d2; bool ok = true;
+    if (LOOKUP) {
+        const int dx1 = abs(a.lx - o.lx), dx2 = abs(a.rx - o.rx), dy1 = abs(a.ly - o.ly), dy2 = abs(a.ry - o.ry);
+        ok = !((dx1 >= kDistN) | (dx2 >= kDistN) | (dy1 >= kDistN) | (dy2 >= kDistN));              // :1257
+        d1 = s_table[ok ? dx1 * kDistN + dy1 : 0];
+        d2 = s_table[ok ? dx2 * kDistN + dy2 : 0];
+    } else {
+        const float dx1 = (float)(a.lx - o.lx), dx2 = (float)(a.rx - o.rx), dy1 = (float)(a.ly - o.ly), dy2 = (float)(a.ry - o.ry);
+        const float p = dx1 * dx1, q = dy1 * dy1, r = dx2 * dx2, s = dy2 * dy2;
+        d1 = __fsqrt_rn(p + q);                                                                      // correctly rounded, as sqrtf
+        d2 = __fsqrt_rn(r + s);
     }
-    if (t < (NMAX + 3) / 4 * 4) { sm.b[t] = t < num ? sm.c.sim[t] : 0.0f; sm.cc[t] = 0.0f; }
+    dist = fabsf(d1 - d2);
+    return ok;
+}
+// H = clamp((30 - dist)/(25.0), 0, 1) for dist <= 30 (matcher.cpp:1268-1272 / :1389-1393): float numerator, double divide,
+// float store.  (float)((double)x/25.0) == x/25.0f (double rounding through 53 bits is innocuous for a quotient of two
+// 24-bit values), and for every float x in [0, 30] the fma sequence below equals x/25.0f — checked exhaustively over all
+// 1,106,247,681 such floats by tools/verify_div25.c.
+__device__ __forceinline__ float h_value(float dist)
+{
+    const float x = 30.0f - dist;
+    const float q0 = x * 0.04f;
+    const float r = fmaf(-q0, 25.0f, x);
+    float h = fmaf(r, 0.04f, q0);
+    if (h > 1.0f) h = 1.0f; else if (h < 0.0f) h = 0.0f;
+    return h;
+}
+
+// S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).
+template <int NMAX, int CACHE, bool LOOKUP, int ITERS>
+__device__ int dist_filter(GraphSmem<NMAX, CACHE>& sm, int num, const float* s_table)
+{
+    typedef GraphSmem<NMAX, CACHE> SM;
+    const int t = threadIdx.x;
+    PHASE_INIT();
+    for (int i = t; i < num * SM::W; i += kTailThreads) sm.hb[i / SM::W][i % SM::W] = 0u;
+    if (t < SM::N4) { sm.b[t] = t < num ? sm.sim[t] : 0.0f; sm.cc[t] = 0.0f; }
+    Pt me = {0, 0, 0, 0};
+    if (t < num) me = unpack_xy(sm.xy[t]);
     __syncthreads();
+    // non-zero pattern of the compatibility matrix (matcher.cpp:1237-1275 / :1363-1397): thread t visits the pairs
+    // (t, t+d mod num), d = 1..num/2, so every unordered pair is evaluated once.  H != 0  <=>  in range and dist < 30.
+    if (t < num) {
+        const int half = num >> 1;
+#pragma unroll 2
+        for (int d = 1; d <= half; ++d) {
+            if (d == half && !(num & 1) && t >= half) break;        // even num: the antipodal pairs are owned by the lower half
+            int k = t + d; if (k >= num) k -= num;
+            float dist;
+            const bool ok = pair_dist<LOOKUP>(me, unpack_xy(sm.xy[k]), s_table, dist);
+            if (ok && dist < 30.0f) {
+                atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
+                atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
+            }
+        }
+    }
+    __syncthreads();
+    PHASE(8);
+    uint32_t row[SM::W];
+#pragma unroll
+    for (int w = 0; w < SM::W; ++w) row[w] = t < num ? sm.hb[t][w] : 0u;
     // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle)
     for (int it = 0; it < ITERS; ++it) {
         if (t < num) {
             float acc = 0.0f;
-            int a = t - 1;                               // address of H[0][t] in the triangle (k < t part walks down column t)
-#pragma unroll 4
-            for (int k = 0; k < t; ++k) {                // H[k][t]
-                const float p = sm.H[a] * sm.b[k];
-                acc += p;
-                a += num - k - 2;
-            }
-            // k == t contributes H[t][t]*b[t] = 0 (+0.0f leaves acc unchanged)
-            a = tri_off(t, num);
-#pragma unroll 4
-            for (int k = t + 1; k < num; ++k) {          // H[t][k], contiguous
-                const float p = sm.H[a] * sm.b[k];
-                acc += p;
-                ++a;
+            int n = 0;
+#pragma unroll
+            for (int w = 0; w < SM::W; ++w) {
+                uint32_t bits = row[w];
+                while (bits) {
+                    const int k = w * 32 + __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    float h;
+                    if (it == 0 || n >= CACHE) {
+                        float dist;
+                        pair_dist<LOOKUP>(me, unpack_xy(sm.xy[k]), s_table, dist);
+                        h = h_value(dist);
+                        if (n < CACHE) sm.stash[n * NMAX + t] = h;
+                    } else h = sm.stash[n * NMAX + t];
+                    const float p = h * sm.b[k];
+                    acc += p;
+                    ++n;
+                }
             }
             sm.cc[t] = acc;
         }
@@ -261,12 +292,19 @@ __device__ int dist_filter(GraphSmem<NMAX>& sm, int num, const float* s_table)
         if (t < num) sm.b[t] = sm.cc[t] * scale;          // nobody reads b between the barrier above and the one below
         __syncthreads();
     }
+    PHASE(9);
     sort_scores(sm, num);
-    greedy<NMAX>(sm, num, 0.0001, [&sm, num](int a, int o) {
-        const float h = a < o ? sm.H[tri(a, o, num)] : sm.H[tri(o, a, num)];
-        return !((double)h < 0.00001);
+    PHASE(10);
+    greedy<NMAX>(sm, num, 0.0001, [&sm, s_table](int a, int o) {
+        if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
+        float dist;
+        pair_dist<LOOKUP>(unpack_xy(sm.xy[a]), unpack_xy(sm.xy[o]), s_table, dist);
+        return !((double)h_value(dist) < 0.00001);
     });
-    return compact(sm);
+    PHASE(11);
+    const int nc = compact(sm);
+    PHASE(12);
+    return nc;
 }
 
 __device__ __forceinline__ float adjust_angle(float angle)            // matcher.cpp:1638-1647
@@ -284,39 +322,56 @@ __device__ __forceinline__ float fold_pi(float d)                      // "if(an
 // rounded atan2f except for results within 1e-16 relative of a rounding boundary.  The value only feeds threshold tests.
 __device__ __forceinline__ float atan2_f32(float y, float x) { return (float)atan2((double)y, (double)x); }
 
-// S9, matcher.cpp:1471-1636
-template <int NMAX>
-__device__ int angle_filter(GraphSmem<NMAX>& sm, int num)
+// the three angle tests of matcher.cpp:1495-1549 for the ordered pair (1 = lower index, 2 = higher index)
+__device__ __forceinline__ bool angle_compatible(const Pt& p1, float lo1, float ro1, const Pt& p2, float lo2, float ro2)
 {
-    constexpr int W = (NMAX + 31) / 32;
+    float angle_1 = adjust_angle(lo1 - lo2);
+    float angle_2 = adjust_angle(ro1 - ro2);
+    float angle_diff = fold_pi(fabsf(angle_1 - angle_2));
+    if ((double)angle_diff > AFIS_PI / 4.) return false;
+    const float dx_1 = (float)(p1.lx - p2.lx), dy_1 = (float)(p1.ly - p2.ly);
+    const float line_angle_1 = -atan2_f32(dy_1, dx_1);
+    angle_1 = adjust_angle(lo1 - line_angle_1);
+    const float dx_2 = (float)(p1.rx - p2.rx), dy_2 = (float)(p1.ry - p2.ry);
+    const float line_angle_2 = -atan2_f32(dy_2, dx_2);
+    angle_2 = adjust_angle(ro1 - line_angle_2);
+    angle_diff = fold_pi(fabsf(angle_1 - angle_2));
+    if ((double)angle_diff > AFIS_PI / 6.) return false;
+    angle_1 = adjust_angle(lo2 - line_angle_1);
+    angle_2 = adjust_angle(ro2 - line_angle_2);
+    angle_diff = fold_pi(fabsf(angle_1 - angle_2));
+    if ((double)angle_diff > AFIS_PI / 6.) return false;
+    return true;
+}
+
+// S9, matcher.cpp:1471-1636
+template <int NMAX, int CACHE>
+__device__ int angle_filter(GraphSmem<NMAX, CACHE>& sm, int num)
+{
+    typedef GraphSmem<NMAX, CACHE> SM;
     const int t = threadIdx.x;
-    for (int i = t; i < num * W; i += kTailThreads) sm.hb[i / W][i % W] = 0u;
-    if (t < (NMAX + 3) / 4 * 4) { sm.b[t] = t < num ? (float)(1.0 / num) : 0.0f; sm.cc[t] = 0.0f; }   // :1558
+    PHASE_INIT();
+    for (int i = t; i < num * SM::W; i += kTailThreads) sm.hb[i / SM::W][i % SM::W] = 0u;
+    if (t < SM::N4) { sm.b[t] = t < num ? (float)(1.0 / num) : 0.0f; sm.cc[t] = 0.0f; }   // :1558
     __syncthreads();
-    const int n_pairs = num * (num - 1) / 2;
-    for (int p = t; p < n_pairs; p += kTailThreads) {
-        int i, j; tri_inv(p, num, i, j);
-        const float lo1 = sm.c.lo[i], lo2 = sm.c.lo[j], ro1 = sm.c.ro[i], ro2 = sm.c.ro[j];
-        float angle_1 = adjust_angle(lo1 - lo2);
-        float angle_2 = adjust_angle(ro1 - ro2);
-        float angle_diff = fold_pi(fabsf(angle_1 - angle_2));
-        if ((double)angle_diff > AFIS_PI / 4.) continue;
-        const float dx_1 = (float)(sm.c.lx[i] - sm.c.lx[j]), dy_1 = (float)(sm.c.ly[i] - sm.c.ly[j]);
-        const float line_angle_1 = -atan2_f32(dy_1, dx_1);
-        angle_1 = adjust_angle(lo1 - line_angle_1);
-        const float dx_2 = (float)(sm.c.rx[i] - sm.c.rx[j]), dy_2 = (float)(sm.c.ry[i] - sm.c.ry[j]);
-        const float line_angle_2 = -atan2_f32(dy_2, dx_2);
-        angle_2 = adjust_angle(ro1 - line_angle_2);
-        angle_diff = fold_pi(fabsf(angle_1 - angle_2));
-        if ((double)angle_diff > AFIS_PI / 6.) continue;
-        angle_1 = adjust_angle(lo2 - line_angle_1);
-        angle_2 = adjust_angle(ro2 - line_angle_2);
-        angle_diff = fold_pi(fabsf(angle_1 - angle_2));
-        if ((double)angle_diff > AFIS_PI / 6.) continue;
-        atomicOr(&sm.hb[i][j >> 5], 1u << (j & 31));
-        atomicOr(&sm.hb[j][i >> 5], 1u << (i & 31));
+    if (t < num) {
+        const Pt me = unpack_xy(sm.xy[t]);
+        const float mlo = sm.lo[t], mro = sm.ro[t];
+        const int half = num >> 1;
+        for (int d = 1; d <= half; ++d) {
+            if (d == half && !(num & 1) && t >= half) break;
+            int k = t + d; if (k >= num) k -= num;
+            const Pt o = unpack_xy(sm.xy[k]);
+            const float olo = sm.lo[k], oro = sm.ro[k];
+            const bool c = t < k ? angle_compatible(me, mlo, mro, o, olo, oro) : angle_compatible(o, olo, oro, me, mlo, mro);
+            if (c) {
+                atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
+                atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
+            }
+        }
     }
     __syncthreads();
+    PHASE(16);
     for (int it = 0; it < 5; ++it) {                                    // :1563-1581
         if (t < num) {
             float s1 = 0.0f;
@@ -332,34 +387,39 @@ __device__ int angle_filter(GraphSmem<NMAX>& sm, int num)
         if (t < num) sm.b[t] = sm.cc[t] * sum;
         __syncthreads();
     }
+    PHASE(17);
     sort_scores(sm, num);
     greedy<NMAX>(sm, num, 0.001, [&sm](int a, int o) { return (sm.hb[a][o >> 5] >> (o & 31)) & 1u; });
-    return compact(sm);
+    PHASE(18);
+    const int nc = compact(sm);
+    PHASE(19);
+    return nc;
 }
 
-template <int NMAX>
-__device__ __forceinline__ float sum_sims(const GraphSmem<NMAX>& sm, int n)   // :508-514 / :775-781
+template <class SM>
+__device__ __forceinline__ float sum_sims(const SM& sm, int n)   // :508-514 / :775-781
 {
     float score = 0.0f;
-    for (int i = 0; i < n; ++i) score += sm.c.sim[i];
+    for (int i = 0; i < n; ++i) score += sm.sim[i];
     return score;
 }
 
 // both graph stages; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
-template <int NMAX, bool LOOKUP, int ITERS>
-__device__ __forceinline__ float graph_score(GraphSmem<NMAX>& sm, int num, const float* s_table)
+template <int NMAX, int CACHE, bool LOOKUP, int ITERS>
+__device__ __forceinline__ float graph_score(GraphSmem<NMAX, CACHE>& sm, int num, const float* s_table)
 {
-    num = dist_filter<NMAX, LOOKUP, ITERS>(sm, num, s_table);
+    num = dist_filter<NMAX, CACHE, LOOKUP, ITERS>(sm, num, s_table);
     if (num < 2) return 0.0f;
-    num = angle_filter<NMAX>(sm, num);
+    num = angle_filter<NMAX, CACHE>(sm, num);
     return sum_sims(sm, num);
 }
 
 // =====================================================================================================================
 // texture tail
 // =====================================================================================================================
+constexpr int kTexCache = 24;
 struct TexSmem {
-    GraphSmem<kTopTex> g;
+    GraphSmem<kTopTex, kTexCache> g;
     float table[kDistN * kDistN];
     float tval[kTopTex];            // staging of the selected rows before they are ordered by rank
     short te[kTopTex], targ[kTopTex];
@@ -426,19 +486,19 @@ __global__ __launch_bounds__(kTailThreads) void k_texture_tail(QueryDev q, Galle
             num = kTopTex;
             int r = 0;
             if (t < num) r = rank_of(sm.g.keys, num, sm.g.keys[t]);
-            if (t < num) { sm.g.c.sim[r] = sm.tval[t]; sm.g.c.li[r] = sm.te[t]; sm.g.c.ri[r] = sm.targ[t]; }
+            if (t < num) { sm.g.sim[r] = sm.tval[t]; sm.g.li[r] = sm.te[t]; sm.g.ri[r] = sm.targ[t]; }
         } else {                                                         // :748-749 rows stay in index order
             num = n_lt;
-            if (t < num) { sm.g.c.sim[t] = rm_val[o + t]; sm.g.c.li[t] = (short)t; sm.g.c.ri[t] = (short)rm_arg[o + t]; }
+            if (t < num) { sm.g.sim[t] = rm_val[o + t]; sm.g.li[t] = (short)t; sm.g.ri[t] = (short)rm_arg[o + t]; }
         }
         __syncthreads();
         if (t < num) {
-            const short2 lp = q.lt_xy[l0 + sm.g.c.li[t]], rp = g.tex_xy[r0 + sm.g.c.ri[t]];
-            sm.g.c.lx[t] = lp.x; sm.g.c.ly[t] = lp.y; sm.g.c.rx[t] = rp.x; sm.g.c.ry[t] = rp.y;
-            sm.g.c.lo[t] = q.lt_ori[l0 + sm.g.c.li[t]]; sm.g.c.ro[t] = g.tex_ori[r0 + sm.g.c.ri[t]];
+            const short2 lp = q.lt_xy[l0 + sm.g.li[t]], rp = g.tex_xy[r0 + sm.g.ri[t]];
+            sm.g.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
+            sm.g.lo[t] = q.lt_ori[l0 + sm.g.li[t]]; sm.g.ro[t] = g.tex_ori[r0 + sm.g.ri[t]];
         }
         __syncthreads();
-        const float score = graph_score<kTopTex, true, 3>(sm.g, num, sm.table);   // :759, :767
+        const float score = graph_score<kTopTex, kTexCache, true, 3>(sm.g, num, sm.table);   // :759, :767
         if (t == 0) *out = score;
         __syncthreads();
     }
@@ -463,18 +523,22 @@ hipError_t launch_texture_tail(const QueryDev& q, const GalleryDev& g, const flo
 // =====================================================================================================================
 // minutiae scorer
 // =====================================================================================================================
-constexpr int kGemmTile = 64;
-constexpr int kGemmLd = 100;          // padded row stride (floats): 16-byte aligned rows, conflict-free b128 column walks
-constexpr int kMinuMaxPts = 2000;     // Max_Nrof_Minutiae, matcher.cpp:788
-constexpr int kKeyRegs = 16;          // per-thread keys held in registers when nL*nR <= 256*16
+constexpr int kMinuCache = 16;
+constexpr int kGemmRows = 64;       // latent rows per GEMM tile
+constexpr int kGemmCols = 32;       // rolled columns per GEMM tile
+constexpr int kGemmLd = 100;        // padded row stride (floats): 16-byte aligned rows, conflict-free b128 column walks
+constexpr int kKeyRegs = 16;        // per-thread keys held in registers when nL*nR <= 256*16
+constexpr int kFastL = 64, kFastR = 128;          // pair shapes whose whole similarity matrix stays in LDS
+constexpr int kFastN = kFastL * kFastR;
 
 struct MinuSmem {
     union {
-        struct { float A[kGemmTile * kGemmLd]; float B[kGemmTile * kGemmLd]; } t;    // 51.2 KB, GEMM phase
-        GraphSmem<kTopMinu> g;                                                        // graph phase
+        struct { float A[kGemmRows * kGemmLd]; float B[kGemmCols * kGemmLd]; } t;    // 38.4 KB, GEMM phase
+        GraphSmem<kTopMinu, kMinuCache> g;                                            // graph phase
     } u;
-    float rowsum[kMinuMaxPts];
-    float colsum[kMinuMaxPts];
+    float simi[kFastN];             // 32 KB
+    float rowsum[kFastL];
+    float colsum[kFastR];
     int te[kTopMinu];
 };
 
@@ -518,12 +582,13 @@ __device__ void select_topk(int n, int K, KeyFn key, u64* list, int* elist, int*
     __syncthreads();
 }
 
+// Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2000] | colsum[2000]
 __global__ __launch_bounds__(kTailThreads) void k_minutiae(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
                                                            float* __restrict__ parts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
-    float* simi = scratch + (size_t)blockIdx.x * scratch_per_wg;
+    float* gscr = scratch + (size_t)blockIdx.x * scratch_per_wg;
     int parity = 0;
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     const int tid = threadIdx.x;
@@ -537,35 +602,47 @@ __global__ __launch_bounds__(kTailThreads) void k_minutiae(QueryDev q, GalleryDe
         float* out = parts + ((size_t)qi * g.G + gi) * 4 + s;
         if (nL <= 0 || nR <= 0) { if (tid == 0) *out = 0.0f; continue; }     // matcher.cpp:400-404
         const int n = nL * nR;
-        uint32_t* gkeys = reinterpret_cast<uint32_t*>(simi + (scratch_per_wg >> 1));
+        PHASE_INIT();
+        const bool fast = nL <= kFastL && nR <= kFastR;
+        const size_t half = (scratch_per_wg - 4096) >> 1;
+        float* simi = fast ? sm.simi : gscr;
+        uint32_t* gkeys = reinterpret_cast<uint32_t*>(gscr + half);
+        float* rowsum = fast ? sm.rowsum : gscr + 2 * half;
+        float* colsum = fast ? sm.colsum : gscr + 2 * half + 2048;
 
         // ---- S1: simi = max(0, A * B^T), canonical order = fmaf chain, k ascending (matcher.cpp:440-452) ----
-        for (int it = 0; it < nL; it += kGemmTile) {
-            for (int jt = 0; jt < nR; jt += kGemmTile) {
-                __syncthreads();
-                for (int e = tid; e < kGemmTile * (kDes / 4); e += kTailThreads) {
+        for (int it = 0; it < nL; it += kGemmRows) {
+            __syncthreads();
+            for (int e = tid; e < kGemmRows * (kDes / 4); e += kTailThreads) {
+                const int r = e / (kDes / 4), k4 = e - r * (kDes / 4);
+                float4 a = make_float4(0, 0, 0, 0);
+                if (it + r < nL) a = *reinterpret_cast<const float4*>(q.lm_des + (size_t)(l0 + it + r) * kDes + k4 * 4);
+                *reinterpret_cast<float4*>(&sm.u.t.A[r * kGemmLd + k4 * 4]) = a;
+            }
+            for (int jt = 0; jt < nR; jt += kGemmCols) {
+                if (jt) __syncthreads();
+                for (int e = tid; e < kGemmCols * (kDes / 4); e += kTailThreads) {
                     const int r = e / (kDes / 4), k4 = e - r * (kDes / 4);
-                    float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
-                    if (it + r < nL) a = *reinterpret_cast<const float4*>(q.lm_des + (size_t)(l0 + it + r) * kDes + k4 * 4);
+                    float4 b = make_float4(0, 0, 0, 0);
                     if (jt + r < nR) b = *reinterpret_cast<const float4*>(g.minu_des + (size_t)(r0 + jt + r) * kDes + k4 * 4);
-                    *reinterpret_cast<float4*>(&sm.u.t.A[r * kGemmLd + k4 * 4]) = a;
                     *reinterpret_cast<float4*>(&sm.u.t.B[r * kGemmLd + k4 * 4]) = b;
                 }
                 __syncthreads();
-                const int ty = tid >> 4, tx = tid & 15;              // rows ty + 16*r, cols tx + 16*c
-                float acc[4][4];
+                const int ty = tid >> 3, tx = tid & 7;               // rows ty + 32*r (r < 2), cols tx + 8*c (c < 4)
+                float acc[2][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+#pragma unroll 4
                 for (int k4 = 0; k4 < kDes / 4; ++k4) {
-                    float4 a[4], b[4];
+                    float4 a[2], b[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const float4*>(&sm.u.t.A[(ty + 16 * r) * kGemmLd + k4 * 4]);
+                    for (int r = 0; r < 2; ++r) a[r] = *reinterpret_cast<const float4*>(&sm.u.t.A[(ty + 32 * r) * kGemmLd + k4 * 4]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(&sm.u.t.B[(tx + 16 * c) * kGemmLd + k4 * 4]);
+                    for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(&sm.u.t.B[(tx + 8 * c) * kGemmLd + k4 * 4]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 2; ++r)
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             float v = acc[r][c];
@@ -575,26 +652,38 @@ __global__ __launch_bounds__(kTailThreads) void k_minutiae(QueryDev q, GalleryDe
                         }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int i = it + ty + 16 * r, j = jt + tx + 16 * c;
+                        const int i = it + ty + 32 * r, j = jt + tx + 8 * c;
                         if (i < nL && j < nR) { float v = acc[r][c]; if (v < 0) v = 0; simi[(size_t)i * nR + j] = v; }
                     }
             }
         }
         __syncthreads();
+        PHASE(0);
         // ---- S2: column sums (rolled) / row sums (latent), index ascending (:455-456) ----
-        for (int j = tid; j < nR; j += kTailThreads) { float sacc = 0.f; for (int i = 0; i < nL; ++i) sacc += simi[(size_t)i * nR + j]; sm.colsum[j] = sacc; }
-        for (int i = tid; i < nL; i += kTailThreads) { float sacc = 0.f; for (int j = 0; j < nR; ++j) sacc += simi[(size_t)i * nR + j]; sm.rowsum[i] = sacc; }
+        for (int j = tid; j < nR; j += kTailThreads) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < nL; ++i) sacc += simi[(size_t)i * nR + j];
+            colsum[j] = sacc;
+        }
+        for (int i = tid; i < nL; i += kTailThreads) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < nR; ++j) sacc += simi[(size_t)i * nR + j];
+            rowsum[i] = sacc;
+        }
         __syncthreads();
+        PHASE(1);
         // ---- S3: top-120 by normalised similarity (:461-488) ----
-        GraphSmem<kTopMinu>& gs = sm.u.g;
+        GraphSmem<kTopMinu, kMinuCache>& gs = sm.u.g;
         const int topN = n < kTopMinu ? n : kTopMinu;
         auto norm_key = [&](int e) {
             const int i = e / nR, j = e - i * nR;
             const float sv = simi[e];
-            float f = sm.rowsum[i] + sm.colsum[j];
+            float f = rowsum[i] + colsum[j];
             f = f - sv;
             return ord_f32((float)((double)sv / ((double)f + 0.000001)));                        // :467
         };
@@ -602,6 +691,7 @@ __global__ __launch_bounds__(kTailThreads) void k_minutiae(QueryDev q, GalleryDe
             uint32_t rk[kKeyRegs];
 #pragma unroll
             for (int u = 0; u < kKeyRegs; ++u) { const int e = tid + u * kTailThreads; rk[u] = e < n ? norm_key(e) : 0u; }
+            PHASE(2);
             // (same search as select_topk, with the register array; written out because a lambda cannot index registers dynamically)
             uint32_t T = 0;
             for (int bit = 31; bit >= 0; --bit) {
@@ -640,24 +730,27 @@ __global__ __launch_bounds__(kTailThreads) void k_minutiae(QueryDev q, GalleryDe
                 }
             }
             __syncthreads();
-        } else {                                                         // large templates: keys in the global scratch
+        } else {                                                         // large pairs: keys in the global scratch
             for (int e = tid; e < n; e += kTailThreads) gkeys[e] = norm_key(e);
             __syncthreads();
             select_topk(n, topN, [gkeys](int e) { return gkeys[e]; }, gs.keys, sm.te, gs.slots, parity, &gs.counter);
         }
+        PHASE(3);
         if (tid < topN) {
             const int r = rank_of(gs.keys, topN, gs.keys[tid]);
             const int e = sm.te[tid];
             const int i1 = e / nR, i2 = e - i1 * nR;
-            gs.c.sim[r] = simi[e]; gs.c.li[r] = (short)i1; gs.c.ri[r] = (short)i2;
+            gs.sim[r] = simi[e]; gs.li[r] = (short)i1; gs.ri[r] = (short)i2;
             const short2 lp = q.lm_xy[l0 + i1], rp = g.minu_xy[r0 + i2];
-            gs.c.lx[r] = lp.x; gs.c.ly[r] = lp.y; gs.c.rx[r] = rp.x; gs.c.ry[r] = rp.y;
-            gs.c.lo[r] = q.lm_ori[l0 + i1]; gs.c.ro[r] = g.minu_ori[r0 + i2];
+            gs.xy[r] = pack_xy(lp.x, lp.y, rp.x, rp.y);
+            gs.lo[r] = q.lm_ori[l0 + i1]; gs.ro[r] = g.minu_ori[r0 + i2];
         }
         __syncthreads();
-        const float score = graph_score<kTopMinu, false, 5>(gs, topN, nullptr);   // :492, :495
+        PHASE(4);
+        const float score = graph_score<kTopMinu, kMinuCache, false, 5>(gs, topN, nullptr);   // :492, :495
         if (tid == 0) *out = score;
         __syncthreads();
+        PHASE(5);
     }
 }
 
@@ -698,6 +791,19 @@ __global__ __launch_bounds__(256) void k_fuse(QueryDev q, GalleryDev g, const fl
     float f = a0 + a1;
     f = f + a2;
     scores[idx] = (float)((double)f + (double)a28 * 0.3);
+}
+
+hipError_t read_phase_cycles(unsigned long long* out32, bool reset)
+{
+#ifdef AFIS_PHASE_TIMING
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_cycles), 32 * sizeof(u64));
+    if (e != hipSuccess) return e;
+    if (reset) { u64 z[32] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)); }
+    return e;
+#else
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    return hipSuccess;
+#endif
 }
 
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream)

@@ -44,7 +44,7 @@ class Timing(C.Structure):
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax"]
+           "afis_search_resident", "afis_queries_free", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -71,6 +71,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.afis_debug_lut.argtypes = [vp, C.POINTER(TemplateView), fp, i32p]
     lib.afis_debug_texture_rowmax.argtypes = [vp, C.POINTER(TemplateView), C.c_int64, fp, i32p, i32p]
+    lib.afis_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     return lib
 
 
@@ -214,6 +215,11 @@ class Matcher:
         t = Timing()
         self._chk(self.lib.afis_get_timing(self.ctx, C.byref(t)))
         return {n: getattr(t, n) for n, _ in Timing._fields_}
+
+    def phase_cycles(self, reset: bool = True):
+        out = (C.c_uint64 * 32)()
+        self._chk(self.lib.afis_debug_phase_cycles(self.ctx, out, 1 if reset else 0))
+        return list(out)
 
     # ---- parity taps ------------------------------------------------------------------------------------------
     def debug_lut(self, latent: FPTemplate) -> np.ndarray:
