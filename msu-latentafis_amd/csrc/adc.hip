@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_lut_build(QueryDev q, const float* __re
         v[r] = lut_entry(des6, cw6);
     }
     float4* t4 = reinterpret_cast<float4*>(lut_tiles + (size_t)tile * kTileFloats);
-    if (variant == 0) {
+    if ((variant & 1) == 0) {
         t4[(0 * 16 + m) * 256 + k] = make_float4(v[0], v[1], v[2], v[3]);
         t4[(1 * 16 + m) * 256 + k] = make_float4(v[4], v[5], v[6], v[7]);
     } else {
@@ -94,8 +94,7 @@ hipError_t launch_lut_reference_layout(const float* des, int n, const float* cod
 // ---------------------------------------------------------------------------------------------------------------
 // S5 + S6
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kAdcThreads = 512;       // 8 waves: 2 per SIMD
-constexpr int kAdcWaves = kAdcThreads / 64;
+// workgroup size is a template parameter: 512 threads = 2 waves per SIMD (<= 256 VGPRs), 1024 = 4 waves per SIMD (<= 128 VGPRs)
 
 __device__ __forceinline__ void wave_argmax(float& v, int& i)
 {
@@ -110,7 +109,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i)
     }
 }
 
-template <int VARIANT>
+template <int VARIANT, int kAdcThreads>
 __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
                                                             int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
 {
@@ -134,6 +133,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax(QueryDev q, GalleryD
     }
     __syncthreads();
 
+    constexpr int kAdcWaves = kAdcThreads / 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g_lo = chunk_id * chunk;
@@ -237,10 +237,13 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
     const int n_chunks = (g.G + chunk - 1) / chunk;
     const long long blocks = (long long)((n_chunks + 7) / 8) * 8 * q.n_tiles;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (variant == 0)
-        hipLaunchKernelGGL(k_adc_rowmax<0>, dim3((unsigned)blocks), dim3(kAdcThreads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg);
-    else
-        hipLaunchKernelGGL(k_adc_rowmax<1>, dim3((unsigned)blocks), dim3(kAdcThreads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg);
+    const int threads = variant >= 2 ? 1024 : 512;             // variants 2,3 = variants 0,1 with 1024-thread workgroups
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((k_adc_rowmax<0, 512>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 1: hipLaunchKernelGGL((k_adc_rowmax<1, 512>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 2: hipLaunchKernelGGL((k_adc_rowmax<0, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    default: hipLaunchKernelGGL((k_adc_rowmax<1, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    }
     return hipGetLastError();
 }
 

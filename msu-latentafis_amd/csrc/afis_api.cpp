@@ -73,11 +73,11 @@ struct afis_ctx {
     DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_empty;
     int max_nR = 0;
     int64_t total_tex_points = 0;
-    DevBuf lut, rm_val, rm_arg, parts, scores, scratch;
+    DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 1;
     int query_batch = 8;
-    int chunk = 64;
+    int chunk = 128;
     int64_t rowmax_budget_bytes = 24ll << 30;
     afis_timing timing = {};
 };
@@ -201,7 +201,7 @@ void afis_destroy(afis_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
-    c->parts.release(); c->scores.release(); c->scratch.release();
+    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -422,15 +422,18 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             int n_wg = 1024;
             while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
+            HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
+            HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             hipStream_t s = ctx->stream;
             HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
             HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), ctx->chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-            HIPCHK(ctx, launch_texture_tail(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
+            HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
-            HIPCHK(ctx, launch_minutiae(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->parts.as<float>(), s));
+            HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
+            HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
@@ -508,7 +511,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
-    if (n == "adc_variant") { if (value < 0 || value > 1) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0 or 1"); ctx->adc_variant = (int)value; }
+    if (n == "adc_variant") { if (value < 0 || value > 3) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3"); ctx->adc_variant = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 1 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 1..65536"); ctx->chunk = (int)value; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }

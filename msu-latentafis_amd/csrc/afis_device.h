@@ -55,12 +55,18 @@ hipError_t launch_lut_build(const QueryDev& q, const float* codewords, float* lu
 // S5+S6: ADC similarity + per-row (max, first argmax) for queries [q0, q0+nq) against gallery templates.
 hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
                              float* rm_val, int32_t* rm_arg, hipStream_t stream);
-// S7+S8b+S9: texture tail -> parts[(q*G+g)*4+3]
-hipError_t launch_texture_tail(const QueryDev& q, const GalleryDev& g, const float* table_dist,
-                               const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream);
-// S1-S3+S8a+S9 for the three selected latent minutiae templates -> parts[(q*G+g)*4+{0,1,2}]
-hipError_t launch_minutiae(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                           float* parts, hipStream_t stream);
+// one correspondence of a minutiae-template list (S3 output), 8 bytes
+struct MinuCand { float sim; short li, ri; };
+// S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]
+hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
+                                const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream);
+// S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
+// (task = (q*3+s)*G + g)
+hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
+                             MinuCand* cands, int32_t* cand_n, hipStream_t stream);
+// S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
+hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
+                                 float* parts, hipStream_t stream);
 // S10: fusion -> scores[q*G+g]
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 

@@ -1,0 +1,536 @@
+// graph.hip — the geometric-consistency stages of a (latent, rolled) pair, one WAVE per correspondence list:
+//   S7  top-200 texture rows (matching/matcher.cpp:736-749)
+//   S8a LSS_R_Fast2_Dist_eigen  (matcher.cpp:1350-1469; pixels, sqrtf, 5 power iterations)  — minutiae lists, <= 120 entries
+//   S8b LSS_R_Fast2_Dist_lookup (matcher.cpp:1225-1348; blocks, table_dist, 3 iterations)   — texture lists,  <= 200 entries
+//   S9  LSS_R_Fast2 + adjust_angle (matcher.cpp:1471-1647)
+//   and the final sum of the surviving similarities (matcher.cpp:508-514, :775-781).
+//
+// Why one wave per list: the work is a chain of short, partly serial phases (sorts, a greedy clique selection, sequential
+// float sums).  A 64-lane workgroup needs no barriers, never has idle waves, and at ~20 KB of LDS eight of them fit on a CU,
+// which is what hides the LDS / transcendental latency of each chain.  Lane l owns rows l, l+64, ... of the list.
+//
+// Every float reduction keeps the reference's sequential order (index ascending, product and sum rounded separately; the
+// file is compiled with -ffp-contract=off); where the reference's order is Eigen's (unpinned) the canonical order of
+// oracle/afis_oracle.cpp is used.  Equal sort keys are ordered by ascending index.
+//
+// How the reference's serial steps are mapped without changing their results:
+//   * std::sort of <= 200 keys        -> rank by counting (each key counts the keys larger than itself);
+//   * "top 200 of n <= 1000"          -> bit-by-bit search for the 200th largest key with ballot/popcount (all keys in registers);
+//   * greedy clique selection          -> rounds: the first still-alive candidate in rank order is accepted and every later
+//                                        candidate that conflicts with it is killed in parallel; identical to the sequential
+//                                        scan, but the trip count is the number of ACCEPTED candidates;
+//   * H (200x200 fp32 = 160 KB)        -> never stored: LDS keeps the bitmask of its non-zero entries, values are recomputed on
+//                                        demand and cached per row; a zero entry would only add +0.0f, so skipping it is exact.
+#include "afis_device.h"
+
+namespace afis {
+
+#define AFIS_PI 3.1415926   /* matching/include.h:22 — a double literal; comparisons against it are in double */
+typedef unsigned long long u64;
+
+__device__ __forceinline__ uint32_t g_ord_f32(float v)
+{
+    v = v + 0.0f;                                   // -0 -> +0 so that equal floats get equal keys
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ u64 g_make_key(float v, int idx) { return ((u64)g_ord_f32(v) << 32) | (uint32_t)(~(uint32_t)idx); }
+__device__ __forceinline__ int g_wave_popc(bool p) { return __popcll(__ballot(p)); }
+__device__ __forceinline__ int g_lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
+// single-wave workgroup: orders this wave's LDS traffic (s_barrier is free for one wave)
+#define WSYNC() __syncthreads()
+
+struct Pt { int lx, ly, rx, ry; };
+__device__ __forceinline__ int2 pack_xy(int lx, int ly, int rx, int ry) { return make_int2((lx & 0xffff) | (ly << 16), (rx & 0xffff) | (ry << 16)); }
+__device__ __forceinline__ Pt unpack_xy(int2 v) { Pt p; p.lx = (int)(short)v.x; p.ly = v.x >> 16; p.rx = (int)(short)v.y; p.ry = v.y >> 16; return p; }
+
+template <int NMAX_, int CACHE_>
+struct __attribute__((aligned(16))) WaveSmem {
+    static constexpr int NMAX = NMAX_, CACHE = CACHE_;
+    static constexpr int W = (NMAX + 31) / 32;
+    static constexpr int N4 = (NMAX + 3) / 4 * 4;
+    static constexpr int U = (NMAX + 63) / 64;
+    float b[N4];                           // 16-byte aligned: read as float4 broadcasts
+    float cc[N4];
+    float sim[NMAX];
+    short li[NMAX], ri[NMAX];
+    int2 xy[NMAX];                         // .x = lx | ly << 16 (latent point), .y = rx | ry << 16 (rolled point)
+    float lo[NMAX], ro[NMAX];
+    uint32_t hb[NMAX][W];                  // bit rows: non-zero pattern of H (distance stage), then the boolean H of the angle stage
+    union {
+        float stash[CACHE * NMAX];         // [n][t]: value of the n-th non-zero of row t (distance stage)
+        struct { float tval[NMAX]; short te[NMAX], targ[NMAX]; } pick;   // texture rows picked by S7, before they are ranked
+    } x;
+    u64 keys[N4];
+    short order[NMAX];                     // rank -> candidate index
+    short sel[NMAX];
+    int nsel;
+};
+
+// ranks (0 = largest) of this lane's U keys among keys[0..n); keys are unique
+template <int U>
+__device__ __forceinline__ void rank_keys(const u64* keys, int n, const u64 (&mine)[U], int (&r)[U])
+{
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = 0;
+#pragma unroll 4
+    for (int k = 0; k < n; ++k) {
+        const u64 kk = keys[k];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] += kk > mine[u];
+    }
+}
+
+// sort the candidates by score b (descending, ties by index): order[rank] = index
+template <class SM>
+__device__ __forceinline__ void sort_scores(SM& sm, int num)
+{
+    const int lane = threadIdx.x;
+    u64 mine[SM::U]; int r[SM::U];
+#pragma unroll
+    for (int u = 0; u < SM::U; ++u) {
+        const int t = lane + 64 * u;
+        mine[u] = t < num ? g_make_key(sm.b[t], t) : 0ull;
+        if (t < num) sm.keys[t] = mine[u];
+    }
+    WSYNC();
+    rank_keys<SM::U>(sm.keys, num, mine, r);
+#pragma unroll
+    for (int u = 0; u < SM::U; ++u) { const int t = lane + 64 * u; if (t < num) sm.order[r[u]] = (short)t; }
+    WSYNC();
+}
+
+// Greedy selection, matcher.cpp:1304-1344 / :1425-1465 / :1593-1633: walk the candidates by descending S; stop at S < thr;
+// skip a candidate whose latent or rolled point is already used or that is incompatible with ANY accepted one.
+// The wave holds the candidates in rank order (lane l: ranks l, l+64, ...).  Each round accepts the first alive candidate and
+// kills every later one that conflicts with it.  Accepted indices go to sm.sel[0..nsel) in acceptance (= rank) order.
+template <class SM, class Compat>
+__device__ int greedy(SM& sm, int num, double thr, Compat compatible)
+{
+    const int lane = threadIdx.x;
+    constexpr int U = SM::U;
+    int idx[U], li[U], ri[U];
+    bool alive[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = lane + 64 * u;
+        idx[u] = 0; li[u] = -1; ri[u] = -1; alive[u] = false;
+        if (p < num) {
+            idx[u] = sm.order[p];
+            li[u] = sm.li[idx[u]]; ri[u] = sm.ri[idx[u]];
+            alive[u] = !((double)sm.b[idx[u]] < thr);          // sorted descending: everything after the first S < thr is < thr too
+        }
+    }
+    int nsel = 0;
+    for (;;) {
+        int first = -1, cidx = 0, cli = 0, cri = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const u64 m = __ballot(alive[u]);
+            if (first < 0 && m) {
+                const int fl = __ffsll((long long)m) - 1;
+                first = 64 * u + fl;
+                cidx = __shfl(idx[u], fl); cli = __shfl(li[u], fl); cri = __shfl(ri[u], fl);
+            }
+        }
+        if (first < 0) break;
+        if (lane == 0) sm.sel[nsel] = (short)cidx;
+        ++nsel;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (alive[u]) {
+                const int p = lane + 64 * u;
+                if (p == first || li[u] == cli || ri[u] == cri || !compatible(cidx, idx[u])) alive[u] = false;
+            }
+        }
+    }
+    WSYNC();
+    return nsel;
+}
+
+// keep only the accepted correspondences, in acceptance order
+template <class SM>
+__device__ void compact(SM& sm, int n)
+{
+    const int lane = threadIdx.x;
+    float sim[SM::U], lo[SM::U], ro[SM::U]; short li[SM::U], ri[SM::U]; int2 xy[SM::U];
+#pragma unroll
+    for (int u = 0; u < SM::U; ++u) {
+        const int t = lane + 64 * u;
+        if (t < n) { const int s = sm.sel[t]; sim[u] = sm.sim[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; lo[u] = sm.lo[s]; ro[u] = sm.ro[s]; }
+    }
+    WSYNC();
+#pragma unroll
+    for (int u = 0; u < SM::U; ++u) {
+        const int t = lane + 64 * u;
+        if (t < n) { sm.sim[t] = sim[u]; sm.li[t] = li[u]; sm.ri[t] = ri[u]; sm.xy[t] = xy[u]; sm.lo[t] = lo[u]; sm.ro[t] = ro[u]; }
+    }
+    WSYNC();
+}
+
+// sum of cc[0..num) in ascending order; cc is zero-padded to a multiple of 4 (x + 0.0f == x)
+template <class SM>
+__device__ __forceinline__ float seq_sum(const SM& sm, int num)
+{
+    float sum = 0.0f;
+    const float4* c4 = reinterpret_cast<const float4*>(sm.cc);
+#pragma unroll 4
+    for (int k = 0; k < (num + 3) / 4; ++k) { const float4 v = c4[k]; sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
+    return sum;
+}
+
+// |dist_latent - dist_rolled| of a correspondence pair; false when the pair is out of the look-up table's range (H = 0).
+// LOOKUP: matcher.cpp:1246-1264 (block coordinates, table_dist).  else: :1372-1385 (pixels, sqrtf).
+template <bool LOOKUP>
+__device__ __forceinline__ bool pair_dist(const Pt& a, const Pt& o, const float* __restrict__ table, float& dist)
+{
+    float d1, d2; bool ok = true;
+    if (LOOKUP) {
+        const int dx1 = abs(a.lx - o.lx), dx2 = abs(a.rx - o.rx), dy1 = abs(a.ly - o.ly), dy2 = abs(a.ry - o.ry);
+        ok = !((dx1 >= kDistN) | (dx2 >= kDistN) | (dy1 >= kDistN) | (dy2 >= kDistN));              // :1257
+        // table_dist[dx*50+dy] = (float)sqrt((16 dx)^2 + (16 dy)^2) (matcher.cpp:45-56).  The argument is an exact integer
+        // < 2^24, and a double sqrt rounded to float equals the correctly rounded float sqrt, so the table entry is
+        // recomputed bit-exactly instead of being fetched (tests/test_host.py checks all 2500 entries).
+        d1 = __fsqrt_rn((float)(256 * (dx1 * dx1 + dy1 * dy1)));
+        d2 = __fsqrt_rn((float)(256 * (dx2 * dx2 + dy2 * dy2)));
+        (void)table;
+    } else {
+        const float dx1 = (float)(a.lx - o.lx), dx2 = (float)(a.rx - o.rx), dy1 = (float)(a.ly - o.ly), dy2 = (float)(a.ry - o.ry);
+        const float p = dx1 * dx1, q = dy1 * dy1, r = dx2 * dx2, s = dy2 * dy2;
+        d1 = __fsqrt_rn(p + q);                                                                      // correctly rounded, as sqrtf
+        d2 = __fsqrt_rn(r + s);
+    }
+    dist = fabsf(d1 - d2);
+    return ok;
+}
+// H = clamp((30 - dist)/(25.0), 0, 1) for dist <= 30 (matcher.cpp:1268-1272 / :1389-1393): float numerator, double divide,
+// float store.  (float)((double)x/25.0) == x/25.0f (double rounding through 53 bits is innocuous for a quotient of two
+// 24-bit values), and for every float x in [0, 30] the fma sequence below equals x/25.0f — checked exhaustively over all
+// 1,106,247,681 such floats by tools/verify_div25.c.
+__device__ __forceinline__ float h_value(float dist)
+{
+    const float x = 30.0f - dist;
+    const float q0 = x * 0.04f;
+    const float r = fmaf(-q0, 25.0f, x);
+    float h = fmaf(r, 0.04f, q0);
+    if (h > 1.0f) h = 1.0f; else if (h < 0.0f) h = 0.0f;
+    return h;
+}
+
+// S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
+template <class SM, bool LOOKUP, int ITERS>
+__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
+{
+    constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX, CACHE = SM::CACHE;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
+    Pt me[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int t = lane + 64 * u;
+        if (t < SM::N4) { sm.b[t] = t < num ? sm.sim[t] : 0.0f; sm.cc[t] = 0.0f; }
+        me[u] = unpack_xy(t < num ? sm.xy[t] : make_int2(0, 0));
+    }
+    WSYNC();
+    // non-zero pattern of the compatibility matrix (matcher.cpp:1237-1275 / :1363-1397): row t visits the pairs
+    // (t, t+d mod num), d = 1..num/2, so every unordered pair is evaluated once.  H != 0  <=>  in range and dist < 30.
+    const int half = num >> 1;
+    const bool even = !(num & 1);
+    for (int d = 1; d <= half; ++d) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = lane + 64 * u;
+            if (t < num && !(d == half && even && t >= half)) {       // even num: the antipodal pairs belong to the lower half
+                int k = t + d; if (k >= num) k -= num;
+                float dist;
+                const bool ok = pair_dist<LOOKUP>(me[u], unpack_xy(sm.xy[k]), table, dist);
+                if (ok && dist < 30.0f) {
+                    atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
+                    atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
+                }
+            }
+        }
+    }
+    WSYNC();
+    // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle)
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = lane + 64 * u;
+            if (t < num) {
+                float acc = 0.0f;
+                int n = 0;
+                for (int w = 0; w < (num + 31) / 32; ++w) {
+                    uint32_t bits = sm.hb[t][w];
+                    while (bits) {
+                        const int k = w * 32 + __ffs(bits) - 1;
+                        bits &= bits - 1;
+                        float h;
+                        if (it == 0 || n >= CACHE) {
+                            float dist;
+                            pair_dist<LOOKUP>(me[u], unpack_xy(sm.xy[k]), table, dist);
+                            h = h_value(dist);
+                            if (n < CACHE) sm.x.stash[n * NMAX + t] = h;
+                        } else h = sm.x.stash[n * NMAX + t];
+                        const float p = h * sm.b[k];
+                        acc += p;
+                        ++n;
+                    }
+                }
+                sm.cc[t] = acc;
+            }
+        }
+        WSYNC();
+        const float sum = seq_sum(sm, num);
+        const float scale = (float)(1.0 / ((double)sum + 0.00001));
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; if (t < num) sm.b[t] = sm.cc[t] * scale; }
+        WSYNC();
+    }
+    sort_scores(sm, num);
+    const int nsel = greedy(sm, num, 0.0001, [&sm, table](int a, int o) {
+        if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
+        float dist;
+        pair_dist<LOOKUP>(unpack_xy(sm.xy[a]), unpack_xy(sm.xy[o]), table, dist);
+        return !((double)h_value(dist) < 0.00001);
+    });
+    compact(sm, nsel);
+    return nsel;
+}
+
+__device__ __forceinline__ float adjust_angle(float angle)            // matcher.cpp:1638-1647
+{
+    if ((double)angle > AFIS_PI) angle = (float)((double)angle - 2 * AFIS_PI);
+    else if ((double)angle < -AFIS_PI) angle = (float)((double)angle + 2 * AFIS_PI);
+    return angle;
+}
+__device__ __forceinline__ float fold_pi(float d)                      // "if(angle_diff>PI) angle_diff = 2*PI - angle_diff"
+{
+    if ((double)d > AFIS_PI) d = (float)(2 * AFIS_PI - (double)d);
+    return d;
+}
+// atan2f of the reference (glibc) replaced by a double-precision atan2 rounded to float: equal to a correctly
+// rounded atan2f except for results within 1e-16 relative of a rounding boundary.  The value only feeds threshold tests.
+__device__ __forceinline__ float atan2_f32(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+// the three angle tests of matcher.cpp:1495-1549 for the ordered pair (1 = lower index, 2 = higher index)
+__device__ __forceinline__ bool angle_compatible(const Pt& p1, float lo1, float ro1, const Pt& p2, float lo2, float ro2)
+{
+    float angle_1 = adjust_angle(lo1 - lo2);
+    float angle_2 = adjust_angle(ro1 - ro2);
+    float angle_diff = fold_pi(fabsf(angle_1 - angle_2));
+    if ((double)angle_diff > AFIS_PI / 4.) return false;
+    const float dx_1 = (float)(p1.lx - p2.lx), dy_1 = (float)(p1.ly - p2.ly);
+    const float line_angle_1 = -atan2_f32(dy_1, dx_1);
+    angle_1 = adjust_angle(lo1 - line_angle_1);
+    const float dx_2 = (float)(p1.rx - p2.rx), dy_2 = (float)(p1.ry - p2.ry);
+    const float line_angle_2 = -atan2_f32(dy_2, dx_2);
+    angle_2 = adjust_angle(ro1 - line_angle_2);
+    angle_diff = fold_pi(fabsf(angle_1 - angle_2));
+    if ((double)angle_diff > AFIS_PI / 6.) return false;
+    angle_1 = adjust_angle(lo2 - line_angle_1);
+    angle_2 = adjust_angle(ro2 - line_angle_2);
+    angle_diff = fold_pi(fabsf(angle_1 - angle_2));
+    if ((double)angle_diff > AFIS_PI / 6.) return false;
+    return true;
+}
+
+// S9, matcher.cpp:1471-1636.  Returns the number of survivors (compacted in place).
+template <class SM>
+__device__ int angle_filter(SM& sm, int num)
+{
+    constexpr int W = SM::W;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
+    const float s0 = (float)(1.0 / num);                                   // :1558
+    for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.cc[t] = 0.0f; }
+    WSYNC();
+    // row t visits the pairs (t, t+d mod num), d = 1..num/2: every unordered pair once, evaluated as (lower, higher) index
+    const int half = num >> 1;
+    const bool even = !(num & 1);
+    for (int d = 1; d <= half; ++d) {
+        for (int t = lane; t < num; t += 64) {
+            if (d == half && even && t >= half) continue;
+            int k = t + d; if (k >= num) k -= num;
+            const int i = t < k ? t : k, j = t < k ? k : t;
+            if (angle_compatible(unpack_xy(sm.xy[i]), sm.lo[i], sm.ro[i], unpack_xy(sm.xy[j]), sm.lo[j], sm.ro[j])) {
+                atomicOr(&sm.hb[i][j >> 5], 1u << (j & 31));
+                atomicOr(&sm.hb[j][i >> 5], 1u << (i & 31));
+            }
+        }
+    }
+    WSYNC();
+    for (int it = 0; it < 5; ++it) {                                       // :1563-1581
+        for (int t = lane; t < num; t += 64) {
+            float s1 = 0.0f;
+            for (int w = 0; w < (num + 31) / 32; ++w) {
+                uint32_t bits = sm.hb[t][w];
+                while (bits) { const int k = w * 32 + __ffs(bits) - 1; bits &= bits - 1; s1 += sm.b[k]; }
+            }
+            sm.cc[t] = s1;
+        }
+        WSYNC();
+        float sum = seq_sum(sm, num);
+        sum = (float)(1.0 / ((double)sum + 0.00001));
+        for (int t = lane; t < num; t += 64) sm.b[t] = sm.cc[t] * sum;
+        WSYNC();
+    }
+    sort_scores(sm, num);
+    const int nsel = greedy(sm, num, 0.001, [&sm](int a, int o) { return (sm.hb[a][o >> 5] >> (o & 31)) & 1u; });
+    compact(sm, nsel);
+    return nsel;
+}
+
+// both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
+template <class SM, bool LOOKUP, int ITERS>
+__device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table)
+{
+    num = dist_filter<SM, LOOKUP, ITERS>(sm, num, table);
+    if (num < 2) return 0.0f;
+    num = angle_filter(sm, num);
+    float score = 0.0f;                                                    // :508-514 / :775-781
+    for (int i = 0; i < num; ++i) score += sm.sim[i];
+    return score;
+}
+
+// =====================================================================================================================
+// texture lists: S7 (top-200 rows of the ADC row maxima) + S8b + S9
+// =====================================================================================================================
+typedef WaveSmem<kTopTex, 8> TexSmem;
+constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
+
+__global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
+                                                      const float* __restrict__ rm_val, const int32_t* __restrict__ rm_arg,
+                                                      float* __restrict__ parts)
+{
+    __shared__ TexSmem sm;
+    const int lane = threadIdx.x;
+    const long long n_tasks = (long long)q.nq * g.G;
+    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int qi = (int)(task / g.G), gi = (int)(task - (long long)qi * g.G);
+        const int l0 = q.lt_off[qi], n_lt = q.lt_off[qi + 1] - l0;
+        const int r0 = g.tex_off[gi], n_rt = g.tex_off[gi + 1] - r0;
+        float* out = parts + (size_t)task * 4 + 3;
+        if (n_lt <= 0 || n_rt <= 0) { if (lane == 0) *out = 0.0f; continue; }   // matcher.cpp:411: scorer not called
+        const size_t o = (size_t)task * q.lt_pad;
+        int num;
+        if (n_lt > kTopTex) {                                            // :736-747: the 200 rows with the largest maxima
+            float v[kTexRegs]; uint32_t key[kTexRegs];
+#pragma unroll
+            for (int u = 0; u < kTexRegs; ++u) {
+                const int e = u * 64 + lane;
+                v[u] = e < n_lt ? rm_val[o + e] : 0.0f;
+                key[u] = e < n_lt ? g_ord_f32(v[u]) : 0u;                // real keys are never 0
+            }
+            uint32_t T = 0;                                              // 200th largest key, built bit by bit
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = T | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int u = 0; u < kTexRegs; ++u) c += g_wave_popc(key[u] >= cand);
+                if (c >= kTopTex) T = cand;
+            }
+            int n_gt = 0;
+#pragma unroll
+            for (int u = 0; u < kTexRegs; ++u) n_gt += g_wave_popc(key[u] > T);
+            const int need = kTopTex - n_gt;                             // of the keys equal to T keep the lowest indices
+            int base_gt = 0, base_eq = 0;
+#pragma unroll
+            for (int u = 0; u < kTexRegs; ++u) {                         // u ascending, lane ascending = index ascending
+                const int e = u * 64 + lane;
+                const bool gt = key[u] > T, eq = key[u] == T;
+                const u64 mg = __ballot(gt), me = __ballot(eq);
+                int pos = -1;
+                if (gt) pos = base_gt + g_lane_prefix(mg);
+                else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
+                if (pos >= 0) {
+                    sm.keys[pos] = g_make_key(v[u], e);
+                    sm.x.pick.tval[pos] = v[u]; sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)rm_arg[o + e];
+                }
+                base_gt += __popcll(mg); base_eq += __popcll(me);
+            }
+            WSYNC();
+            num = kTopTex;
+            u64 mine[TexSmem::U]; int r[TexSmem::U];
+#pragma unroll
+            for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? sm.keys[t] : 0ull; }
+            rank_keys<TexSmem::U>(sm.keys, num, mine, r);
+#pragma unroll
+            for (int u = 0; u < TexSmem::U; ++u) {
+                const int t = lane + 64 * u;
+                if (t < num) { sm.sim[r[u]] = sm.x.pick.tval[t]; sm.li[r[u]] = sm.x.pick.te[t]; sm.ri[r[u]] = sm.x.pick.targ[t]; }
+            }
+        } else {                                                         // :748-749 rows stay in index order
+            num = n_lt;
+            for (int t = lane; t < num; t += 64) { sm.sim[t] = rm_val[o + t]; sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
+        }
+        WSYNC();
+        for (int t = lane; t < num; t += 64) {
+            const int a = sm.li[t], b = sm.ri[t];
+            const short2 lp = q.lt_xy[l0 + a], rp = g.tex_xy[r0 + b];
+            sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
+            sm.lo[t] = q.lt_ori[l0 + a]; sm.ro[t] = g.tex_ori[r0 + b];
+        }
+        WSYNC();
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist);   // :759, :767
+        if (lane == 0) *out = score;
+        WSYNC();
+    }
+}
+
+hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
+                                const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream)
+{
+    const long long n_tasks = (long long)q.nq * g.G;
+    if (n_tasks <= 0) return hipSuccess;
+    const int grid = (int)(n_tasks < 16384 ? n_tasks : 16384);
+    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, parts);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// minutiae lists (produced by k_minu_cands, already in rank order): S8a + S9
+// =====================================================================================================================
+typedef WaveSmem<kTopMinu, 12> MinuGraphSmem;
+
+__global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
+                                                       const int32_t* __restrict__ cand_n, float* __restrict__ parts)
+{
+    __shared__ MinuGraphSmem sm;
+    const int lane = threadIdx.x;
+    const long long n_tasks = (long long)q.nq * 3 * g.G;
+    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        // task order as in k_minu_cands: gallery template fastest, then selected template, then query
+        const int gi = (int)(task % g.G);
+        const int qs = (int)(task / g.G);
+        const int qi = qs / 3, s = qs - qi * 3;
+        float* out = parts + ((size_t)qi * g.G + gi) * 4 + s;
+        const int num = cand_n[task];
+        if (num <= 0) { if (lane == 0) *out = 0.0f; continue; }             // matcher.cpp:400-404
+        const int l0 = q.lm_off[qs], r0 = g.minu_off[gi];
+        const MinuCand* c = cands + (size_t)task * kTopMinu;
+        for (int t = lane; t < num; t += 64) {
+            const MinuCand cd = c[t];
+            sm.sim[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
+            const short2 lp = q.lm_xy[l0 + cd.li], rp = g.minu_xy[r0 + cd.ri];
+            sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
+            sm.lo[t] = q.lm_ori[l0 + cd.li]; sm.ro[t] = g.minu_ori[r0 + cd.ri];
+        }
+        WSYNC();
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr);   // :492, :495
+        if (lane == 0) *out = score;
+        WSYNC();
+    }
+}
+
+hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
+                                 float* parts, hipStream_t stream)
+{
+    const long long n_tasks = (long long)q.nq * 3 * g.G;
+    if (n_tasks <= 0) return hipSuccess;
+    const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
+    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts);
+    return hipGetLastError();
+}
+
+}  // namespace afis

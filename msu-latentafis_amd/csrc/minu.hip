@@ -1,0 +1,301 @@
+// minu.hip — candidate generation of the minutiae-template scorer and the final score fusion:
+//   S1  descriptor similarity  simi = max(0, A * B^T)              (matching/matcher.cpp:440-452)
+//   S2  normalisation          norm = s / (rowsum + colsum - s + 1e-6) (matcher.cpp:455-470)
+//   S3  the 120 correspondences with the largest norm, in rank order (matcher.cpp:473-488)
+//   S10 fusion                 final = score[0] + score[1] + score[2] + score[28]*0.3   (matcher.cpp:376-417, :188)
+// The correspondence lists go to HBM (120 x 8 B per task) and are consumed by k_graph_minutiae (graph.hip).
+//
+// One 256-thread workgroup per (query, selected latent template, gallery template) task, persistent over a strided task list.
+// Canonical arithmetic (see oracle/afis_oracle.cpp): descriptor dot products are k-ascending fmaf chains, row/column sums are
+// index-ascending, the normalisation is evaluated in double exactly as the reference's expression promotes it.
+#include "afis_device.h"
+
+namespace afis {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+typedef unsigned long long u64;
+
+#ifdef AFIS_PHASE_TIMING
+__device__ u64 g_phase_cycles[32];
+#define PHASE_INIT() u64 ph_t0 = __builtin_readcyclecounter()
+#define PHASE(i) do { if (threadIdx.x == 0) { const u64 ph_t1 = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], ph_t1 - ph_t0); ph_t0 = ph_t1; } } while (0)
+#else
+#define PHASE_INIT() do {} while (0)
+#define PHASE(i) do {} while (0)
+#endif
+
+__device__ __forceinline__ uint32_t ord_f32(float v)
+{
+    v = v + 0.0f;                                   // -0 -> +0 so that equal floats get equal keys
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Workgroup-wide sum of wave-uniform partial counts (each wave passes its own total).  One barrier per call.
+__device__ __forceinline__ int wg_sum(int wave_total, int* s_slots /*[2][kWaves]*/, int& parity)
+{
+    if ((threadIdx.x & 63) == 0) s_slots[parity * kWaves + (threadIdx.x >> 6)] = wave_total;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) tot += s_slots[parity * kWaves + w];
+    parity ^= 1;
+    return tot;
+}
+__device__ __forceinline__ int wave_popc(bool p) { return __popcll(__ballot(p)); }
+
+constexpr int kGemmRows = 64;       // latent rows per GEMM tile
+constexpr int kGemmCols = 32;       // rolled columns per GEMM tile
+constexpr int kGemmLd = 100;        // padded row stride (floats): 16-byte aligned rows, conflict-free b128 column walks
+constexpr int kKeyRegs = 16;        // per-thread keys held in registers when nL*nR <= 256*16
+constexpr int kFastL = 64, kFastR = 128;          // pair shapes whose whole similarity matrix stays in LDS
+constexpr int kFastN = kFastL * kFastR;
+
+struct MinuSmem {
+    float A[kGemmRows * kGemmLd];   // 25.6 KB
+    float B[kGemmCols * kGemmLd];   // 12.8 KB
+    float simi[kFastN];             // 32 KB
+    float rowsum[kFastL];
+    float colsum[kFastR];
+    u64 keys[128];
+    int te[kTopMinu];
+    int slots[2 * kWaves];
+    int counter;
+};
+
+// Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
+__global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
+                                                         MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
+    float* gscr = scratch + (size_t)blockIdx.x * scratch_per_wg;
+    int parity = 0;
+    const long long n_tasks = (long long)q.nq * 3 * g.G;
+    const int tid = threadIdx.x;
+    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        // task order: gallery template fastest, then selected template, then query
+        const int gi = (int)(task % g.G);
+        const int qs = (int)(task / g.G);                    // qi*3 + s
+        const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
+        const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
+        if (nL <= 0 || nR <= 0) { if (tid == 0) cand_n[task] = 0; continue; }     // matcher.cpp:400-404
+        const int n = nL * nR;
+        PHASE_INIT();
+        const bool fast = nL <= kFastL && nR <= kFastR;
+        const size_t half = (scratch_per_wg - 4096) >> 1;
+        float* simi = fast ? sm.simi : gscr;
+        uint32_t* gkeys = reinterpret_cast<uint32_t*>(gscr + half);
+        float* rowsum = fast ? sm.rowsum : gscr + 2 * half;
+        float* colsum = fast ? sm.colsum : gscr + 2 * half + 2048;
+
+        // ---- S1: simi = max(0, A * B^T), canonical order = fmaf chain, k ascending (matcher.cpp:440-452) ----
+        for (int it = 0; it < nL; it += kGemmRows) {
+            __syncthreads();
+            for (int e = tid; e < kGemmRows * (kDes / 4); e += kThreads) {
+                const int r = e / (kDes / 4), k4 = e - r * (kDes / 4);
+                float4 a = make_float4(0, 0, 0, 0);
+                if (it + r < nL) a = *reinterpret_cast<const float4*>(q.lm_des + (size_t)(l0 + it + r) * kDes + k4 * 4);
+                *reinterpret_cast<float4*>(&sm.A[r * kGemmLd + k4 * 4]) = a;
+            }
+            for (int jt = 0; jt < nR; jt += kGemmCols) {
+                if (jt) __syncthreads();
+                for (int e = tid; e < kGemmCols * (kDes / 4); e += kThreads) {
+                    const int r = e / (kDes / 4), k4 = e - r * (kDes / 4);
+                    float4 b = make_float4(0, 0, 0, 0);
+                    if (jt + r < nR) b = *reinterpret_cast<const float4*>(g.minu_des + (size_t)(r0 + jt + r) * kDes + k4 * 4);
+                    *reinterpret_cast<float4*>(&sm.B[r * kGemmLd + k4 * 4]) = b;
+                }
+                __syncthreads();
+                const int ty = tid >> 3, tx = tid & 7;               // rows ty + 32*r (r < 2), cols tx + 8*c (c < 4)
+                float acc[2][4];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+#pragma unroll 4
+                for (int k4 = 0; k4 < kDes / 4; ++k4) {
+                    float4 a[2], b[4];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) a[r] = *reinterpret_cast<const float4*>(&sm.A[(ty + 32 * r) * kGemmLd + k4 * 4]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) b[c] = *reinterpret_cast<const float4*>(&sm.B[(tx + 8 * c) * kGemmLd + k4 * 4]);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float v = acc[r][c];
+                            v = fmaf(a[r].x, b[c].x, v); v = fmaf(a[r].y, b[c].y, v);
+                            v = fmaf(a[r].z, b[c].z, v); v = fmaf(a[r].w, b[c].w, v);
+                            acc[r][c] = v;
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int i = it + ty + 32 * r, j = jt + tx + 8 * c;
+                        if (i < nL && j < nR) { float v = acc[r][c]; if (v < 0) v = 0; simi[(size_t)i * nR + j] = v; }
+                    }
+            }
+        }
+        __syncthreads();
+        PHASE(0);
+        // ---- S2: column sums (rolled) / row sums (latent), index ascending (:455-456) ----
+        for (int j = tid; j < nR; j += kThreads) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < nL; ++i) sacc += simi[(size_t)i * nR + j];
+            colsum[j] = sacc;
+        }
+        for (int i = tid; i < nL; i += kThreads) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < nR; ++j) sacc += simi[(size_t)i * nR + j];
+            rowsum[i] = sacc;
+        }
+        __syncthreads();
+        PHASE(1);
+        // ---- S3: top-120 by normalised similarity (:461-488) ----
+        const int topN = n < kTopMinu ? n : kTopMinu;
+        auto norm_key = [&](int e) {
+            const int i = e / nR, j = e - i * nR;
+            const float sv = simi[e];
+            float f = rowsum[i] + colsum[j];
+            f = f - sv;
+            return ord_f32((float)((double)sv / ((double)f + 0.000001)));                        // :467
+        };
+        // K-th largest key T, built bit by bit from wave-level ballot counts; then the keys above T plus the lowest-index
+        // keys equal to T.  `keyv(u)` is this thread's u-th key (element e = tid + u*256), 0 beyond n (real keys are >= 2^31).
+        uint32_t rk[kKeyRegs];
+        const bool in_regs = n <= kThreads * kKeyRegs;
+        const int n_u = in_regs ? kKeyRegs : (n + kThreads - 1) / kThreads;
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < kKeyRegs; ++u) { const int e = tid + u * kThreads; rk[u] = e < n ? norm_key(e) : 0u; }
+        } else {
+            for (int e = tid; e < n; e += kThreads) gkeys[e] = norm_key(e);
+            __syncthreads();
+        }
+        PHASE(2);
+        auto count_if = [&](auto pred) {                    // pred(key, e) -> bool; returns the workgroup-wide count
+            int c = 0;
+            if (in_regs) {
+#pragma unroll
+                for (int u = 0; u < kKeyRegs; ++u) c += wave_popc(pred(rk[u], (uint32_t)(tid + u * kThreads)));
+            } else {
+                for (int u = 0; u < n_u; ++u) { const int e = tid + u * kThreads; c += wave_popc(e < n && pred(gkeys[e < n ? e : 0], (uint32_t)e)); }
+            }
+            return wg_sum(c, sm.slots, parity);
+        };
+        uint32_t T = 0x80000000u;                           // every real key has the top bit set (norm >= 0)
+        for (int bit = 30; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            if (count_if([cand](uint32_t k, uint32_t) { return k >= cand; }) >= topN) T = cand;
+        }
+        const int n_gt = count_if([T](uint32_t k, uint32_t) { return k > T; });
+        const int n_eq = count_if([T](uint32_t k, uint32_t) { return k == T; });
+        const int need = topN - n_gt;                       // >= 1
+        uint32_t Bnd = 0xffffffffu;                         // keep the keys equal to T whose index is <= Bnd
+        if (n_eq != need) {
+            Bnd = 0;
+            for (int bit = 30; bit >= 0; --bit) {           // Bnd = largest bound with count(key == T && e < Bnd) < need
+                const uint32_t cand = Bnd | (1u << bit);
+                if (count_if([T, cand](uint32_t k, uint32_t e) { return k == T && e < cand; }) < need) Bnd = cand;
+            }
+        }
+        if (tid == 0) sm.counter = 0;
+        __syncthreads();
+        auto emit = [&](uint32_t k, int e) {
+            if (e < n && (k > T || (k == T && (uint32_t)e <= Bnd))) {
+                const int pos = atomicAdd(&sm.counter, 1);
+                sm.keys[pos] = ((u64)k << 32) | (uint32_t)(~(uint32_t)e);
+                sm.te[pos] = e;
+            }
+        };
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < kKeyRegs; ++u) emit(rk[u], tid + u * kThreads);
+        } else {
+            for (int e = tid; e < n; e += kThreads) emit(gkeys[e], e);
+        }
+        __syncthreads();
+        PHASE(3);
+        if (tid < topN) {                                   // rank by counting: the list leaves in rank order
+            const u64 mine = sm.keys[tid];
+            int r = 0;
+#pragma unroll 8
+            for (int k = 0; k < topN; ++k) r += sm.keys[k] > mine;
+            const int e = sm.te[tid];
+            const int i1 = e / nR, i2 = e - i1 * nR;
+            MinuCand c; c.sim = simi[e]; c.li = (short)i1; c.ri = (short)i2;
+            cands[(size_t)task * kTopMinu + r] = c;
+        }
+        if (tid == 0) cand_n[task] = topN;
+        __syncthreads();
+        PHASE(4);
+    }
+}
+
+hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
+                             MinuCand* cands, int32_t* cand_n, hipStream_t stream)
+{
+    const long long n_tasks = (long long)q.nq * 3 * g.G;
+    if (n_tasks <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MinuSmem));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
+    hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// S10 fusion: final = score[0] + score[1] + score[2] + score[28]*0.3 (matcher.cpp:188), where the reference's score
+// vector holds the three minutiae scores at [0..2] and the texture score at index (#latent minutiae templates).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void k_fuse(QueryDev q, GalleryDev g, const float* __restrict__ parts, float* __restrict__ scores)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)q.nq * g.G;
+    if (idx >= n) return;
+    const int qi = (int)(idx / g.G), gi = (int)(idx - (long long)qi * g.G);
+    if (q.status[qi] != 0 || g.empty[gi]) { scores[idx] = -1.0f; return; }     // :145, :181-187
+    const float* p = parts + (size_t)idx * 4;
+    const int slot = q.tex_slot[qi];
+    const float tex = p[3];
+    const float a0 = slot == 0 ? tex : p[0];
+    const float a1 = slot == 1 ? tex : p[1];
+    const float a2 = slot == 2 ? tex : p[2];
+    const float a28 = slot == 28 ? tex : 0.0f;
+    float f = a0 + a1;
+    f = f + a2;
+    scores[idx] = (float)((double)f + (double)a28 * 0.3);
+}
+
+hipError_t read_phase_cycles(unsigned long long* out32, bool reset)
+{
+#ifdef AFIS_PHASE_TIMING
+    hipError_t e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_phase_cycles), 32 * sizeof(u64));
+    if (e != hipSuccess) return e;
+    if (reset) { u64 z[32] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)); }
+    return e;
+#else
+    for (int i = 0; i < 32; ++i) out32[i] = 0;
+    return hipSuccess;
+#endif
+}
+
+hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream)
+{
+    const long long n = (long long)q.nq * g.G;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fuse, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q, g, parts, scores);
+    return hipGetLastError();
+}
+
+}  // namespace afis

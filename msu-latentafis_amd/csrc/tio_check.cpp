@@ -1,0 +1,53 @@
+// tio_check — host-only self-test hook for template_io (no GPU, no HIP): parses a latent/rolled .dat or a codebook and prints a
+// canonical summary (return code, template counts, per-template sizes and FNV-1a hashes of the payloads); `roundtrip` re-writes the
+// parsed template and reports whether the bytes are identical.  Used by tests/test_host.py to cross-check the C++ parser/writer
+// against the Python mirror and the oracle's parser.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "template_io.h"
+
+using namespace afis;
+
+static unsigned long long fnv(const void* p, size_t n, unsigned long long h = 1469598103934665603ull)
+{
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: tio_check latent|rolled|codebook|roundtrip-latent|roundtrip-rolled <file>\n"); return 2; }
+    const std::string mode = argv[1];
+    std::vector<uint8_t> b;
+    if (!read_file(argv[2], b)) { printf("rc=io\n"); return 1; }
+    if (mode == "codebook") {
+        HostCodebook cb;
+        const bool ok = parse_codebook(b.data(), b.size(), cb);
+        printf("ok=%d M=%d K=%d dsub=%d hash=%016llx\n", ok ? 1 : 0, cb.M, cb.K, cb.dsub, fnv(cb.words.data(), cb.words.size() * 4));
+        return 0;
+    }
+    const bool rolled = mode.find("rolled") != std::string::npos;
+    HostTemplate t;
+    const int rc = rolled ? parse_rolled_dat(b.data(), b.size(), t) : parse_latent_dat(b.data(), b.size(), t);
+    if (mode.rfind("roundtrip", 0) == 0) {
+        const std::vector<uint8_t> w = rolled ? write_rolled_dat(t) : write_latent_dat(t);
+        printf("rc=%d identical=%d in=%zu out=%zu\n", rc, (w == b) ? 1 : 0, b.size(), w.size());
+        return 0;
+    }
+    printf("rc=%d n_minu=%zu n_tex=%zu h=%d w=%d blkH=%d blkW=%d\n", rc, t.minu.size(), t.tex.size(), t.h, t.w, t.blkH, t.blkW);
+    for (const HostMinutiae& m : t.minu) {
+        unsigned long long h = fnv(m.x.data(), m.x.size() * 2); h = fnv(m.y.data(), m.y.size() * 2, h); h = fnv(m.ori.data(), m.ori.size() * 4, h);
+        h = fnv(m.des.data(), m.des.size() * 4, h);
+        printf("minu n=%d des_len=%d hash=%016llx\n", m.n(), m.des_len, h);
+    }
+    for (const HostTexture& x : t.tex) {
+        unsigned long long h = fnv(x.x.data(), x.x.size() * 2); h = fnv(x.y.data(), x.y.size() * 2, h); h = fnv(x.ori.data(), x.ori.size() * 4, h);
+        h = fnv(x.des.data(), x.des.size() * 4, h); h = fnv(x.codes.data(), x.codes.size(), h);
+        printf("tex n=%d des_len=%d hash=%016llx\n", x.n(), x.des_len, h);
+    }
+    return 0;
+}

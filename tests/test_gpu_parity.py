@@ -137,3 +137,126 @@ def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     q27 = names.index("minu27_tex")
     p = res["parts"][q27, 0]
     assert np.isclose(res["scores"][q27, 0], (p[0] + p[1]) + p[2], rtol=1e-6)      # score[28] out of range -> 0
+
+
+# ---- committed golden vectors --------------------------------------------------------------------------------------------
+def test_golden_vectors(codebook_bytes):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_pairs.npz"))
+    m = M.Matcher(codebook_bytes)
+    for j in range(12):
+        assert m.gallery_add_dat(gold[f"rolled_{j}"].tobytes()) == 0
+    m.gallery_commit(0)
+    res = m.search_dat([gold[f"latent_{i}"].tobytes() for i in range(2)], k=3, want_parts=True)
+    got = np.concatenate([res["parts"], res["scores"][..., None]], axis=-1)
+    want = gold["parts"][1]                                   # tie_mode 1: equal keys by ascending index
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(want))
+    assert err.max() <= 1e-3, (np.argwhere(err > 1e-3), got[err > 1e-3], want[err > 1e-3])
+    assert list(res["topk_idx"][0]) == [0, 1, 2] and list(res["topk_idx"][1]) == [3, 4, 5]
+
+
+# ---- size-independent properties at a larger scale --------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def medium(cb):
+    G, Q = 3000, 6
+    lats = S.make_latents(77, Q)
+    gal = S.make_packed_gallery(77, G, cb)
+    planted = S.plant_mates(77, gal, cb, lats)
+    return lats, gal, planted
+
+
+def test_medium_properties_and_sharding(codebook_bytes, cb, oracle, medium):
+    lats, gal, planted = medium
+    G = gal.G
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add_packed(gal); m.gallery_commit(0)
+    r1 = m.search(lats, k=24, want_parts=True)
+    # (1) idempotence + resident == one-shot
+    qh = m.upload_queries(lats)
+    r2 = m.search_resident(qh, k=24, want_scores=True, want_parts=True)
+    m.free_queries(qh)
+    assert np.array_equal(r1["scores"], r2["scores"]) and np.array_equal(r1["topk_idx"], r2["topk_idx"])
+    # (2) the planted mates lead every rank list in planting order (overlap 0.8 > 0.5 > 0.35 > 0.25)
+    for q in range(len(lats)):
+        want = [g for g, _ in planted[q]]
+        assert list(r1["topk_idx"][q][:len(want)]) == want, (q, r1["topk_idx"][q][:6], want)
+        assert r1["topk_score"][q][0] > 50
+    # (3) the rank list is the top-k of the score vector, score descending then index ascending
+    for q in range(len(lats)):
+        order = np.lexsort((np.arange(G), -r1["scores"][q].astype(np.float64)))[:24]
+        assert np.array_equal(r1["topk_idx"][q], order) and np.array_equal(r1["topk_score"][q], r1["scores"][q][order])
+    # (4) fusion identity on every pair: final = (s0+s1)+s2 + 0.3*tex  (28 latent minutiae templates)
+    p = r1["parts"]
+    fused = ((p[..., 0] + p[..., 1]) + p[..., 2]).astype(np.float64) + p[..., 3].astype(np.float64) * 0.3
+    assert np.array_equal(fused.astype(np.float32), r1["scores"])
+    assert (r1["scores"] >= 0).all()
+    # (5) both ADC variants give identical bits
+    m.set_option("adc_variant", 0)
+    r0 = m.search(lats, k=0)
+    assert np.array_equal(r0["scores"], r1["scores"])
+    # (6) gallery sharding: two contiguous shards with global indices, merged rank lists == single-shard rank lists
+    SH = importlib.import_module("msu-latentafis_amd.host.sharding")
+    nm, nt = S.gallery_counts(77, G)
+    bounds = SH.shard_bounds(nt, 2)
+    idx, sc = [], []
+    for lo, hi in bounds:
+        ms = M.Matcher(codebook_bytes)
+        ms.gallery_add_packed(gal.slice(lo, hi)); ms.gallery_commit(lo)
+        rs = ms.search(lats, k=24)
+        assert np.array_equal(rs["scores"], r1["scores"][:, lo:hi])
+        idx.append(rs["topk_idx"]); sc.append(rs["topk_score"])
+        ms.close()
+    mi, msc = SH.merge_topk(np.stack(idx), np.stack(sc), 24)
+    assert np.array_equal(mi, r1["topk_idx"]) and np.array_equal(msc, r1["topk_score"])
+    # (7) a sample of pairs against the oracle (mates + random non-mates)
+    ocb = oracle.codebook(codebook_bytes)
+    rng = np.random.default_rng(0)
+    bad = 0; n = 0
+    for q in range(2):
+        hl, _ = oracle.latent(ocb, T.write_latent(lats[q]))
+        sample = [g for g, _ in planted[q]] + list(rng.integers(0, G, 40))
+        for g in sample:
+            hr, _ = oracle.rolled(T.write_rolled(gal.template(int(g))))
+            rc, want = oracle.pair(ocb, hl, hr, 1)
+            got = np.append(r1["parts"][q, g], r1["scores"][q, g])
+            n += 1
+            bad += int((np.abs(got - want) > 1e-3 * np.maximum(1, np.abs(want))).any())
+    assert bad <= max(1, n // 100), (bad, n)
+
+
+def test_cli_matches_oracle(codebook_bytes, cb, oracle, small, tmp_path):
+    """The drop-in CLI: -l and -ldir output files against the oracle's scores (SURVEY §3.1 / §3.2 formats)."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    lats, gal = small
+    (tmp_path / "work").mkdir(); (tmp_path / "gal").mkdir(); (tmp_path / "lat").mkdir(); (tmp_path / "out").mkdir()
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    for j, g in enumerate(gal[:12]):
+        (tmp_path / "gal" / f"R{j:03d}.dat").write_bytes(T.write_rolled(g))
+    (tmp_path / "gal" / "R_empty.dat").write_bytes(b"")          # empty file -> score -1
+    for i, L in enumerate(lats[:2]):
+        (tmp_path / "lat" / f"L{i}.dat").write_bytes(T.write_latent(L))
+    ocb = oracle.codebook(codebook_bytes)
+    out = subprocess.run([exe, "-ldir", str(tmp_path / "lat"), "-g", str(tmp_path / "gal"), "-s", str(tmp_path / "out") + "/", "-c", str(cbp)],
+                         capture_output=True, text=True, cwd=tmp_path / "work")
+    assert out.returncode == 0, out.stderr
+    assert "Gallery size: 13" in out.stdout and "Latent minutiae templates: 28" in out.stdout and "Total matching duration (ms):" in out.stdout
+    for i in range(2):
+        hl, _ = oracle.latent(ocb, T.write_latent(lats[i]))
+        lines = (tmp_path / "out" / f"L{i}.csv").read_text().splitlines()
+        assert len(lines) == 13
+        for line in lines:
+            path, score = line.rsplit(",", 1)
+            path = path.strip('"')
+            hr, _ = oracle.rolled(open(path, "rb").read())
+            rc, want = oracle.pair(ocb, hl, hr, 1)
+            exp = -1.0 if rc == 2 else want[4]
+            assert abs(float(score) - float("%.3f" % exp)) <= 2e-3 * max(1, abs(exp)), (line, exp)
+    out = subprocess.run([exe, "-l", str(tmp_path / "lat" / "L0.dat"), "-g", str(tmp_path / "gal"), "-s", str(tmp_path / "out") + "/", "-c", str(cbp)],
+                         capture_output=True, text=True, cwd=tmp_path / "work")
+    assert out.returncode == 0, out.stderr
+    lines = (tmp_path / "out" / "L0.csv").read_text().splitlines()
+    assert lines[0] == "filename,score" and len(lines) == 14 and lines[1].startswith('1"') and "R000.dat" in lines[1]
+    assert "Match Results" in out.stdout and "Rank     Filename      Score" in out.stdout
+    scores = [float(l.rsplit(",", 1)[1]) for l in lines[1:]]
+    assert scores == sorted(scores, reverse=True) and scores[-1] == -1.0

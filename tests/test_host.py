@@ -1,0 +1,152 @@
+"""CPU tests of the host logic: .dat / codebook formats (Python mirror and the C++ implementation the CLI and C ABI use), the
+C-ABI surface, and the synthetic generator."""
+import ctypes
+import importlib
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+
+T = importlib.import_module("msu-latentafis_amd.host.templates")
+S = importlib.import_module("msu-latentafis_amd.host.synth")
+M = importlib.import_module("msu-latentafis_amd.host.matcher")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "msu-latentafis_amd", "csrc")
+
+
+def fnv(parts):
+    h = 1469598103934665603
+    for b in parts:
+        for byte in b:
+            h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.fixture(scope="module")
+def cb(codebook_bytes):
+    return T.Codebook.from_bytes(codebook_bytes)
+
+
+@pytest.fixture(scope="module")
+def tio():
+    exe = os.path.join(CSRC, "tio_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", CSRC, "tio_check"], check=True)
+    return exe
+
+
+def test_codebook_shipped_file(codebook_bytes, cb, tio, tmp_path):
+    assert len(codebook_bytes) == 98310 and (cb.M, cb.K, cb.dsub) == (16, 256, 6)
+    assert cb.to_bytes() == codebook_bytes
+    assert -0.65 < cb.words.min() < -0.64 and 0.51 < cb.words.max() < 0.52
+    p = tmp_path / "cb.dat"; p.write_bytes(codebook_bytes)
+    out = subprocess.run([tio, "codebook", str(p)], capture_output=True, text=True, check=True).stdout
+    assert "ok=1 M=16 K=256 dsub=6" in out
+    assert int(re.search(r"hash=([0-9a-f]+)", out).group(1), 16) == fnv([cb.words.tobytes()])
+    with pytest.raises(ValueError):
+        T.Codebook.from_bytes(b"\x10\x00\x00\x01\x06\x00")
+
+
+def test_pq_encode_picks_nearest_codeword(cb):
+    rng = np.random.default_rng(0)
+    idx = rng.integers(0, 256, (50, 16))
+    des = np.stack([np.concatenate([cb.words[m, idx[i, m]] for m in range(16)]) for i in range(50)]).astype(np.float32)
+    assert np.array_equal(cb.encode(des), idx.astype(np.uint8))
+    assert np.array_equal(cb.encode(des + rng.normal(0, 1e-4, des.shape).astype(np.float32)), idx.astype(np.uint8))
+
+
+def test_dat_roundtrip_python_and_cpp(cb, tio, tmp_path):
+    lats, gal = cases.small_set(cb, seed=2, n_lat=1, n_gal=4)
+    lb, rb = T.write_latent(lats[0]), T.write_rolled(gal[0])
+    rc, L = T.read_latent(lb)
+    assert rc == 0 and len(L.minu) == 28 and len(L.tex) == 1 and np.array_equal(L.tex[0].des, lats[0].tex[0].des)
+    assert np.array_equal(L.minu[26].des, lats[0].minu[26].des) and np.array_equal(L.minu[2].x, lats[0].minu[2].x)
+    rc, R = T.read_rolled(rb)
+    assert rc == 0 and np.array_equal(R.tex[0].codes, gal[0].tex[0].codes) and np.array_equal(R.minu[0].ori, gal[0].minu[0].ori)
+    assert T.write_latent(L) == lb and T.write_rolled(R) == rb
+    # header layout of descriptor_PQ.py:87-107: 12 x u16 (version 1 first), h, w, blkH, blkW, u8 count
+    assert lb[:2] == b"\x01\x00" and lb[2:24] == b"\x00" * 22 and lb[32] == 28 and rb[32] == 1
+    for kind, buf, t in (("latent", lb, L), ("rolled", rb, R)):
+        p = tmp_path / f"{kind}.dat"; p.write_bytes(buf)
+        out = subprocess.run([tio, kind, str(p)], capture_output=True, text=True, check=True).stdout.splitlines()
+        assert out[0].startswith(f"rc=0 n_minu={len(t.minu)} n_tex={len(t.tex)} ")
+        hashes = [int(re.search(r"hash=([0-9a-f]+)", l).group(1), 16) for l in out[1:]]
+        want = [fnv([m.x.astype("<i2").tobytes(), m.y.astype("<i2").tobytes(), m.ori.tobytes(), m.des.tobytes()]) for m in t.minu]
+        want += [fnv([x.x.astype("<i2").tobytes(), x.y.astype("<i2").tobytes(), x.ori.tobytes(),
+                      x.des.tobytes() if x.des is not None else b"", x.codes.tobytes() if x.codes is not None else b""]) for x in t.tex]
+        assert hashes == want
+        rt = subprocess.run([tio, f"roundtrip-{kind}", str(p)], capture_output=True, text=True, check=True).stdout
+        assert "identical=1" in rt
+
+
+def test_reader_edge_cases(cb, tio, tmp_path):
+    # empty / tiny files (matcher.cpp:798-801, :899-902)
+    assert T.read_latent(b"")[0] == 1 and T.read_rolled(b"\x00" * 10)[0] == 1
+    lats, gal = cases.small_set(cb, seed=3, n_lat=1, n_gal=2)
+    # more than 2000 texture points -> -1 and the rolled template is treated as empty (matcher.cpp:865-869, :173-177)
+    big = T.FPTemplate(minu=list(gal[0].minu), tex=list(gal[0].tex))
+    buf = bytearray(T.write_rolled(big))
+    off = 33 + 2 + gal[0].minu[0].n * (2 + 2 + 4) + 2 + gal[0].minu[0].n * 96 * 4 + 1
+    buf[off:off + 2] = (2001).to_bytes(2, "little")
+    rc, t = T.read_rolled(bytes(buf))
+    assert rc == -1 and t.minu == [] and t.tex == []
+    p = tmp_path / "big.dat"; p.write_bytes(bytes(buf))
+    assert subprocess.run([tio, "rolled", str(p)], capture_output=True, text=True).stdout.startswith("rc=-1")
+    # truncated file: what was read before the end is kept, nothing after (ifstream semantics)
+    rb = T.write_rolled(gal[1])
+    rc, t = T.read_rolled(rb[:len(rb) - 100])
+    assert rc == 0 and len(t.tex) == 1 and np.array_equal(t.tex[0].codes[:-7], gal[1].tex[0].codes[:-7]) and not t.tex[0].codes[-1].any()
+    # texture counts above 1000 are legal on disk (clamped at match time, matcher.cpp:544-547)
+    assert T.MAX_NROF_MINUTIAE == 2000
+
+
+def test_header_only_template_when_no_minutiae(cb):
+    """descriptor_PQ.py:90-93: a template without minutiae templates is 12 shorts + 4 zero shorts and nothing else."""
+    t = T.FPTemplate()
+    assert T.write_rolled(t) == b"\x01\x00" + b"\x00" * 22 + b"\x00" * 8 and T.write_latent(t) == T.write_rolled(t)
+    rc, r = T.read_rolled(T.write_rolled(t))
+    assert rc == 0 and r.minu == [] and r.tex == []
+
+
+def test_abi_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "afis_matcher.h")).read()
+    declared = sorted(set(re.findall(r"\b(afis_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    lib = M.load_library()                       # dlopen only: no device call
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(M.EXPORTS) == set(declared)
+    # no torch / C++ types in the signatures
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # signatures only, comments stripped
+    assert "std::" not in code and "torch" not in code and "hip" not in code.lower() and "&" not in code
+
+
+def test_cli_help_runs_without_gpu():
+    exe = os.path.join(CSRC, "match")
+    if not os.path.exists(exe):
+        pytest.skip("match not built")
+    out = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "-ldir" in out.stdout and "-c <codebook.dat>" in out.stdout
+
+
+def test_synthetic_gallery_is_shard_consistent(cb):
+    G = 2500
+    full = S.make_packed_gallery(9, G, cb)
+    part = S.make_packed_gallery(9, G, cb, 700, 2100)
+    ref = full.slice(700, 2100)
+    for f in ("minu_off", "minu_x", "minu_des", "tex_off", "tex_codes", "tex_ori"):
+        assert np.array_equal(getattr(part, f), getattr(ref, f)), f
+    lats = S.make_latents(9, 3, n_tex_lo=220, n_tex_hi=260)
+    p1 = S.plant_mates(9, full, cb, lats)
+    p2 = S.plant_mates(9, part, cb, lats, G=G, lo=700)
+    assert p1 == p2
+    ref = full.slice(700, 2100)
+    for f in ("minu_x", "minu_des", "tex_codes", "tex_x"):
+        assert np.array_equal(getattr(part, f), getattr(ref, f)), f
+    nm, nt = S.gallery_counts(9, G)
+    assert nm.min() >= 20 and nm.max() <= 200 and nt.min() >= 600 and nt.max() <= 1000
+    assert np.allclose(np.linalg.norm(full.minu_des[:100], axis=1), 1.73, atol=1e-4)

@@ -1,0 +1,15 @@
+import sys, importlib, itertools
+sys.path.insert(0, "/root/repo")
+T = importlib.import_module("msu-latentafis_amd.host.templates"); S = importlib.import_module("msu-latentafis_amd.host.synth"); M = importlib.import_module("msu-latentafis_amd.host.matcher")
+cbb = open("/root/repo/tests/golden/codebook_EmbeddingSize_96_stride_16_subdim_6.dat","rb").read(); cb = T.Codebook.from_bytes(cbb)
+G, Q = 10000, 4
+lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb); S.plant_mates(1, gal, cb, lats)
+m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0); qh = m.upload_queries(lats)
+ref = None
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3]
+for variant, chunk in itertools.product(variants, (32, 64, 128)):
+    m.set_option("adc_variant", variant); m.set_option("chunk", chunk)
+    m.search_resident(qh); r = m.search_resident(qh, want_scores=True); tm = m.timing()
+    if ref is None: ref = r["scores"]
+    same = (r["scores"] == ref).all()
+    print(f"variant {variant} chunk {chunk:4d}: adc {tm['adc_ms']:.2f} ms  lookups/s {tm['adc_lookups']/tm['adc_ms']/1e9:.2f} T  identical={same}")
