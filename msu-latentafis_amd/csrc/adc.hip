@@ -20,6 +20,8 @@ namespace afis {
 // Tile layouts (float index inside the 32768-float tile of rows r = 0..7, rq = r/4, r4 = r%4):
 //   variant 0 : ((rq*16 + m)*256 + k)*4 + r4
 //   variant 1 : (((mg*256 + k)*4 + c)*2 + rq)*4 + r4   with m = 4*mg + c   (chain-major: bank slot depends on (c,rq))
+//   variant 4 : ((k*2 + (mg&1))*16 + c*4 + rq*2 + (mg>>1))*4 + r4   — the 16-byte bank slot (float4 index mod 16) is
+//               (chain c, row-quad rq, mg>>1); the entry of m = 0 holds lut - 6 (see k_adc_rowmax_cf)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lut_entry(const float* __restrict__ des6, const float* __restrict__ cw6)
 {
@@ -56,7 +58,13 @@ __global__ __launch_bounds__(256) void k_lut_build(QueryDev q, const float* __re
         v[r] = lut_entry(des6, cw6);
     }
     float4* t4 = reinterpret_cast<float4*>(lut_tiles + (size_t)tile * kTileFloats);
-    if ((variant & 1) == 0) {
+    if (variant >= 4) {
+        const int mg = m >> 2, c = m & 3;
+        const float six = m == 0 ? 6.0f : 0.0f;                 // -(l0 - 6) == 6 - l0 exactly
+        const int e = (k * 2 + (mg & 1)) * 16 + c * 4 + (mg >> 1);
+        t4[e + 0] = make_float4(v[0] - six, v[1] - six, v[2] - six, v[3] - six);
+        t4[e + 2] = make_float4(v[4] - six, v[5] - six, v[6] - six, v[7] - six);
+    } else if ((variant & 1) == 0) {
         t4[(0 * 16 + m) * 256 + k] = make_float4(v[0], v[1], v[2], v[3]);
         t4[(1 * 16 + m) * 256 + k] = make_float4(v[4], v[5], v[6], v[7]);
     } else {
@@ -103,7 +111,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i)
     for (int off = 32; off >= 1; off >>= 1) {
         const float ov = __shfl_xor(v, off);
         const int oi = __shfl_xor(i, off);
-        const bool take = (ov > v) || (ov == v && oi < i);
+        const bool take = (ov > v) | ((ov == v) & (oi < i));     // bitwise: no short-circuit branches
         v = take ? ov : v;
         i = take ? oi : i;
     }
@@ -230,6 +238,163 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax(QueryDev q, GalleryD
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Conflict-free variant (4).  A ds_read_b128 is serviced 16 lanes at a time, each lane on one of 16 bank slots of 16 bytes.
+// Here the 16 lanes of a group are 16 different CLASSES (a = lane & 15): chain rotation pc (4) x row-quad swap pr (2) x a
+// half-period shift pm (2).  At every read instruction lane class (pc, pr, pm) touches chain perm[(c+pc)&3], row quad r^pr
+// and sub-quantizer group mg = (j + 2*pm) & 3, and the LUT tile stores (chain, row-quad, mg>>1) in the slot index, so the 16
+// lanes of a group always hit 16 distinct slots whatever their PQ codes are: zero bank conflicts by construction.
+//   * lanes with pm = 1 run half a period late: steps j = 0,1 finish the PREVIOUS point (mg = 2,3), steps j = 2,3 start the
+//     current one (mg = 0,1).  Their finished sums are consumed after j = 1, the others' after j = 3.
+//   * a chain is restarted with x = fma(x, keep, -v), keep = 0 for the lanes that start a point at this step and 1 for the
+//     rest; fma(x, 1, -v) == x - v and fma(x, 0, -v) == 0 - v, and the tile holds l0 - 6 for m = 0, so the first chain
+//     starts at 6 - l0 exactly as matcher.cpp:571-580.  Each chain still sees m = c, c+4, c+8, c+12 in this order.
+//   * the PQ codes are stored pre-permuted per class (GalleryDev::tex_codes_cf), so every byte extraction uses constants.
+// ---------------------------------------------------------------------------------------------------------------
+template <int kAdcThreads>
+__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
+                                                               int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
+{
+    __shared__ float4 s_lut[kTileFloats / 4];                 // 128 KB
+    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
+    const int tile = seq % q.n_tiles;
+    const int chunk_id = (seq / q.n_tiles) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
+    int qi = 0;
+    while (qi + 1 < q.nq && tile >= q.tile_off[qi + 1]) ++qi;
+    const int row0 = (tile - q.tile_off[qi]) * kTileRows;
+    const int n_lt = q.lt_off[qi + 1] - q.lt_off[qi];
+    {
+        const float4* src = reinterpret_cast<const float4*>(lut_tiles + (size_t)tile * kTileFloats);
+        for (int i = threadIdx.x; i < kTileFloats / 4; i += kAdcThreads) s_lut[i] = src[i];
+    }
+    __syncthreads();
+
+    constexpr int kAdcWaves = kAdcThreads / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g_lo = chunk_id * chunk;
+    const int g_hi = min(g.G, g_lo + chunk);
+
+    const int a = lane & 15, pr = a & 1, pc = (a >> 1) & 3, pm = a >> 3;
+    const bool late = pm != 0;
+    int so[4][2];                                              // byte offset of (physical chain slot c, half hi) for row-quad slot 0
+    {
+        const int perm[4] = {0, 2, 1, 3};                      // physical order (d1,d3,d2,d4): (P0+P2)+(P1+P3) is rotation-invariant
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) so[c][hi] = (perm[(c + pc) & 3] * 4 + pr * 2 + (hi ^ pm)) * 16;   // bytes
+    }
+    const float keep0 = late ? 1.0f : 0.0f;                    // step j = 0 restarts the chains of the on-time lanes
+    const float keep2 = late ? 0.0f : 1.0f;                    // step j = 2 restarts the chains of the late lanes
+
+    for (int gi = g_lo + wave; gi < g_hi; gi += kAdcWaves) {
+        const int p0 = g.tex_off[gi], n_pts = g.tex_off[gi + 1] - p0;
+        if (n_pts <= 0) continue;
+        const int n_blocks = (n_pts + 63) >> 6;
+        float best[kTileRows]; int bidx[kTileRows];
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; }
+        float P[4][2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) P[c][r][i] = 0.0f;
+        uint32_t old0 = 0, old1 = 0;
+
+        auto consume = [&](bool valid, int p) {                // (d1+d2)+(d3+d4), matcher.cpp:592, then the running first maximum
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sres = (P[0][r][i] + P[2][r][i]) + (P[1][r][i] + P[3][r][i]);
+                    const bool take = valid & (sres > best[r * 4 + i]);
+                    best[r * 4 + i] = take ? sres : best[r * 4 + i];
+                    bidx[r * 4 + i] = take ? p : bidx[r * 4 + i];
+                }
+        };
+
+        // one extra (drain) block lets the late lanes finish the last point; its steps 2,3 run on zero codes and are never consumed
+        uint4 cw_next = make_uint4(0, 0, 0, 0);
+        if (lane < n_pts) cw_next = g.tex_codes_cf[p0 + lane];
+#if defined(ADC_ABLATE) && ADC_ABLATE == 4
+        for (int blk = 0; blk < 0; ++blk) {
+#elif defined(ADC_ABLATE) && ADC_ABLATE == 5
+        for (int blk = 0; blk <= n_blocks; blk += 4) {
+#else
+        for (int blk = 0; blk <= n_blocks; ++blk) {
+#endif
+            const int p = blk * 64 + lane;
+            const bool have = blk < n_blocks && p < n_pts;
+            const uint4 cw = cw_next;
+            cw_next = make_uint4(0, 0, 0, 0);
+            if (blk + 1 < n_blocks && p + 64 < n_pts) cw_next = g.tex_codes_cf[p0 + p + 64];      // prefetch the next block's codes
+            const uint32_t w[4] = {late ? old0 : cw.x, late ? old1 : cw.y, cw.z, cw.w};
+            // all 32 look-ups of the block are issued before the first accumulate
+            float4 v[4][4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t code = __builtin_amdgcn_ubfe(w[j], 8 * c, 8);
+                    const uint32_t a0 = (code << 9) + (uint32_t)so[c][j >> 1];          // v_lshl_add_u32
+                    const uint32_t a1 = a0 ^ 32u;                                        // the other row quad: slot bit 1
+                    const char* lb = reinterpret_cast<const char*>(s_lut) + (j & 1) * 256;   // folds into the ds_read offset field
+                    v[j][c][0] = *reinterpret_cast<const float4*>(lb + a0);
+                    v[j][c][1] = *reinterpret_cast<const float4*>(lb + a1);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = j == 0 ? keep0 : keep2;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float4 x = v[j][c][r];
+#if defined(ADC_ABLATE) && ADC_ABLATE == 2
+                        asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+                        continue;
+#endif
+                        if (j == 0 || j == 2) {                // steps that restart the chains of one half of the lanes
+                            P[c][r][0] = fmaf(P[c][r][0], keep, -x.x); P[c][r][1] = fmaf(P[c][r][1], keep, -x.y);
+                            P[c][r][2] = fmaf(P[c][r][2], keep, -x.z); P[c][r][3] = fmaf(P[c][r][3], keep, -x.w);
+                        } else {
+                            P[c][r][0] -= x.x; P[c][r][1] -= x.y; P[c][r][2] -= x.z; P[c][r][3] -= x.w;
+                        }
+                    }
+#if !defined(ADC_ABLATE) || ADC_ABLATE != 1
+                if (j == 1) consume(late && blk > 0 && p - 64 < n_pts, p - 64);   // the late lanes have just finished the previous block's point
+                if (j == 3) consume(!late && have, p);
+#else
+                if (j == 3 && blk == n_blocks) consume(true, p);
+#endif
+            }
+            old0 = cw.x; old1 = cw.y;
+        }
+        if (pr) {                                              // this lane kept rows 4..7 in slots 0..3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tv = best[r]; best[r] = best[r + 4]; best[r + 4] = tv;
+                int ti = bidx[r]; bidx[r] = bidx[r + 4]; bidx[r + 4] = ti;
+            }
+        }
+        float outv = 0.f; int outi = 0;
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) {
+            wave_argmax(best[r], bidx[r]);
+            if (lane == r) { outv = best[r]; outi = bidx[r]; }
+        }
+        if (lane < kTileRows && row0 + lane < n_lt) {
+            const size_t o = ((size_t)qi * g.G + gi) * q.lt_pad + row0 + lane;
+            rm_val[o] = outv;
+            rm_arg[o] = outi;
+        }
+    }
+}
+
 hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
                              float* rm_val, int32_t* rm_arg, hipStream_t stream)
 {
@@ -237,11 +402,13 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
     const int n_chunks = (g.G + chunk - 1) / chunk;
     const long long blocks = (long long)((n_chunks + 7) / 8) * 8 * q.n_tiles;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const int threads = variant >= 2 ? 1024 : 512;             // variants 2,3 = variants 0,1 with 1024-thread workgroups
+    const int threads = (variant == 2 || variant == 3) ? 1024 : 512;   // variants 2,3 = variants 0,1 with 1024-thread workgroups
     switch (variant) {
     case 0: hipLaunchKernelGGL((k_adc_rowmax<0, 512>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     case 1: hipLaunchKernelGGL((k_adc_rowmax<1, 512>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     case 2: hipLaunchKernelGGL((k_adc_rowmax<0, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 4: hipLaunchKernelGGL((k_adc_rowmax_cf<512>), dim3((unsigned)blocks), dim3(512), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 5: hipLaunchKernelGGL((k_adc_rowmax_cf<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     default: hipLaunchKernelGGL((k_adc_rowmax<1, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     }
     return hipGetLastError();

@@ -70,14 +70,15 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_empty;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_empty;
     int max_nR = 0;
     int64_t total_tex_points = 0;
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n;
     std::vector<float> h_scores, h_parts;
-    int adc_variant = 1;
+    int adc_variant = 5;
     int query_batch = 8;
     int chunk = 128;
+    int minu_generic = 0;
     int64_t rowmax_budget_bytes = 24ll << 30;
     afis_timing timing = {};
 };
@@ -147,7 +148,7 @@ void views_of(const HostTemplate& t, std::vector<afis_minutiae_view>& mv, std::v
 void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release();
-    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_empty.release();
+    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_empty.release();
 }
 
 }  // namespace
@@ -288,13 +289,29 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_codes, hg.tcodes, ctx->stream));
+    {   // conflict-free ADC layout: point p of a template belongs to lane class a = p & 15 (pc = (a>>1)&3, pm = a>>3);
+        // dword d holds sub-quantizer group mg = (d + 2*pm) & 3, byte c of it holds chain perm[(c + pc) & 3]  (adc.hip)
+        std::vector<uint8_t> cf(hg.tcodes.size());
+        static const int perm[4] = {0, 2, 1, 3};
+        for (int64_t t = 0; t < G; ++t) {
+            for (int64_t pt = hg.tex_off[t]; pt < hg.tex_off[t + 1]; ++pt) {
+                const int a = (int)((pt - hg.tex_off[t]) & 15), pc = (a >> 1) & 3, pm = a >> 3;
+                const uint8_t* src = &hg.tcodes[(size_t)pt * kM];
+                uint8_t* dst = &cf[(size_t)pt * kM];
+                for (int d = 0; d < 4; ++d)
+                    for (int c = 0; c < 4; ++c) dst[d * 4 + c] = src[4 * ((d + 2 * pm) & 3) + perm[(c + pc) & 3]];
+            }
+        }
+        HIPCHK(ctx, upload(ctx->g_tex_codes_cf, cf, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     GalleryDev& g = ctx->gal;
     g.G = (int32_t)G;
     g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
     g.minu_des = ctx->g_minu_des.as<float>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
-    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.empty = ctx->g_empty.as<uint8_t>();
+    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.empty = ctx->g_empty.as<uint8_t>();
     ctx->max_nR = max_nR;
     ctx->total_tex_points = (int64_t)hg.tx.size();
     ctx->index_base = index_base;
@@ -432,7 +449,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
-            HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
+            HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
@@ -511,9 +528,10 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
-    if (n == "adc_variant") { if (value < 0 || value > 3) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3"); ctx->adc_variant = (int)value; }
+    if (n == "adc_variant") { if (value < 0 || value > 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..5"); ctx->adc_variant = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 1 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 1..65536"); ctx->chunk = (int)value; }
+    else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
     return AFIS_OK;

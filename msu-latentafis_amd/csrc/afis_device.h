@@ -28,6 +28,7 @@ struct GalleryDev {
     const short2*  tex_xy = nullptr;     // [NT]   block coords
     const float*   tex_ori = nullptr;    // [NT]
     const uint4*   tex_codes = nullptr;  // [NT]   16 PQ code bytes per point, byte m = sub-quantizer m
+    const uint4*   tex_codes_cf = nullptr;  // [NT] the same bytes permuted per lane class for the conflict-free ADC kernel (adc.hip)
     const uint8_t* empty = nullptr;      // [G] 1 = rolled template has neither minutiae nor texture (score -1)
 };
 
@@ -62,8 +63,9 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
                                 const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
 // (task = (q*3+s)*G + g)
+// Pairs with <= 64 latent and <= 128 rolled minutiae go through an LDS/scalar-cache fast kernel, the rest through the tiled generic one.
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                             MinuCand* cands, int32_t* cand_n, hipStream_t stream);
+                             int max_nL, int max_nR, int force_generic, MinuCand* cands, int32_t* cand_n, hipStream_t stream);
 // S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
                                  float* parts, hipStream_t stream);

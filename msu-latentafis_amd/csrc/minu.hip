@@ -66,7 +66,7 @@ struct MinuSmem {
 
 // Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
 __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
-                                                         MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
+                                                         MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int skip_fast)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
         const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
         const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
         if (nL <= 0 || nR <= 0) { if (tid == 0) cand_n[task] = 0; continue; }     // matcher.cpp:400-404
+        if (skip_fast && nL <= kFastL && nR <= kFastR) continue;                   // done by k_minu_cands_fast
         const int n = nL * nR;
         PHASE_INIT();
         const bool fast = nL <= kFastL && nR <= kFastR;
@@ -238,8 +239,195 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fast path: pairs with nL <= 64 latent and nR <= 128 rolled minutiae (every template the extraction normally produces).
+//   S1  lane = latent minutia i (its 96-d descriptor lives in VGPRs), wave w takes the rolled minutiae j = w, w+4, ...;
+//       the rolled descriptor is wave-uniform, so it arrives through the scalar cache (s_load) and feeds v_fmac as an SGPR
+//       operand: no LDS tiles, no barriers, k-ascending fmaf chain as in the oracle.
+//   S2  sums and S3 keys from the LDS-resident similarity matrix.
+//   S3  top-120 in two stages with ONE barrier: every wave finds the 120 largest of its own quarter of the keys (bit-by-bit
+//       threshold search on ballot/popcount counts, keys in registers), wave 0 then takes the 120 largest of those <= 480 and
+//       ranks them.  Keys are 45-bit composites (norm key << 13 | 8191 - element index): unique, so "larger = earlier" is
+//       exactly "norm descending, index ascending" and no tie handling is needed.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kFastU = kFastN / kThreads;            // 32 keys per lane at most
+struct FastSmem {
+    float simi[kFastN];                               // 32 KB
+    float rowsum[kFastL];
+    float colsum[kFastR];
+    u64 list[kWaves * kTopMinu];                      // stage-1 survivors
+    u64 top[128];                                     // stage-2 survivors
+    int counts[kWaves];
+};
+
+// K-th largest of the wave's composite keys c[0..U) (0 = padding), K >= 1 and K <= number of non-zero keys
+template <int U>
+__device__ __forceinline__ u64 wave_kth_largest(const u64 (&c)[U], int K)
+{
+    u64 T = 0;
+    for (int bit = 44; bit >= 0; --bit) {
+        const u64 cand = T | (1ull << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt += wave_popc(c[u] >= cand);
+        if (cnt >= K) T = cand;
+    }
+    return T;
+}
+__device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
+
+__global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_des,
+                                                              const float* __restrict__ rol_des,   // = q.lm_des / g.minu_des, as read-only
+                                                              MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)   // kernel arguments: scalar loads
+{
+    __shared__ FastSmem sm;
+    const long long n_tasks = (long long)q.nq * 3 * g.G;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+        const int gi = (int)(task % g.G);
+        const int qs = (int)(task / g.G);
+        const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
+        const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
+        if (nL <= 0 || nR <= 0) { if (tid == 0) cand_n[task] = 0; continue; }     // matcher.cpp:400-404
+        if (nL > kFastL || nR > kFastR) continue;                                  // left to k_minu_cands
+        const int n = nL * nR;
+        PHASE_INIT();
+        // ---- S1 (matcher.cpp:440-452) ----
+        {
+            float a[kDes];
+            const float4* ap = reinterpret_cast<const float4*>(lat_des + (size_t)(l0 + (lane < nL ? lane : 0)) * kDes);
+#pragma unroll
+            for (int k4 = 0; k4 < kDes / 4; ++k4) { const float4 v = ap[k4]; a[4 * k4] = v.x; a[4 * k4 + 1] = v.y; a[4 * k4 + 2] = v.z; a[4 * k4 + 3] = v.w; }
+            for (int j = wave; j < nR; j += kWaves) {
+                const float* __restrict__ b = rol_des + (size_t)(r0 + j) * kDes;       // wave-uniform address: scalar loads
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kDes; ++k) acc = fmaf(a[k], b[k], acc);
+                if (acc < 0) acc = 0;
+                if (lane < nL) sm.simi[lane * nR + j] = acc;
+            }
+        }
+        __syncthreads();
+        PHASE(16);
+        // ---- S2 (:455-456): index-ascending sums ----
+        if (tid < nR) {
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int i = 0; i < nL; ++i) sacc += sm.simi[i * nR + tid];
+            sm.colsum[tid] = sacc;
+        } else if (tid >= 128 && tid - 128 < nL) {
+            const int i = tid - 128;
+            float sacc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < nR; ++j) sacc += sm.simi[i * nR + j];
+            sm.rowsum[i] = sacc;
+        }
+        __syncthreads();
+        PHASE(17);
+        // ---- S3 (:461-488) stage 1: element e = (u*4 + wave)*64 + lane belongs to this wave ----
+        const int topN = n < kTopMinu ? n : kTopMinu;
+        uint32_t rk[kFastU];                                                 // 32-bit norm keys; the element index is implied by (u, lane)
+        int n_own = 0;
+        {
+            // (i, j) of the lane's first element and the step between consecutive elements (256), without per-element divisions
+            int e = wave * 64 + lane;
+            int i = e / nR, j = e - i * nR;
+            const int si = kThreads / nR, sj = kThreads - si * nR;
+#pragma unroll
+            for (int u = 0; u < kFastU; ++u) {
+                uint32_t key = 0;                                            // real keys have the top bit set
+                if (e < n) {
+                    const float sv = sm.simi[e];
+                    float f = sm.rowsum[i] + sm.colsum[j];
+                    f = f - sv;
+                    key = ord_f32((float)((double)sv / ((double)f + 0.000001)));                    // :467
+                }
+                rk[u] = key;
+                n_own += wave_popc(e < n);
+                e += kThreads; i += si; j += sj; if (j >= nR) { j -= nR; ++i; }
+            }
+        }
+        PHASE(18);
+        const int Kw = n_own < kTopMinu ? n_own : kTopMinu;
+        if (Kw > 0) {
+            uint32_t T = 0x80000000u;
+            for (int bit = 30; bit >= 0; --bit) {
+                const uint32_t cand = T | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < kFastU; ++u) cnt += wave_popc(rk[u] >= cand);
+                if (cnt >= Kw) T = cand;
+            }
+            int n_gt = 0;
+#pragma unroll
+            for (int u = 0; u < kFastU; ++u) n_gt += wave_popc(rk[u] > T);
+            const int need = Kw - n_gt;                                      // keys equal to T: keep the lowest element indices
+            int base_gt = 0, base_eq = 0;
+#pragma unroll
+            for (int u = 0; u < kFastU; ++u) {                               // (u, lane) ascending = element index ascending
+                const int e = (u * kWaves + wave) * 64 + lane;
+                const bool gt = rk[u] > T, eq = rk[u] == T;
+                const u64 mg = __ballot(gt), me = __ballot(eq);
+                int pos = -1;
+                if (gt) pos = base_gt + lane_prefix(mg);
+                else if (eq) { const int r = base_eq + lane_prefix(me); if (r < need) pos = n_gt + r; }
+                if (pos >= 0) sm.list[wave * kTopMinu + pos] = ((u64)rk[u] << 13) | (u64)(8191 - e);
+                base_gt += __popcll(mg); base_eq += __popcll(me);
+            }
+        }
+        if (lane == 0) sm.counts[wave] = Kw;
+        __syncthreads();
+        PHASE(19);
+        // ---- stage 2 (wave 0): the topN largest of the <= 480 survivors, then rank them ----
+        if (wave == 0) {
+            constexpr int V = kWaves * kTopMinu / 64 + 1;                     // 8 keys per lane
+            u64 d[V];
+            int off[kWaves + 1]; off[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) off[w + 1] = off[w] + sm.counts[w];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int p = v * 64 + lane;                                  // position in the concatenation of the four lists
+                u64 key = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.list[w * kTopMinu + p - off[w]];
+                d[v] = key;
+            }
+            const u64 T = wave_kth_largest<V>(d, topN);
+            int base = 0;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const bool take = d[v] >= T && d[v] != 0;
+                const u64 m = __ballot(take);
+                if (take) sm.top[base + lane_prefix(m)] = d[v];
+                base += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // rank by counting; the list leaves in rank order
+            u64 mine[2]; int r[2] = {0, 0};
+            mine[0] = lane < topN ? sm.top[lane] : 0; mine[1] = lane + 64 < topN ? sm.top[lane + 64] : 0;
+#pragma unroll 4
+            for (int k = 0; k < topN; ++k) { const u64 kk = sm.top[k]; r[0] += kk > mine[0]; r[1] += kk > mine[1]; }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (lane + 64 * h < topN) {
+                    const int e = 8191 - (int)(mine[h] & 8191);
+                    const int i1 = e / nR, i2 = e - i1 * nR;
+                    MinuCand cd; cd.sim = sm.simi[e]; cd.li = (short)i1; cd.ri = (short)i2;
+                    cands[(size_t)task * kTopMinu + r[h]] = cd;
+                }
+            }
+            if (lane == 0) cand_n[task] = topN;
+        }
+        __syncthreads();
+        PHASE(20);
+    }
+}
+
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                             MinuCand* cands, int32_t* cand_n, hipStream_t stream)
+                             int max_nL, int max_nR, int force_generic, MinuCand* cands, int32_t* cand_n, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
@@ -249,8 +437,14 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (!force_generic) {
+        const int gridf = (int)(n_tasks < 8192 ? n_tasks : 8192);
+        hipLaunchKernelGGL(k_minu_cands_fast, dim3(gridf), dim3(kThreads), 0, stream, q, g, q.lm_des, g.minu_des, cands, cand_n);
+        if (max_nL <= kFastL && max_nR <= kFastR) return hipGetLastError();       // every pair took the fast path
+    }
     const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
-    hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n);
+    hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n,
+                       force_generic ? 0 : 1);
     return hipGetLastError();
 }
 

@@ -47,7 +47,7 @@ def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
 def test_rowmax_bit_exact(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -68,7 +68,7 @@ def _compare(res, orc_parts, tol=1e-3):
     return got, want, err
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 5])
 def test_scores_small(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -190,10 +190,15 @@ def test_medium_properties_and_sharding(codebook_bytes, cb, oracle, medium):
     fused = ((p[..., 0] + p[..., 1]) + p[..., 2]).astype(np.float64) + p[..., 3].astype(np.float64) * 0.3
     assert np.array_equal(fused.astype(np.float32), r1["scores"])
     assert (r1["scores"] >= 0).all()
-    # (5) both ADC variants give identical bits
-    m.set_option("adc_variant", 0)
+    # (5) every ADC variant and the generic minutiae candidate kernel give identical bits
+    for v in (0, 1, 4):
+        m.set_option("adc_variant", v)
+        r0 = m.search(lats, k=0)
+        assert np.array_equal(r0["scores"], r1["scores"]), v
+    m.set_option("adc_variant", 5); m.set_option("minu_generic", 1)
     r0 = m.search(lats, k=0)
     assert np.array_equal(r0["scores"], r1["scores"])
+    m.set_option("minu_generic", 0)
     # (6) gallery sharding: two contiguous shards with global indices, merged rank lists == single-shard rank lists
     SH = importlib.import_module("msu-latentafis_amd.host.sharding")
     nm, nt = S.gallery_counts(77, G)
@@ -228,6 +233,8 @@ def test_cli_matches_oracle(codebook_bytes, cb, oracle, small, tmp_path):
     """The drop-in CLI: -l and -ldir output files against the oracle's scores (SURVEY §3.1 / §3.2 formats)."""
     import os, subprocess
     exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(M.LIB_PATH), "match"], check=True)
     lats, gal = small
     (tmp_path / "work").mkdir(); (tmp_path / "gal").mkdir(); (tmp_path / "lat").mkdir(); (tmp_path / "out").mkdir()
     cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)

@@ -9,4 +9,4 @@ m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0); qh = m.uploa
 m.search_resident(qh); m.phase_cycles(True)
 m.search_resident(qh); ph = m.phase_cycles(True); tm = m.timing()
 tot = sum(ph); print("timing", {k: round(v,2) for k,v in tm.items() if k.endswith("ms")})
-print("phase Mcycles:", [round(p/1e6) for p in ph[:20]])
+print("phase Mcycles:", [round(p/1e6) for p in ph[:24]])
