@@ -47,10 +47,10 @@ struct HostGallery {
 // One group of latents resident on the device.
 struct QueryGroup {
     QueryDev dev;
-    DevBuf lm_off, lm_xy, lm_ori, lm_des, lt_off, lt_xy, lt_ori, lt_des, tile_off, tex_slot, status;
+    DevBuf lm_off, lm_xy, lm_ori, lm_des, lm_desp, lt_off, lt_xy, lt_ori, lt_des, tile_off, tex_slot, status;
     int nq = 0; int max_nL = 0; int64_t lut_rows_x_tiles = 0;
     std::vector<int32_t> h_lt_n;
-    void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
+    void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lm_desp.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
                      lt_des.release(); tile_off.release(); tex_slot.release(); status.release(); }
 };
 
@@ -70,7 +70,7 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_empty;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_desp, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_empty;
     int max_nR = 0;
     int64_t total_tex_points = 0;
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n;
@@ -145,9 +145,20 @@ void views_of(const HostTemplate& t, std::vector<afis_minutiae_view>& mv, std::v
     out.n_minu = (int)mv.size(); out.minu = mv.data(); out.n_tex = (int)tv.size(); out.tex = tv.data();
 }
 
+// k-permuted descriptor copy for the MFMA fragments: out[row][g*24 + s] = in[row][4*s + g]
+std::vector<float> permute_k(const std::vector<float>& in)
+{
+    std::vector<float> out(in.size());
+    const size_t rows = in.size() / kDes;
+    for (size_t r = 0; r < rows; ++r)
+        for (int g = 0; g < 4; ++g)
+            for (int s = 0; s < 24; ++s) out[r * kDes + g * 24 + s] = in[r * kDes + 4 * s + g];
+    return out;
+}
+
 void free_gallery_dev(afis_ctx* c)
 {
-    c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release();
+    c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_desp.release();
     c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_empty.release();
 }
 
@@ -285,6 +296,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     HIPCHK(ctx, upload(ctx->g_minu_xy, mxy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_ori, hg.mori, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_des, hg.mdes, ctx->stream));
+    { const std::vector<float> p = permute_k(hg.mdes); HIPCHK(ctx, upload(ctx->g_minu_desp, p, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
     HIPCHK(ctx, upload(ctx->g_tex_off, to, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
@@ -310,7 +322,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     GalleryDev& g = ctx->gal;
     g.G = (int32_t)G;
     g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
-    g.minu_des = ctx->g_minu_des.as<float>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
+    g.minu_des = ctx->g_minu_des.as<float>(); g.minu_desp = ctx->g_minu_desp.as<float>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
     g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.empty = ctx->g_empty.as<uint8_t>();
     ctx->max_nR = max_nR;
     ctx->total_tex_points = (int64_t)hg.tx.size();
@@ -367,13 +379,15 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
     }
     hipStream_t s = ctx->stream;
     HIPCHK(ctx, upload(grp.lm_off, lm_off, s)); HIPCHK(ctx, upload(grp.lm_xy, lm_xy, s)); HIPCHK(ctx, upload(grp.lm_ori, lm_ori, s));
-    HIPCHK(ctx, upload(grp.lm_des, lm_des, s)); HIPCHK(ctx, upload(grp.lt_off, lt_off, s)); HIPCHK(ctx, upload(grp.lt_xy, lt_xy, s));
+    HIPCHK(ctx, upload(grp.lm_des, lm_des, s)); HIPCHK(ctx, upload(grp.lt_off, lt_off, s));
+    const std::vector<float> lm_desp = permute_k(lm_des);
+    HIPCHK(ctx, upload(grp.lm_desp, lm_desp, s)); HIPCHK(ctx, upload(grp.lt_xy, lt_xy, s));
     HIPCHK(ctx, upload(grp.lt_ori, lt_ori, s)); HIPCHK(ctx, upload(grp.lt_des, lt_des, s)); HIPCHK(ctx, upload(grp.tile_off, tile_off, s));
     HIPCHK(ctx, upload(grp.tex_slot, tex_slot, s)); HIPCHK(ctx, upload(grp.status, status, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     QueryDev& d = grp.dev;
     d.nq = nq;
-    d.lm_off = grp.lm_off.as<int32_t>(); d.lm_xy = grp.lm_xy.as<short2>(); d.lm_ori = grp.lm_ori.as<float>(); d.lm_des = grp.lm_des.as<float>();
+    d.lm_off = grp.lm_off.as<int32_t>(); d.lm_xy = grp.lm_xy.as<short2>(); d.lm_ori = grp.lm_ori.as<float>(); d.lm_des = grp.lm_des.as<float>(); d.lm_desp = grp.lm_desp.as<float>();
     d.lt_off = grp.lt_off.as<int32_t>(); d.lt_xy = grp.lt_xy.as<short2>(); d.lt_ori = grp.lt_ori.as<float>(); d.lt_des = grp.lt_des.as<float>();
     d.tile_off = grp.tile_off.as<int32_t>(); d.tex_slot = grp.tex_slot.as<int32_t>(); d.status = grp.status.as<int32_t>();
     d.n_tiles = tile_off.back();

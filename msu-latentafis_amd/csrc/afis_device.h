@@ -24,6 +24,7 @@ struct GalleryDev {
     const short2*  minu_xy = nullptr;    // [NM]   pixel coords
     const float*   minu_ori = nullptr;   // [NM]
     const float*   minu_des = nullptr;   // [NM][96]
+    const float*   minu_desp = nullptr;  // [NM][96] same values, k-permuted [g][s] = des[4s+g] (MFMA fragment order, minu.hip)
     const int32_t* tex_off = nullptr;    // [G+1]  (counts already clamped to 1000)
     const short2*  tex_xy = nullptr;     // [NT]   block coords
     const float*   tex_ori = nullptr;    // [NT]
@@ -39,6 +40,7 @@ struct QueryDev {
     const short2*  lm_xy = nullptr;
     const float*   lm_ori = nullptr;
     const float*   lm_des = nullptr;     // [NLM][96]
+    const float*   lm_desp = nullptr;    // [NLM][96] k-permuted copy
     const int32_t* lt_off = nullptr;     // [nq+1] texture rows (clamped to 1000)
     const short2*  lt_xy = nullptr;
     const float*   lt_ori = nullptr;

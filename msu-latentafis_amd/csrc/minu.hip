@@ -241,9 +241,9 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Fast path: pairs with nL <= 64 latent and nR <= 128 rolled minutiae (every template the extraction normally produces).
-//   S1  lane = latent minutia i (its 96-d descriptor lives in VGPRs), wave w takes the rolled minutiae j = w, w+4, ...;
-//       the rolled descriptor is wave-uniform, so it arrives through the scalar cache (s_load) and feeds v_fmac as an SGPR
-//       operand: no LDS tiles, no barriers, k-ascending fmaf chain as in the oracle.
+//   S1  the one dense contraction of the path (the reference's Eigen GEMM) runs on the matrix cores with the exact-fp32
+//       v_mfma_f32_16x16x4_f32: wave w owns the 16-column tiles w, w+4, ...; fragments come straight from HBM/L2 (k-permuted
+//       descriptor copies), results go to the LDS-resident similarity matrix.  No LDS staging, no barriers.
 //   S2  sums and S3 keys from the LDS-resident similarity matrix.
 //   S3  top-120 in two stages with ONE barrier: every wave finds the 120 largest of its own quarter of the keys (bit-by-bit
 //       threshold search on ballot/popcount counts, keys in registers), wave 0 then takes the 120 largest of those <= 480 and
@@ -276,9 +276,9 @@ __device__ __forceinline__ u64 wave_kth_largest(const u64 (&c)[U], int K)
 }
 __device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
-__global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_des,
-                                                              const float* __restrict__ rol_des,   // = q.lm_des / g.minu_des, as read-only
-                                                              MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)   // kernel arguments: scalar loads
+__global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
+                                                              const float* __restrict__ rol_desp,   // k-permuted descriptor copies
+                                                              MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
 {
     __shared__ FastSmem sm;
     const long long n_tasks = (long long)q.nq * 3 * g.G;
@@ -293,19 +293,38 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, Galler
         if (nL > kFastL || nR > kFastR) continue;                                  // left to k_minu_cands
         const int n = nL * nR;
         PHASE_INIT();
-        // ---- S1 (matcher.cpp:440-452) ----
+        // ---- S1 (matcher.cpp:440-452): simi = max(0, A * B^T) on the matrix cores ----
+        // v_mfma_f32_16x16x4_f32 is exact fp32: D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C)))), i.e. bit for bit the
+        // k-ascending fmaf chain of the oracle (CDNA4 guide §3 "FP32-input MFMA").  Operand layout: lane l supplies A[i = l&15][k = l>>4]
+        // and B[k = l>>4][j = l&15]; step s covers k = 4s .. 4s+3.  lat_desp / rol_desp hold every descriptor with its 96 values
+        // permuted as [g][s] = des[4s + g], so the 24 values lane group g needs are contiguous (six 16-byte loads).
         {
-            float a[kDes];
-            const float4* ap = reinterpret_cast<const float4*>(lat_des + (size_t)(l0 + (lane < nL ? lane : 0)) * kDes);
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int li = lane & 15, lg = lane >> 4;
+            const int n_it = (nL + 15) >> 4, n_jt = (nR + 15) >> 4;
+            for (int jt = wave; jt < n_jt; jt += kWaves) {
+                const int jr = min(jt * 16 + li, nR - 1);
+                float bf[24];
+                const float4* bp = reinterpret_cast<const float4*>(rol_desp + (size_t)(r0 + jr) * kDes + lg * 24);
 #pragma unroll
-            for (int k4 = 0; k4 < kDes / 4; ++k4) { const float4 v = ap[k4]; a[4 * k4] = v.x; a[4 * k4 + 1] = v.y; a[4 * k4 + 2] = v.z; a[4 * k4 + 3] = v.w; }
-            for (int j = wave; j < nR; j += kWaves) {
-                const float* __restrict__ b = rol_des + (size_t)(r0 + j) * kDes;       // wave-uniform address: scalar loads
-                float acc = 0.0f;
+                for (int v = 0; v < 6; ++v) { const float4 x = bp[v]; bf[4 * v] = x.x; bf[4 * v + 1] = x.y; bf[4 * v + 2] = x.z; bf[4 * v + 3] = x.w; }
+                for (int it = 0; it < n_it; ++it) {
+                    const int ir = min(it * 16 + li, nL - 1);
+                    float af[24];
+                    const float4* ap = reinterpret_cast<const float4*>(lat_desp + (size_t)(l0 + ir) * kDes + lg * 24);
 #pragma unroll
-                for (int k = 0; k < kDes; ++k) acc = fmaf(a[k], b[k], acc);
-                if (acc < 0) acc = 0;
-                if (lane < nL) sm.simi[lane * nR + j] = acc;
+                    for (int v = 0; v < 6; ++v) { const float4 x = ap[v]; af[4 * v] = x.x; af[4 * v + 1] = x.y; af[4 * v + 2] = x.z; af[4 * v + 3] = x.w; }
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < 24; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], bf[st], acc, 0, 0, 0);
+                    const int j = jt * 16 + li;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                      // D: col = lane & 15, row = (lane >> 4) * 4 + r
+                        const int i = it * 16 + lg * 4 + r;
+                        float v = acc[r]; if (v < 0) v = 0;
+                        if (i < nL && j < nR) sm.simi[i * nR + j] = v;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -439,7 +458,7 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
     }
     if (!force_generic) {
         const int gridf = (int)(n_tasks < 8192 ? n_tasks : 8192);
-        hipLaunchKernelGGL(k_minu_cands_fast, dim3(gridf), dim3(kThreads), 0, stream, q, g, q.lm_des, g.minu_des, cands, cand_n);
+        hipLaunchKernelGGL(k_minu_cands_fast, dim3(gridf), dim3(kThreads), 0, stream, q, g, q.lm_desp, g.minu_desp, cands, cand_n);
         if (max_nL <= kFastL && max_nR <= kFastR) return hipGetLastError();       // every pair took the fast path
     }
     const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
