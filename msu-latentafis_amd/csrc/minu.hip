@@ -276,6 +276,63 @@ __device__ __forceinline__ u64 wave_kth_largest(const u64 (&c)[U], int K)
 }
 __device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
+// Stage 1 of the top-120 selection for one wave: keys of the elements e = (u*4 + wave)*64 + lane, u < U, are computed into
+// registers; the wave's Kw largest (ties: lowest element index) are written to list[] as 45-bit composites.  Returns Kw.
+template <int U>
+__device__ __forceinline__ int wave_stage1(const FastSmem& sm, u64* list, int n, int nR, int wave, int lane)
+{
+    uint32_t rk[U];                                                      // 32-bit norm keys; the element index is implied by (u, lane)
+    int n_own = 0;
+    {
+        // (i, j) of the lane's first element and the step between consecutive elements (256), without per-element divisions
+        int e = wave * 64 + lane;
+        int i = e / nR, j = e - i * nR;
+        const int si = kThreads / nR, sj = kThreads - si * nR;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t key = 0;                                            // real keys have the top bit set
+            if (e < n) {
+                const float sv = sm.simi[e];
+                float f = sm.rowsum[i] + sm.colsum[j];
+                f = f - sv;
+                key = ord_f32((float)((double)sv / ((double)f + 0.000001)));                    // matcher.cpp:467
+            }
+            rk[u] = key;
+            n_own += wave_popc(e < n);
+            e += kThreads; i += si; j += sj; if (j >= nR) { j -= nR; ++i; }
+        }
+    }
+    const int Kw = n_own < kTopMinu ? n_own : kTopMinu;
+    if (Kw > 0) {
+        // norm lies in [0, 1): every key is in [0x80000000, 0xBF800000), so bit 31 is set and bit 30 clear
+        uint32_t T = 0x80000000u;
+        for (int bit = 29; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) cnt += wave_popc(rk[u] >= cand);
+            if (cnt >= Kw) T = cand;
+        }
+        int n_gt = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) n_gt += wave_popc(rk[u] > T);
+        const int need = Kw - n_gt;                                      // keys equal to T: keep the lowest element indices
+        int base_gt = 0, base_eq = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                                    // (u, lane) ascending = element index ascending
+            const int e = (u * kWaves + wave) * 64 + lane;
+            const bool gt = rk[u] > T, eq = rk[u] == T;
+            const u64 mg = __ballot(gt), me = __ballot(eq);
+            int pos = -1;
+            if (gt) pos = base_gt + lane_prefix(mg);
+            else if (eq) { const int r = base_eq + lane_prefix(me); if (r < need) pos = n_gt + r; }
+            if (pos >= 0) list[pos] = ((u64)rk[u] << 13) | (u64)(8191 - e);
+            base_gt += __popcll(mg); base_eq += __popcll(me);
+        }
+    }
+    return Kw;
+}
+
 __global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
                                                               const float* __restrict__ rol_desp,   // k-permuted descriptor copies
                                                               MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
@@ -302,28 +359,40 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, Galler
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int li = lane & 15, lg = lane >> 4;
             const int n_it = (nL + 15) >> 4, n_jt = (nR + 15) >> 4;
-            for (int jt = wave; jt < n_jt; jt += kWaves) {
+            // work item = (column tile jt, pair of row tiles): the two row tiles are independent accumulator chains (an MFMA needs
+            // 40 cycles before its result can be accumulated into again), and items are dealt round-robin to the four waves
+            const int n_ip = (n_it + 1) >> 1;
+            for (int item = wave; item < n_jt * n_ip; item += kWaves) {
+                const int jt = item / n_ip, it0 = (item - jt * n_ip) * 2;
+                const bool two = it0 + 1 < n_it;
                 const int jr = min(jt * 16 + li, nR - 1);
-                float bf[24];
+                const int ir0 = min(it0 * 16 + li, nL - 1), ir1 = min(it0 * 16 + 16 + li, nL - 1);
                 const float4* bp = reinterpret_cast<const float4*>(rol_desp + (size_t)(r0 + jr) * kDes + lg * 24);
+                const float4* ap0 = reinterpret_cast<const float4*>(lat_desp + (size_t)(l0 + ir0) * kDes + lg * 24);
+                const float4* ap1 = reinterpret_cast<const float4*>(lat_desp + (size_t)(l0 + ir1) * kDes + lg * 24);
+                float bf[24], af0[24], af1[24];
 #pragma unroll
-                for (int v = 0; v < 6; ++v) { const float4 x = bp[v]; bf[4 * v] = x.x; bf[4 * v + 1] = x.y; bf[4 * v + 2] = x.z; bf[4 * v + 3] = x.w; }
-                for (int it = 0; it < n_it; ++it) {
-                    const int ir = min(it * 16 + li, nL - 1);
-                    float af[24];
-                    const float4* ap = reinterpret_cast<const float4*>(lat_desp + (size_t)(l0 + ir) * kDes + lg * 24);
+                for (int v = 0; v < 6; ++v) {
+                    const float4 x = bp[v], y = ap0[v], z = ap1[v];
+                    bf[4 * v] = x.x; bf[4 * v + 1] = x.y; bf[4 * v + 2] = x.z; bf[4 * v + 3] = x.w;
+                    af0[4 * v] = y.x; af0[4 * v + 1] = y.y; af0[4 * v + 2] = y.z; af0[4 * v + 3] = y.w;
+                    af1[4 * v] = z.x; af1[4 * v + 1] = z.y; af1[4 * v + 2] = z.z; af1[4 * v + 3] = z.w;
+                }
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int v = 0; v < 6; ++v) { const float4 x = ap[v]; af[4 * v] = x.x; af[4 * v + 1] = x.y; af[4 * v + 2] = x.z; af[4 * v + 3] = x.w; }
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int st = 0; st < 24; ++st) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[st], bf[st], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[st], bf[st], acc1, 0, 0, 0);
+                }
+                const int j = jt * 16 + li;
 #pragma unroll
-                    for (int st = 0; st < 24; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], bf[st], acc, 0, 0, 0);
-                    const int j = jt * 16 + li;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {                      // D: col = lane & 15, row = (lane >> 4) * 4 + r
-                        const int i = it * 16 + lg * 4 + r;
-                        float v = acc[r]; if (v < 0) v = 0;
-                        if (i < nL && j < nR) sm.simi[i * nR + j] = v;
-                    }
+                for (int r = 0; r < 4; ++r) {                          // D: col = lane & 15, row = (lane >> 4) * 4 + r
+                    const int i0 = it0 * 16 + lg * 4 + r, i1 = i0 + 16;
+                    float v0 = acc0[r], v1 = acc1[r];
+                    if (v0 < 0) v0 = 0;
+                    if (v1 < 0) v1 = 0;
+                    if (i0 < nL && j < nR) sm.simi[i0 * nR + j] = v0;
+                    if (two && i1 < nL && j < nR) sm.simi[i1 * nR + j] = v1;
                 }
             }
         }
@@ -346,55 +415,12 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, Galler
         PHASE(17);
         // ---- S3 (:461-488) stage 1: element e = (u*4 + wave)*64 + lane belongs to this wave ----
         const int topN = n < kTopMinu ? n : kTopMinu;
-        uint32_t rk[kFastU];                                                 // 32-bit norm keys; the element index is implied by (u, lane)
-        int n_own = 0;
-        {
-            // (i, j) of the lane's first element and the step between consecutive elements (256), without per-element divisions
-            int e = wave * 64 + lane;
-            int i = e / nR, j = e - i * nR;
-            const int si = kThreads / nR, sj = kThreads - si * nR;
-#pragma unroll
-            for (int u = 0; u < kFastU; ++u) {
-                uint32_t key = 0;                                            // real keys have the top bit set
-                if (e < n) {
-                    const float sv = sm.simi[e];
-                    float f = sm.rowsum[i] + sm.colsum[j];
-                    f = f - sv;
-                    key = ord_f32((float)((double)sv / ((double)f + 0.000001)));                    // :467
-                }
-                rk[u] = key;
-                n_own += wave_popc(e < n);
-                e += kThreads; i += si; j += sj; if (j >= nR) { j -= nR; ++i; }
-            }
-        }
+        // number of key slots per lane actually needed: 8 (n <= 2048), 16 (n <= 4096) or 32
+        int Kw;
+        if (n <= 8 * kThreads) Kw = wave_stage1<8>(sm, sm.list + wave * kTopMinu, n, nR, wave, lane);
+        else if (n <= 16 * kThreads) Kw = wave_stage1<16>(sm, sm.list + wave * kTopMinu, n, nR, wave, lane);
+        else Kw = wave_stage1<kFastU>(sm, sm.list + wave * kTopMinu, n, nR, wave, lane);
         PHASE(18);
-        const int Kw = n_own < kTopMinu ? n_own : kTopMinu;
-        if (Kw > 0) {
-            uint32_t T = 0x80000000u;
-            for (int bit = 30; bit >= 0; --bit) {
-                const uint32_t cand = T | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int u = 0; u < kFastU; ++u) cnt += wave_popc(rk[u] >= cand);
-                if (cnt >= Kw) T = cand;
-            }
-            int n_gt = 0;
-#pragma unroll
-            for (int u = 0; u < kFastU; ++u) n_gt += wave_popc(rk[u] > T);
-            const int need = Kw - n_gt;                                      // keys equal to T: keep the lowest element indices
-            int base_gt = 0, base_eq = 0;
-#pragma unroll
-            for (int u = 0; u < kFastU; ++u) {                               // (u, lane) ascending = element index ascending
-                const int e = (u * kWaves + wave) * 64 + lane;
-                const bool gt = rk[u] > T, eq = rk[u] == T;
-                const u64 mg = __ballot(gt), me = __ballot(eq);
-                int pos = -1;
-                if (gt) pos = base_gt + lane_prefix(mg);
-                else if (eq) { const int r = base_eq + lane_prefix(me); if (r < need) pos = n_gt + r; }
-                if (pos >= 0) sm.list[wave * kTopMinu + pos] = ((u64)rk[u] << 13) | (u64)(8191 - e);
-                base_gt += __popcll(mg); base_eq += __popcll(me);
-            }
-        }
         if (lane == 0) sm.counts[wave] = Kw;
         __syncthreads();
         PHASE(19);
@@ -413,11 +439,39 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, Galler
                 for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.list[w * kTopMinu + p - off[w]];
                 d[v] = key;
             }
-            const u64 T = wave_kth_largest<V>(d, topN);
+            // topN largest composites = norm key descending, element index ascending.  Threshold search on the 32-bit keys;
+            // among the keys equal to the threshold the lowest element indices win (second, 13-bit search, only when needed).
+            uint32_t hk[V], he[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { hk[v] = (uint32_t)(d[v] >> 13); he[v] = 8191u - (uint32_t)(d[v] & 8191); }
+            uint32_t T = 0x80000000u;
+            for (int bit = 29; bit >= 0; --bit) {
+                const uint32_t cand = T | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int v = 0; v < V; ++v) cnt += wave_popc(hk[v] >= cand);
+                if (cnt >= topN) T = cand;
+            }
+            int n_gt = 0, n_eq = 0;
+#pragma unroll
+            for (int v = 0; v < V; ++v) { n_gt += wave_popc(hk[v] > T); n_eq += wave_popc(hk[v] == T); }
+            const int need = topN - n_gt;
+            uint32_t Emax = 0xffffffffu;
+            if (n_eq != need) {
+                uint32_t X = 0;                                       // largest X with count(eq && e < X) < need
+                for (int bit = 12; bit >= 0; --bit) {
+                    const uint32_t cand = X | (1u << bit);
+                    int cnt = 0;
+#pragma unroll
+                    for (int v = 0; v < V; ++v) cnt += wave_popc(hk[v] == T && he[v] < cand);
+                    if (cnt < need) X = cand;
+                }
+                Emax = X;
+            }
             int base = 0;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                const bool take = d[v] >= T && d[v] != 0;
+                const bool take = hk[v] > T || (hk[v] == T && he[v] <= Emax);
                 const u64 m = __ballot(take);
                 if (take) sm.top[base + lane_prefix(m)] = d[v];
                 base += __popcll(m);
