@@ -256,6 +256,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, Galle
                                                                int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
 {
     __shared__ float4 s_lut[kTileFloats / 4];                 // 128 KB
+    __shared__ int s_next;                                    // next unclaimed gallery template of the chunk
     const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
     const int tile = seq % q.n_tiles;
     const int chunk_id = (seq / q.n_tiles) * 8 + xcd;
@@ -267,12 +268,11 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, Galle
     {
         const float4* src = reinterpret_cast<const float4*>(lut_tiles + (size_t)tile * kTileFloats);
         for (int i = threadIdx.x; i < kTileFloats / 4; i += kAdcThreads) s_lut[i] = src[i];
+        if (threadIdx.x == 0) s_next = 0;
     }
     __syncthreads();
 
-    constexpr int kAdcWaves = kAdcThreads / 64;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g_lo = chunk_id * chunk;
     const int g_hi = min(g.G, g_lo + chunk);
 
@@ -289,7 +289,12 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, Galle
     const float keep0 = late ? 1.0f : 0.0f;                    // step j = 0 restarts the chains of the on-time lanes
     const float keep2 = late ? 0.0f : 1.0f;                    // step j = 2 restarts the chains of the late lanes
 
-    for (int gi = g_lo + wave; gi < g_hi; gi += kAdcWaves) {
+    // templates differ in size (600..1000 points): waves claim them one at a time, so no wave idles at the end of the chunk
+    for (;;) {
+        int claimed = 0;
+        if (lane == 0) claimed = atomicAdd(&s_next, 1);
+        const int gi = g_lo + __builtin_amdgcn_readfirstlane(claimed);
+        if (gi >= g_hi) break;
         const int p0 = g.tex_off[gi], n_pts = g.tex_off[gi + 1] - p0;
         if (n_pts <= 0) continue;
         const int n_blocks = (n_pts + 63) >> 6;
@@ -320,57 +325,50 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, Galle
         // one extra (drain) block lets the late lanes finish the last point; its steps 2,3 run on zero codes and are never consumed
         uint4 cw_next = make_uint4(0, 0, 0, 0);
         if (lane < n_pts) cw_next = g.tex_codes_cf[p0 + lane];
-#if defined(ADC_ABLATE) && ADC_ABLATE == 4
-        for (int blk = 0; blk < 0; ++blk) {
-#elif defined(ADC_ABLATE) && ADC_ABLATE == 5
-        for (int blk = 0; blk <= n_blocks; blk += 4) {
-#else
         for (int blk = 0; blk <= n_blocks; ++blk) {
-#endif
             const int p = blk * 64 + lane;
             const bool have = blk < n_blocks && p < n_pts;
             const uint4 cw = cw_next;
             cw_next = make_uint4(0, 0, 0, 0);
             if (blk + 1 < n_blocks && p + 64 < n_pts) cw_next = g.tex_codes_cf[p0 + p + 64];      // prefetch the next block's codes
             const uint32_t w[4] = {late ? old0 : cw.x, late ? old1 : cw.y, cw.z, cw.w};
-            // all 32 look-ups of the block are issued before the first accumulate
-            float4 v[4][4][2];
+            // look-ups are issued kGroup steps (kGroup x 8 ds_read_b128) ahead of their accumulates: the whole block for the
+            // 512-thread build (256 VGPRs per lane), one step for the 1024-thread build (128 VGPRs, four waves per SIMD hide the rest)
+            constexpr int kGroup = kAdcThreads >= 1024 ? 1 : 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int jg = 0; jg < 4; jg += kGroup) {
+                float4 v[kGroup][4][2];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t code = __builtin_amdgcn_ubfe(w[j], 8 * c, 8);
-                    const uint32_t a0 = (code << 9) + (uint32_t)so[c][j >> 1];          // v_lshl_add_u32
-                    const uint32_t a1 = a0 ^ 32u;                                        // the other row quad: slot bit 1
-                    const char* lb = reinterpret_cast<const char*>(s_lut) + (j & 1) * 256;   // folds into the ds_read offset field
-                    v[j][c][0] = *reinterpret_cast<const float4*>(lb + a0);
-                    v[j][c][1] = *reinterpret_cast<const float4*>(lb + a1);
-                }
+                for (int jj = 0; jj < kGroup; ++jj)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float keep = j == 0 ? keep0 : keep2;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const float4 x = v[j][c][r];
-#if defined(ADC_ABLATE) && ADC_ABLATE == 2
-                        asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
-                        continue;
-#endif
-                        if (j == 0 || j == 2) {                // steps that restart the chains of one half of the lanes
-                            P[c][r][0] = fmaf(P[c][r][0], keep, -x.x); P[c][r][1] = fmaf(P[c][r][1], keep, -x.y);
-                            P[c][r][2] = fmaf(P[c][r][2], keep, -x.z); P[c][r][3] = fmaf(P[c][r][3], keep, -x.w);
-                        } else {
-                            P[c][r][0] -= x.x; P[c][r][1] -= x.y; P[c][r][2] -= x.z; P[c][r][3] -= x.w;
-                        }
+                    for (int c = 0; c < 4; ++c) {
+                        const int j = jg + jj;
+                        const uint32_t code = __builtin_amdgcn_ubfe(w[j], 8 * c, 8);
+                        const uint32_t a0 = (code << 9) + (uint32_t)so[c][j >> 1];          // v_lshl_add_u32
+                        const uint32_t a1 = a0 ^ 32u;                                        // the other row quad: slot bit 1
+                        const char* lb = reinterpret_cast<const char*>(s_lut) + (j & 1) * 256;   // folds into the ds_read offset field
+                        v[jj][c][0] = *reinterpret_cast<const float4*>(lb + a0);
+                        v[jj][c][1] = *reinterpret_cast<const float4*>(lb + a1);
                     }
-#if !defined(ADC_ABLATE) || ADC_ABLATE != 1
-                if (j == 1) consume(late && blk > 0 && p - 64 < n_pts, p - 64);   // the late lanes have just finished the previous block's point
-                if (j == 3) consume(!late && have, p);
-#else
-                if (j == 3 && blk == n_blocks) consume(true, p);
-#endif
+#pragma unroll
+                for (int jj = 0; jj < kGroup; ++jj) {
+                    const int j = jg + jj;
+                    const float keep = j == 0 ? keep0 : keep2;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const float4 x = v[jj][c][r];
+                            if (j == 0 || j == 2) {            // steps that restart the chains of one half of the lanes
+                                P[c][r][0] = fmaf(P[c][r][0], keep, -x.x); P[c][r][1] = fmaf(P[c][r][1], keep, -x.y);
+                                P[c][r][2] = fmaf(P[c][r][2], keep, -x.z); P[c][r][3] = fmaf(P[c][r][3], keep, -x.w);
+                            } else {
+                                P[c][r][0] -= x.x; P[c][r][1] -= x.y; P[c][r][2] -= x.z; P[c][r][3] -= x.w;
+                            }
+                        }
+                    if (j == 1) consume(late && blk > 0 && p - 64 < n_pts, p - 64);   // the late lanes have just finished the previous block's point
+                    if (j == 3) consume(!late && have, p);
+                }
             }
             old0 = cw.x; old1 = cw.y;
         }

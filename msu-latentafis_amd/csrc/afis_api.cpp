@@ -77,7 +77,7 @@ struct afis_ctx {
     std::vector<float> h_scores, h_parts;
     int adc_variant = 5;
     int query_batch = 8;
-    int chunk = 128;
+    int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     int64_t rowmax_budget_bytes = 24ll << 30;
     afis_timing timing = {};
@@ -459,7 +459,9 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
-            HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), ctx->chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+            // larger chunks amortise the 128 KB LUT tile load; smaller ones keep enough workgroups in flight on a small gallery
+            const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32));
+            HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
@@ -544,7 +546,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     const std::string n(name);
     if (n == "adc_variant") { if (value < 0 || value > 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..5"); ctx->adc_variant = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
-    else if (n == "chunk") { if (value < 1 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 1..65536"); ctx->chunk = (int)value; }
+    else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
@@ -599,7 +601,7 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_val.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_arg.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
         HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, ctx->stream));
-        HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
+        HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk > 0 ? ctx->chunk : 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(val, ctx->rm_val.as<float>() + (size_t)gidx * d.lt_pad, (size_t)n_lt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(arg, ctx->rm_arg.as<int32_t>() + (size_t)gidx * d.lt_pad, (size_t)n_lt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

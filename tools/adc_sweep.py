@@ -7,7 +7,7 @@ lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb); S.plant_mate
 m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0); qh = m.upload_queries(lats)
 ref = None
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3]
-for variant, chunk in itertools.product(variants, (32, 64, 128)):
+for variant, chunk in itertools.product(variants, (128, 256, 512)):
     m.set_option("adc_variant", variant); m.set_option("chunk", chunk)
     m.search_resident(qh); r = m.search_resident(qh, want_scores=True); tm = m.timing()
     if ref is None: ref = r["scores"]
