@@ -69,16 +69,22 @@ def main():
     ap.add_argument("--query-batch", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="test mode: every rank uses GPU 0 (validates the N>1 path on a 1-GPU box)")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = 0 if a.share_gpu else local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local)
+        torch.cuda.set_device(gpu)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+        else:
+            dist.init_process_group(a.backend)
+    dev = torch.device("cuda", gpu) if a.backend == "nccl" else torch.device("cpu")
 
     with open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb") as f:
         cb_bytes = f.read()
@@ -95,7 +101,7 @@ def main():
     planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
     t_gen = time.perf_counter() - t_gen
 
-    m = M.Matcher(cb_bytes, device=local)
+    m = M.Matcher(cb_bytes, device=gpu)
     if a.variant >= 0: m.set_option("adc_variant", a.variant)
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)
@@ -150,7 +156,7 @@ def main():
         lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "adc_hbm_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and world == 1 and G == 100000 and Q == 100:      # measured for the default workload only
             try:
                 traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
             except Exception:

@@ -267,3 +267,36 @@ def test_cli_matches_oracle(codebook_bytes, cb, oracle, small, tmp_path):
     assert "Match Results" in out.stdout and "Rank     Filename      Score" in out.stdout
     scores = [float(l.rsplit(",", 1)[1]) for l in lines[1:]]
     assert scores == sorted(scores, reverse=True) and scores[-1] == -1.0
+
+
+def test_edge_shapes_against_oracle(codebook_bytes, cb, oracle):
+    """Shapes off the fast paths: > 64 latent / > 128 rolled minutiae (generic candidate kernel), texture templates above the
+    1000-point clamp (matcher.cpp:544-547), tiny templates (fewer than 120 / 200 candidates), duplicated points (ties)."""
+    rng = np.random.default_rng(42)
+    big = S.make_latent(rng, n_tex_lo=1100, n_tex_hi=1200, n_minu_lo=90, n_minu_hi=110)        # texture > 1000 rows, minutiae > 64
+    tiny = S.make_latent(rng, n_tex_lo=40, n_tex_hi=60, n_minu_lo=3, n_minu_hi=6)
+    dup = S.make_latent(rng, n_tex_lo=230, n_tex_hi=260)
+    t0 = dup.tex[0]
+    t0.x[50:100] = t0.x[0:50]; t0.y[50:100] = t0.y[0:50]; t0.des[50:100] = t0.des[0:50]; t0.ori[50:100] = t0.ori[0:50]   # exact duplicates
+    lats = [big, tiny, dup]
+    gal = []
+    for L in lats:
+        gal.append(S.make_mate(rng, cb, L, frac=0.8, n_minu=min(300, max(8, len(L._pool[0]) * 3)), n_tex=1300 if L is big else 500))
+        gal.append(S.make_mate(rng, cb, L, frac=0.4, n_minu=150, n_tex=700))
+    gal.append(S.make_rolled(rng, cb, n_minu=5, n_tex=30))
+    gal.append(S.make_rolled(rng, cb, n_minu=260, n_tex=1900))
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add(gal); m.gallery_commit(0)
+    res = m.search(lats, k=0, want_parts=True)
+    ocb = oracle.codebook(codebook_bytes)
+    hr = [oracle.rolled(T.write_rolled(g))[0] for g in gal]
+    worst = 0.0
+    for qi, L in enumerate(lats):
+        hl, _ = oracle.latent(ocb, T.write_latent(L))
+        rc, sc, parts = oracle.search(ocb, hl, hr, tie_mode=1, want_parts=True)
+        got = np.concatenate([res["parts"][qi], res["scores"][qi][:, None]], axis=1)
+        err = np.abs(got - parts) / np.maximum(1.0, np.abs(parts))
+        worst = max(worst, float(err.max()))
+        assert err.max() <= 1e-3, (qi, np.argwhere(err > 1e-3), got[err > 1e-3], parts[err > 1e-3])
+    assert res["scores"][0, 0] > 100 and res["scores"][2, 4] > 50
+    print("edge shapes: max rel err", worst)
