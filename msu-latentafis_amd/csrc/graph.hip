@@ -7,7 +7,8 @@
 //
 // Why one wave per list: the work is a chain of short, partly serial phases (sorts, a greedy clique selection, sequential
 // float sums).  A 64-lane workgroup needs no barriers, never has idle waves, and at ~20 KB of LDS eight of them fit on a CU,
-// which is what hides the LDS / transcendental latency of each chain.  Lane l owns rows l, l+64, ... of the list.
+// which is what hides the LDS / transcendental latency of each chain (a wave issues at most one VALU instruction per ~8 cycles on
+// this chip; a SIMD needs >= 4 resident waves to stay busy).  Lane l owns rows l, l+64, ... of the list.
 //
 // Every float reduction keeps the reference's sequential order (index ascending, product and sum rounded separately; the
 // file is compiled with -ffp-contract=off); where the reference's order is Eigen's (unpinned) the canonical order of
@@ -55,13 +56,13 @@ struct __attribute__((aligned(16))) WaveSmem {
     float sim[NMAX];
     short li[NMAX], ri[NMAX];
     int2 xy[NMAX];                         // .x = lx | ly << 16 (latent point), .y = rx | ry << 16 (rolled point)
-    float lo[NMAX], ro[NMAX];
     uint32_t hb[NMAX][W];                  // bit rows: non-zero pattern of H (distance stage), then the boolean H of the angle stage
+    // LDS is what limits how many lists a CU works on at once, so buffers with disjoint lifetimes share storage:
     union {
-        float stash[CACHE * NMAX];         // [n][t]: value of the n-th non-zero of row t (distance stage)
-        struct { float tval[NMAX]; short te[NMAX], targ[NMAX]; } pick;   // texture rows picked by S7, before they are ranked
+        float stash[CACHE * NMAX];                                                  // power iterations: [n][t] = value of the n-th non-zero of row t
+        struct { u64 keys[N4]; float lo[NMAX], ro[NMAX]; } s;                       // sorts (after the iterations); orientations (angle stage only)
+        struct { u64 keys[N4]; float tval[NMAX]; short te[NMAX], targ[NMAX]; } pick;   // texture rows picked by S7, before they are ranked
     } x;
-    u64 keys[N4];
     short order[NMAX];                     // rank -> candidate index
     short sel[NMAX];
     int nsel;
@@ -91,10 +92,10 @@ __device__ __forceinline__ void sort_scores(SM& sm, int num)
     for (int u = 0; u < SM::U; ++u) {
         const int t = lane + 64 * u;
         mine[u] = t < num ? g_make_key(sm.b[t], t) : 0ull;
-        if (t < num) sm.keys[t] = mine[u];
+        if (t < num) sm.x.s.keys[t] = mine[u];
     }
     WSYNC();
-    rank_keys<SM::U>(sm.keys, num, mine, r);
+    rank_keys<SM::U>(sm.x.s.keys, num, mine, r);
 #pragma unroll
     for (int u = 0; u < SM::U; ++u) { const int t = lane + 64 * u; if (t < num) sm.order[r[u]] = (short)t; }
     WSYNC();
@@ -153,17 +154,17 @@ template <class SM>
 __device__ void compact(SM& sm, int n)
 {
     const int lane = threadIdx.x;
-    float sim[SM::U], lo[SM::U], ro[SM::U]; short li[SM::U], ri[SM::U]; int2 xy[SM::U];
+    float sim[SM::U]; short li[SM::U], ri[SM::U]; int2 xy[SM::U];
 #pragma unroll
     for (int u = 0; u < SM::U; ++u) {
         const int t = lane + 64 * u;
-        if (t < n) { const int s = sm.sel[t]; sim[u] = sm.sim[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; lo[u] = sm.lo[s]; ro[u] = sm.ro[s]; }
+        if (t < n) { const int s = sm.sel[t]; sim[u] = sm.sim[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; }
     }
     WSYNC();
 #pragma unroll
     for (int u = 0; u < SM::U; ++u) {
         const int t = lane + 64 * u;
-        if (t < n) { sm.sim[t] = sim[u]; sm.li[t] = li[u]; sm.ri[t] = ri[u]; sm.xy[t] = xy[u]; sm.lo[t] = lo[u]; sm.ro[t] = ro[u]; }
+        if (t < n) { sm.sim[t] = sim[u]; sm.li[t] = li[u]; sm.ri[t] = ri[u]; sm.xy[t] = xy[u]; }
     }
     WSYNC();
 }
@@ -335,12 +336,15 @@ __device__ __forceinline__ bool angle_compatible(const Pt& p1, float lo1, float 
     return true;
 }
 
-// S9, matcher.cpp:1471-1636.  Returns the number of survivors (compacted in place).
+// S9, matcher.cpp:1471-1636.  Returns the number of survivors (compacted in place).  lori / rori: orientation arrays of the
+// latent and rolled template (global memory), indexed by the correspondences' point indices; only the survivors of the distance
+// stage need them.
 template <class SM>
-__device__ int angle_filter(SM& sm, int num)
+__device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori)
 {
     constexpr int W = SM::W;
     const int lane = threadIdx.x;
+    for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
     for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
     const float s0 = (float)(1.0 / num);                                   // :1558
     for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.cc[t] = 0.0f; }
@@ -353,7 +357,7 @@ __device__ int angle_filter(SM& sm, int num)
             if (d == half && even && t >= half) continue;
             int k = t + d; if (k >= num) k -= num;
             const int i = t < k ? t : k, j = t < k ? k : t;
-            if (angle_compatible(unpack_xy(sm.xy[i]), sm.lo[i], sm.ro[i], unpack_xy(sm.xy[j]), sm.lo[j], sm.ro[j])) {
+            if (angle_compatible(unpack_xy(sm.xy[i]), sm.x.s.lo[i], sm.x.s.ro[i], unpack_xy(sm.xy[j]), sm.x.s.lo[j], sm.x.s.ro[j])) {
                 atomicOr(&sm.hb[i][j >> 5], 1u << (j & 31));
                 atomicOr(&sm.hb[j][i >> 5], 1u << (i & 31));
             }
@@ -383,11 +387,12 @@ __device__ int angle_filter(SM& sm, int num)
 
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
 template <class SM, bool LOOKUP, int ITERS>
-__device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table)
+__device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
+                                             const float* __restrict__ rori)
 {
     num = dist_filter<SM, LOOKUP, ITERS>(sm, num, table);
     if (num < 2) return 0.0f;
-    num = angle_filter(sm, num);
+    num = angle_filter(sm, num, lori, rori);
     float score = 0.0f;                                                    // :508-514 / :775-781
     for (int i = 0; i < num; ++i) score += sm.sim[i];
     return score;
@@ -396,7 +401,7 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
 // =====================================================================================================================
 // texture lists: S7 (top-200 rows of the ADC row maxima) + S8b + S9
 // =====================================================================================================================
-typedef WaveSmem<kTopTex, 8> TexSmem;
+typedef WaveSmem<kTopTex, 4> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
 
 __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
                 if (gt) pos = base_gt + g_lane_prefix(mg);
                 else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
                 if (pos >= 0) {
-                    sm.keys[pos] = g_make_key(v[u], e);
+                    sm.x.pick.keys[pos] = g_make_key(v[u], e);
                     sm.x.pick.tval[pos] = v[u]; sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)rm_arg[o + e];
                 }
                 base_gt += __popcll(mg); base_eq += __popcll(me);
@@ -453,8 +458,8 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             num = kTopTex;
             u64 mine[TexSmem::U]; int r[TexSmem::U];
 #pragma unroll
-            for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? sm.keys[t] : 0ull; }
-            rank_keys<TexSmem::U>(sm.keys, num, mine, r);
+            for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? sm.x.pick.keys[t] : 0ull; }
+            rank_keys<TexSmem::U>(sm.x.pick.keys, num, mine, r);
 #pragma unroll
             for (int u = 0; u < TexSmem::U; ++u) {
                 const int t = lane + 64 * u;
@@ -469,10 +474,9 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             const int a = sm.li[t], b = sm.ri[t];
             const short2 lp = q.lt_xy[l0 + a], rp = g.tex_xy[r0 + b];
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
-            sm.lo[t] = q.lt_ori[l0 + a]; sm.ro[t] = g.tex_ori[r0 + b];
         }
         WSYNC();
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist);   // :759, :767
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0);   // :759, :767
         if (lane == 0) *out = score;
         WSYNC();
     }
@@ -491,7 +495,7 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // =====================================================================================================================
 // minutiae lists (produced by k_minu_cands, already in rank order): S8a + S9
 // =====================================================================================================================
-typedef WaveSmem<kTopMinu, 12> MinuGraphSmem;
+typedef WaveSmem<kTopMinu, 6> MinuGraphSmem;
 
 __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
                                                        const int32_t* __restrict__ cand_n, float* __restrict__ parts)
@@ -514,10 +518,9 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
             sm.sim[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
             const short2 lp = q.lm_xy[l0 + cd.li], rp = g.minu_xy[r0 + cd.ri];
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
-            sm.lo[t] = q.lm_ori[l0 + cd.li]; sm.ro[t] = g.minu_ori[r0 + cd.ri];
         }
         WSYNC();
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr);   // :492, :495
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0);   // :492, :495
         if (lane == 0) *out = score;
         WSYNC();
     }
