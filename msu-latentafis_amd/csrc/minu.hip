@@ -333,7 +333,7 @@ __device__ __forceinline__ int wave_stage1(const FastSmem& sm, u64* list, int n,
     return Kw;
 }
 
-__global__ __launch_bounds__(kThreads) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
+__global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
                                                               const float* __restrict__ rol_desp,   // k-permuted descriptor copies
                                                               MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
 {
