@@ -135,7 +135,8 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q);
 
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
 /* Tunables: "adc_variant" (0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups,
- * 4 = conflict-free lane classes, 5 = 4 with 1024-thread workgroups [default]; all bit-identical), "query_batch" (latents per
+ * 4 = conflict-free lane classes, 5 = 4 with 1024-thread workgroups, 6/7 = 4/5 with one-instruction addressing, VCC-based
+ * first-maximum update and a transposed wave reduction [7 = default]; all bit-identical), "query_batch" (latents per
  * launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel),
  * "rowmax_budget_mb".  Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);

@@ -22,6 +22,8 @@ namespace afis {
 //   variant 1 : (((mg*256 + k)*4 + c)*2 + rq)*4 + r4   with m = 4*mg + c   (chain-major: bank slot depends on (c,rq))
 //   variant 4 : ((k*2 + (mg&1))*16 + c*4 + rq*2 + (mg>>1))*4 + r4   — the 16-byte bank slot (float4 index mod 16) is
 //               (chain c, row-quad rq, mg>>1); the entry of m = 0 holds lut - 6 (see k_adc_rowmax_cf)
+//   variant 6 : ((mg&1)*4096 + k*16 + c*4 + rq*2 + (mg>>1))*4 + r4   — same bank slots; the byte address is
+//               (mg&1) << 16 | code << 8 | slot << 4, i.e. one v_perm_b32 of the code word (see k_adc_rowmax_cf2)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lut_entry(const float* __restrict__ des6, const float* __restrict__ cw6)
 {
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(256) void k_lut_build(QueryDev q, const float* __re
     if (variant >= 4) {
         const int mg = m >> 2, c = m & 3;
         const float six = m == 0 ? 6.0f : 0.0f;                 // -(l0 - 6) == 6 - l0 exactly
-        const int e = (k * 2 + (mg & 1)) * 16 + c * 4 + (mg >> 1);
+        const int e = variant >= 6 ? (mg & 1) * 4096 + k * 16 + c * 4 + (mg >> 1)
+                                   : (k * 2 + (mg & 1)) * 16 + c * 4 + (mg >> 1);
         t4[e + 0] = make_float4(v[0] - six, v[1] - six, v[2] - six, v[3] - six);
         t4[e + 2] = make_float4(v[4] - six, v[5] - six, v[6] - six, v[7] - six);
     } else if ((variant & 1) == 0) {
@@ -393,6 +396,194 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, Galle
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Variants 6/7: the conflict-free scheme of variants 4/5 on a VALU diet (the loop is VALU-issue bound: packed adds cost
+// 5.0 cycles per SIMD, 4-byte encodings 2.8, VOP3 encodings 4.3 — tools/ubench).
+//   * LUT byte address = (mg&1) << 16 | code << 8 | slot << 4 is assembled by ONE v_perm_b32 from the packed code word and a
+//     per-lane constant (byte 0 = slot << 4, byte 3 = 1); the other row quad is a0 ^ 32.
+//   * the running first maximum is updated under the EXEC mask of the lanes that have just finished a point, so the compare
+//     writes VCC and the two selects use the short encoding.
+//   * the per-template reduction over the 64 lanes is TRANSPOSED: at the first three butterfly stages a lane keeps half of its
+//     rows and hands the other half to its partner (8 -> 4 -> 2 -> 1 rows), so 11 exchanges replace 48; stages within a row of
+//     16 lanes are DPP moves (quad_perm, row_ror), only the last two cross 16-lane rows through ds_bpermute.  Stage one needs
+//     no selects because partner lanes (pr = lane & 1) already hold their row quads in swapped slots.
+//   The reduction is over the total order (value descending, point index ascending), so its result does not depend on the tree.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) { return __int_as_float(dpp_i<CTRL>(__float_as_int(x))); }
+typedef float v2f __attribute__((ext_vector_type(2)));
+// if (s > best) { best = s; idx = p; } as compare-to-VCC + two short-encoded selects (the compiler's choice, compares into SGPR
+// pairs + VOP3 selects, costs 4.3 + 2 x 4.3 issue cycles per row instead of 3 x 2.8)
+__device__ __forceinline__ void first_max_update(float& best, int& idx, float s, int p)
+{
+    asm("v_cmp_gt_f32 vcc, %2, %0\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc"
+        : "+v"(best), "+v"(idx) : "v"(s), "v"(p) : "vcc");
+}
+__device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
+{
+    const bool take = (ov > v) | ((ov == v) & (oi < i));
+    v = take ? ov : v;
+    i = take ? oi : i;
+}
+
+template <int kAdcThreads>
+__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf2(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
+                                                                int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
+{
+    __shared__ float4 s_lut[kTileFloats / 4];                 // 128 KB
+    __shared__ int s_next;                                    // next unclaimed gallery template of the chunk
+    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
+    const int tile = seq % q.n_tiles;
+    const int chunk_id = (seq / q.n_tiles) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
+    int qi = 0;
+    while (qi + 1 < q.nq && tile >= q.tile_off[qi + 1]) ++qi;
+    const int row0 = (tile - q.tile_off[qi]) * kTileRows;
+    const int n_lt = q.lt_off[qi + 1] - q.lt_off[qi];
+    {
+        const float4* src = reinterpret_cast<const float4*>(lut_tiles + (size_t)tile * kTileFloats);
+        for (int i = threadIdx.x; i < kTileFloats / 4; i += kAdcThreads) s_lut[i] = src[i];
+        if (threadIdx.x == 0) s_next = 0;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int g_lo = chunk_id * chunk;
+    const int g_hi = min(g.G, g_lo + chunk);
+
+    const int a = lane & 15, pr = a & 1, pc = (a >> 1) & 3, pm = a >> 3;
+    const bool late = pm != 0;
+    uint32_t so[4][2];                                         // byte 0: slot << 4 of (physical chain slot c, half hi), byte 3: 1
+    {
+        const int perm[4] = {0, 2, 1, 3};                      // physical order (d1,d3,d2,d4): (P0+P2)+(P1+P3) is rotation-invariant
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) so[c][hi] = 0x01000000u | (uint32_t)((perm[(c + pc) & 3] * 4 + pr * 2 + (hi ^ pm)) * 16);
+    }
+    const float keep0 = late ? 1.0f : 0.0f;                    // step j = 0 restarts the chains of the on-time lanes
+    const float keep2 = late ? 0.0f : 1.0f;                    // step j = 2 restarts the chains of the late lanes
+    const char* lut_b = reinterpret_cast<const char*>(s_lut);
+
+    for (;;) {
+        int claimed = 0;
+        if (lane == 0) claimed = atomicAdd(&s_next, 1);
+        const int gi = g_lo + __builtin_amdgcn_readfirstlane(claimed);
+        if (gi >= g_hi) break;
+        const int p0 = g.tex_off[gi], n_pts = g.tex_off[gi + 1] - p0;
+        if (n_pts <= 0) continue;
+        const int n_blocks = (n_pts + 63) >> 6;
+        float best[kTileRows]; int bidx[kTileRows];
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; }
+        v2f P[4][2][2];                                        // [physical chain][row-quad slot][row pair]: explicit packed fp32
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) P[c][r][i] = v2f{0.0f, 0.0f};
+        uint32_t old0 = 0, old1 = 0;
+
+        auto consume = [&](bool valid, int p) {                // (d1+d2)+(d3+d4), matcher.cpp:592, then the running first maximum
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const v2f sres = (P[0][r][i] + P[2][r][i]) + (P[1][r][i] + P[3][r][i]);
+                        first_max_update(best[r * 4 + 2 * i], bidx[r * 4 + 2 * i], sres.x, p);
+                        first_max_update(best[r * 4 + 2 * i + 1], bidx[r * 4 + 2 * i + 1], sres.y, p);
+                    }
+            }
+        };
+
+        uint4 cw_next = make_uint4(0, 0, 0, 0);
+        if (lane < n_pts) cw_next = g.tex_codes_cf[p0 + lane];
+        for (int blk = 0; blk <= n_blocks; ++blk) {            // one extra (drain) block lets the late lanes finish the last point
+            const int p = blk * 64 + lane;
+            const bool have = blk < n_blocks && p < n_pts;
+            const uint4 cw = cw_next;
+            cw_next = make_uint4(0, 0, 0, 0);
+            if (blk + 1 < n_blocks && p + 64 < n_pts) cw_next = g.tex_codes_cf[p0 + p + 64];      // prefetch the next block's codes
+            const uint32_t w[4] = {late ? old0 : cw.x, late ? old1 : cw.y, cw.z, cw.w};
+            constexpr int kGroup = kAdcThreads >= 1024 ? 1 : 4;
+#pragma unroll
+            for (int jg = 0; jg < 4; jg += kGroup) {
+                float4 v[kGroup][4][2];
+#pragma unroll
+                for (int jj = 0; jj < kGroup; ++jj)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int j = jg + jj;
+                        // bytes of the address: [slot << 4 (so byte 0)] [code (w byte c)] [(j&1) ? 1 (so byte 3) : 0] [0]
+                        const uint32_t sel = 0x0c000004u | (uint32_t)(c << 8) | ((j & 1) ? 0x00070000u : 0x000c0000u);
+                        const uint32_t a0 = __builtin_amdgcn_perm(so[c][j >> 1], w[j], sel);
+                        const uint32_t a1 = a0 ^ 32u;                                        // the other row quad: slot bit 1
+                        v[jj][c][0] = *reinterpret_cast<const float4*>(lut_b + a0);
+                        v[jj][c][1] = *reinterpret_cast<const float4*>(lut_b + a1);
+                    }
+#pragma unroll
+                for (int jj = 0; jj < kGroup; ++jj) {
+                    const int j = jg + jj;
+                    const v2f keep = j == 0 ? v2f{keep0, keep0} : v2f{keep2, keep2};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const float4 x = v[jj][c][r];
+                            const v2f lo{x.x, x.y}, hi{x.z, x.w};
+                            if (j == 0 || j == 2) {            // steps that restart the chains of one half of the lanes
+                                P[c][r][0] = __builtin_elementwise_fma(P[c][r][0], keep, -lo);
+                                P[c][r][1] = __builtin_elementwise_fma(P[c][r][1], keep, -hi);
+                            } else {
+                                P[c][r][0] -= lo; P[c][r][1] -= hi;
+                            }
+                        }
+                    if (j == 1) consume(late && blk > 0 && p - 64 < n_pts, p - 64);   // the late lanes have just finished the previous block's point
+                    if (j == 3) consume(!late && have, p);
+                }
+            }
+            old0 = cw.x; old1 = cw.y;
+        }
+
+        // ---- transposed first-maximum reduction over the wave ------------------------------------------------------
+        // physical slot k of a lane holds row (pr ^ (k >> 2)) * 4 + (k & 3)
+        constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
+#pragma unroll
+        for (int k = 0; k < 4; ++k)                            // lane ^ 1 keeps the other row quad in ITS slots 0..3
+            argmax_merge(best[k], bidx[k], dpp_f<kXor1>(best[k + 4]), dpp_i<kXor1>(bidx[k + 4]));
+        const bool b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+        float wv[2]; int wi[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                          // lane ^ 2: keep slots {0,1} (b1 = 0) or {2,3} (b1 = 1)
+            const float sv = b1 ? best[k] : best[k + 2]; const int si = b1 ? bidx[k] : bidx[k + 2];
+            wv[k] = b1 ? best[k + 2] : best[k]; wi[k] = b1 ? bidx[k + 2] : bidx[k];
+            argmax_merge(wv[k], wi[k], dpp_f<kXor2>(sv), dpp_i<kXor2>(si));
+        }
+        float rv; int ri;
+        {                                                      // lanes +-4 in the row of 16 have the other b2: keep w[b2]
+            const float sv = b2 ? wv[0] : wv[1]; const int si = b2 ? wi[0] : wi[1];
+            rv = b2 ? wv[1] : wv[0]; ri = b2 ? wi[1] : wi[0];
+            argmax_merge(rv, ri, dpp_f<kRor4>(sv), dpp_i<kRor4>(si));
+        }
+        argmax_merge(rv, ri, dpp_f<kRor8>(rv), dpp_i<kRor8>(ri));          // lane ^ 8: same row, the other two quads
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(rv, off); const int oi = __shfl_xor(ri, off);
+            argmax_merge(rv, ri, ov, oi);
+        }
+        const int row = row0 + (lane & 1) * 4 + (lane & 2) + ((lane >> 2) & 1);
+        if (lane < kTileRows && row < n_lt) {
+            const size_t o = ((size_t)qi * g.G + gi) * q.lt_pad + row;
+            rm_val[o] = rv;
+            rm_arg[o] = ri;
+        }
+    }
+}
+
 hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
                              float* rm_val, int32_t* rm_arg, hipStream_t stream)
 {
@@ -407,6 +598,8 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
     case 2: hipLaunchKernelGGL((k_adc_rowmax<0, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     case 4: hipLaunchKernelGGL((k_adc_rowmax_cf<512>), dim3((unsigned)blocks), dim3(512), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     case 5: hipLaunchKernelGGL((k_adc_rowmax_cf<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 6: hipLaunchKernelGGL((k_adc_rowmax_cf2<512>), dim3((unsigned)blocks), dim3(512), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 7: hipLaunchKernelGGL((k_adc_rowmax_cf2<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     default: hipLaunchKernelGGL((k_adc_rowmax<1, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     }
     return hipGetLastError();

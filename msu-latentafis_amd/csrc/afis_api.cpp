@@ -75,7 +75,7 @@ struct afis_ctx {
     int64_t total_tex_points = 0;
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n;
     std::vector<float> h_scores, h_parts;
-    int adc_variant = 5;
+    int adc_variant = 7;
     int query_batch = 8;
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
@@ -544,7 +544,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
-    if (n == "adc_variant") { if (value < 0 || value > 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..5"); ctx->adc_variant = (int)value; }
+    if (n == "adc_variant") { if (value < 0 || value > 7) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..7"); ctx->adc_variant = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }

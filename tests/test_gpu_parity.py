@@ -47,7 +47,7 @@ def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 7])
 def test_rowmax_bit_exact(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -68,7 +68,7 @@ def _compare(res, orc_parts, tol=1e-3):
     return got, want, err
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5])
+@pytest.mark.parametrize("variant", [0, 1, 5, 7])
 def test_scores_small(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
