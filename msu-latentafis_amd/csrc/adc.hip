@@ -12,6 +12,7 @@
 // reduction is intra-wave only.  Blocks that share a gallery chunk are consecutive on one XCD (block b runs on
 // XCD b % 8) so the chunk's PQ codes are fetched from HBM once per XCD and re-read from that XCD's L2.
 #include "afis_device.h"
+#include <type_traits>
 
 namespace afis {
 
@@ -23,7 +24,7 @@ namespace afis {
 //   variant 4 : ((k*2 + (mg&1))*16 + c*4 + rq*2 + (mg>>1))*4 + r4   — the 16-byte bank slot (float4 index mod 16) is
 //               (chain c, row-quad rq, mg>>1); the entry of m = 0 holds lut - 6 (see k_adc_rowmax_cf)
 //   variant 6 : ((mg&1)*4096 + k*16 + c*4 + rq*2 + (mg>>1))*4 + r4   — same bank slots; the byte address is
-//               (mg&1) << 16 | code << 8 | slot << 4, i.e. one v_perm_b32 of the code word (see k_adc_rowmax_cf2)
+//               (mg&1) << 16 | code << 8 | slot << 4, i.e. one v_perm_b32 of the code word (see k_adc_rowmax_cf)
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float lut_entry(const float* __restrict__ des6, const float* __restrict__ cw6)
 {
@@ -63,8 +64,7 @@ __global__ __launch_bounds__(256) void k_lut_build(QueryDev q, const float* __re
     if (variant >= 4) {
         const int mg = m >> 2, c = m & 3;
         const float six = m == 0 ? 6.0f : 0.0f;                 // -(l0 - 6) == 6 - l0 exactly
-        const int e = variant >= 6 ? (mg & 1) * 4096 + k * 16 + c * 4 + (mg >> 1)
-                                   : (k * 2 + (mg & 1)) * 16 + c * 4 + (mg >> 1);
+        const int e = (mg & 1) * 4096 + k * 16 + c * 4 + (mg >> 1);
         t4[e + 0] = make_float4(v[0] - six, v[1] - six, v[2] - six, v[3] - six);
         t4[e + 2] = make_float4(v[4] - six, v[5] - six, v[6] - six, v[7] - six);
     } else if ((variant & 1) == 0) {
@@ -242,163 +242,22 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax(QueryDev q, GalleryD
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Conflict-free variant (4).  A ds_read_b128 is serviced 16 lanes at a time, each lane on one of 16 bank slots of 16 bytes.
-// Here the 16 lanes of a group are 16 different CLASSES (a = lane & 15): chain rotation pc (4) x row-quad swap pr (2) x a
-// half-period shift pm (2).  At every read instruction lane class (pc, pr, pm) touches chain perm[(c+pc)&3], row quad r^pr
-// and sub-quantizer group mg = (j + 2*pm) & 3, and the LUT tile stores (chain, row-quad, mg>>1) in the slot index, so the 16
-// lanes of a group always hit 16 distinct slots whatever their PQ codes are: zero bank conflicts by construction.
-//   * lanes with pm = 1 run half a period late: steps j = 0,1 finish the PREVIOUS point (mg = 2,3), steps j = 2,3 start the
-//     current one (mg = 0,1).  Their finished sums are consumed after j = 1, the others' after j = 3.
+// Conflict-free variants (6 = 512 threads, 7 = 1024 threads).  A ds_read_b128 is serviced 16 lanes at a time, each lane on
+// one of 16 bank slots of 16 bytes.  Here the 16 lanes of a group are 16 different CLASSES (a = lane & 15): chain rotation
+// pc (4) x row-quad swap pr (2) x a half-period shift pm (2).  At every read instruction lane class (pc, pr, pm) touches chain
+// perm[(c+pc)&3], row quad r^pr and sub-quantizer group mg = (j + 2*pm) & 3, and the LUT tile stores (chain, row-quad, mg>>1)
+// in the slot index, so the 16 lanes of a group always hit 16 distinct slots whatever their PQ codes are: zero bank conflicts
+// by construction (SQ_LDS_BANK_CONFLICT = 0 in profiles/).
+//   * lanes with pm = 1 run half a period late: steps j = 0,1 finish the PREVIOUS block's point (mg = 2,3), steps j = 2,3 start
+//     the current one (mg = 0,1).  GalleryDev::tex_codes_cf is laid out for exactly this: entry (block k, lane l) holds, for a
+//     late lane, the code words of mg 2,3 of point (k-1)*64+l and of mg 0,1 of point k*64+l, so every lane just reads its entry
+//     (one extra drain block per template, zero padded; no bounds checks, no selects).
 //   * a chain is restarted with x = fma(x, keep, -v), keep = 0 for the lanes that start a point at this step and 1 for the
 //     rest; fma(x, 1, -v) == x - v and fma(x, 0, -v) == 0 - v, and the tile holds l0 - 6 for m = 0, so the first chain
 //     starts at 6 - l0 exactly as matcher.cpp:571-580.  Each chain still sees m = c, c+4, c+8, c+12 in this order.
-//   * the PQ codes are stored pre-permuted per class (GalleryDev::tex_codes_cf), so every byte extraction uses constants.
-// ---------------------------------------------------------------------------------------------------------------
-template <int kAdcThreads>
-__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
-                                                               int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
-{
-    __shared__ float4 s_lut[kTileFloats / 4];                 // 128 KB
-    __shared__ int s_next;                                    // next unclaimed gallery template of the chunk
-    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
-    const int tile = seq % q.n_tiles;
-    const int chunk_id = (seq / q.n_tiles) * 8 + xcd;
-    if (chunk_id >= n_chunks) return;
-    int qi = 0;
-    while (qi + 1 < q.nq && tile >= q.tile_off[qi + 1]) ++qi;
-    const int row0 = (tile - q.tile_off[qi]) * kTileRows;
-    const int n_lt = q.lt_off[qi + 1] - q.lt_off[qi];
-    {
-        const float4* src = reinterpret_cast<const float4*>(lut_tiles + (size_t)tile * kTileFloats);
-        for (int i = threadIdx.x; i < kTileFloats / 4; i += kAdcThreads) s_lut[i] = src[i];
-        if (threadIdx.x == 0) s_next = 0;
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int g_lo = chunk_id * chunk;
-    const int g_hi = min(g.G, g_lo + chunk);
-
-    const int a = lane & 15, pr = a & 1, pc = (a >> 1) & 3, pm = a >> 3;
-    const bool late = pm != 0;
-    int so[4][2];                                              // byte offset of (physical chain slot c, half hi) for row-quad slot 0
-    {
-        const int perm[4] = {0, 2, 1, 3};                      // physical order (d1,d3,d2,d4): (P0+P2)+(P1+P3) is rotation-invariant
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi) so[c][hi] = (perm[(c + pc) & 3] * 4 + pr * 2 + (hi ^ pm)) * 16;   // bytes
-    }
-    const float keep0 = late ? 1.0f : 0.0f;                    // step j = 0 restarts the chains of the on-time lanes
-    const float keep2 = late ? 0.0f : 1.0f;                    // step j = 2 restarts the chains of the late lanes
-
-    // templates differ in size (600..1000 points): waves claim them one at a time, so no wave idles at the end of the chunk
-    for (;;) {
-        int claimed = 0;
-        if (lane == 0) claimed = atomicAdd(&s_next, 1);
-        const int gi = g_lo + __builtin_amdgcn_readfirstlane(claimed);
-        if (gi >= g_hi) break;
-        const int p0 = g.tex_off[gi], n_pts = g.tex_off[gi + 1] - p0;
-        if (n_pts <= 0) continue;
-        const int n_blocks = (n_pts + 63) >> 6;
-        float best[kTileRows]; int bidx[kTileRows];
-#pragma unroll
-        for (int r = 0; r < kTileRows; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; }
-        float P[4][2][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) P[c][r][i] = 0.0f;
-        uint32_t old0 = 0, old1 = 0;
-
-        auto consume = [&](bool valid, int p) {                // (d1+d2)+(d3+d4), matcher.cpp:592, then the running first maximum
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float sres = (P[0][r][i] + P[2][r][i]) + (P[1][r][i] + P[3][r][i]);
-                    const bool take = valid & (sres > best[r * 4 + i]);
-                    best[r * 4 + i] = take ? sres : best[r * 4 + i];
-                    bidx[r * 4 + i] = take ? p : bidx[r * 4 + i];
-                }
-        };
-
-        // one extra (drain) block lets the late lanes finish the last point; its steps 2,3 run on zero codes and are never consumed
-        uint4 cw_next = make_uint4(0, 0, 0, 0);
-        if (lane < n_pts) cw_next = g.tex_codes_cf[p0 + lane];
-        for (int blk = 0; blk <= n_blocks; ++blk) {
-            const int p = blk * 64 + lane;
-            const bool have = blk < n_blocks && p < n_pts;
-            const uint4 cw = cw_next;
-            cw_next = make_uint4(0, 0, 0, 0);
-            if (blk + 1 < n_blocks && p + 64 < n_pts) cw_next = g.tex_codes_cf[p0 + p + 64];      // prefetch the next block's codes
-            const uint32_t w[4] = {late ? old0 : cw.x, late ? old1 : cw.y, cw.z, cw.w};
-            // look-ups are issued kGroup steps (kGroup x 8 ds_read_b128) ahead of their accumulates: the whole block for the
-            // 512-thread build (256 VGPRs per lane), one step for the 1024-thread build (128 VGPRs, four waves per SIMD hide the rest)
-            constexpr int kGroup = kAdcThreads >= 1024 ? 1 : 4;
-#pragma unroll
-            for (int jg = 0; jg < 4; jg += kGroup) {
-                float4 v[kGroup][4][2];
-#pragma unroll
-                for (int jj = 0; jj < kGroup; ++jj)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int j = jg + jj;
-                        const uint32_t code = __builtin_amdgcn_ubfe(w[j], 8 * c, 8);
-                        const uint32_t a0 = (code << 9) + (uint32_t)so[c][j >> 1];          // v_lshl_add_u32
-                        const uint32_t a1 = a0 ^ 32u;                                        // the other row quad: slot bit 1
-                        const char* lb = reinterpret_cast<const char*>(s_lut) + (j & 1) * 256;   // folds into the ds_read offset field
-                        v[jj][c][0] = *reinterpret_cast<const float4*>(lb + a0);
-                        v[jj][c][1] = *reinterpret_cast<const float4*>(lb + a1);
-                    }
-#pragma unroll
-                for (int jj = 0; jj < kGroup; ++jj) {
-                    const int j = jg + jj;
-                    const float keep = j == 0 ? keep0 : keep2;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-#pragma unroll
-                        for (int r = 0; r < 2; ++r) {
-                            const float4 x = v[jj][c][r];
-                            if (j == 0 || j == 2) {            // steps that restart the chains of one half of the lanes
-                                P[c][r][0] = fmaf(P[c][r][0], keep, -x.x); P[c][r][1] = fmaf(P[c][r][1], keep, -x.y);
-                                P[c][r][2] = fmaf(P[c][r][2], keep, -x.z); P[c][r][3] = fmaf(P[c][r][3], keep, -x.w);
-                            } else {
-                                P[c][r][0] -= x.x; P[c][r][1] -= x.y; P[c][r][2] -= x.z; P[c][r][3] -= x.w;
-                            }
-                        }
-                    if (j == 1) consume(late && blk > 0 && p - 64 < n_pts, p - 64);   // the late lanes have just finished the previous block's point
-                    if (j == 3) consume(!late && have, p);
-                }
-            }
-            old0 = cw.x; old1 = cw.y;
-        }
-        if (pr) {                                              // this lane kept rows 4..7 in slots 0..3
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float tv = best[r]; best[r] = best[r + 4]; best[r + 4] = tv;
-                int ti = bidx[r]; bidx[r] = bidx[r + 4]; bidx[r + 4] = ti;
-            }
-        }
-        float outv = 0.f; int outi = 0;
-#pragma unroll
-        for (int r = 0; r < kTileRows; ++r) {
-            wave_argmax(best[r], bidx[r]);
-            if (lane == r) { outv = best[r]; outi = bidx[r]; }
-        }
-        if (lane < kTileRows && row0 + lane < n_lt) {
-            const size_t o = ((size_t)qi * g.G + gi) * q.lt_pad + row0 + lane;
-            rm_val[o] = outv;
-            rm_arg[o] = outi;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Variants 6/7: the conflict-free scheme of variants 4/5 on a VALU diet (the loop is VALU-issue bound: packed adds cost
-// 5.0 cycles per SIMD, 4-byte encodings 2.8, VOP3 encodings 4.3 — tools/ubench).
+//   * the finished sums (d1+d2)+(d3+d4) of the late lanes (after j = 1) and of the on-time lanes (after j = 3) land in the same
+//     registers, so ONE first-maximum update per block serves all 64 lanes.
+// The loop is VALU-issue bound (packed adds cost 5.0 cycles per SIMD, 4-byte encodings 2.8, VOP3 encodings 4.3 — tools/ubench):
 //   * LUT byte address = (mg&1) << 16 | code << 8 | slot << 4 is assembled by ONE v_perm_b32 from the packed code word and a
 //     per-lane constant (byte 0 = slot << 4, byte 3 = 1); the other row quad is a0 ^ 32.
 //   * the running first maximum is updated under the EXEC mask of the lanes that have just finished a point, so the compare
@@ -429,7 +288,7 @@ __device__ __forceinline__ void argmax_merge(float& v, int& i, float ov, int oi)
 }
 
 template <int kAdcThreads>
-__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf2(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
+__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, GalleryDev g, const float* __restrict__ lut_tiles,
                                                                 int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
 {
     __shared__ float4 s_lut[kTileFloats / 4];                 // 128 KB
@@ -466,15 +325,34 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf2(QueryDev q, Gall
     const float keep0 = late ? 1.0f : 0.0f;                    // step j = 0 restarts the chains of the on-time lanes
     const float keep2 = late ? 0.0f : 1.0f;                    // step j = 2 restarts the chains of the late lanes
     const char* lut_b = reinterpret_cast<const char*>(s_lut);
+    const int lane_pt = lane - 64 * pm;
 
-    for (;;) {
-        int claimed = 0;
-        if (lane == 0) claimed = atomicAdd(&s_next, 1);
-        const int gi = g_lo + __builtin_amdgcn_readfirstlane(claimed);
-        if (gi >= g_hi) break;
-        const int p0 = g.tex_off[gi], n_pts = g.tex_off[gi + 1] - p0;
-        if (n_pts <= 0) continue;
-        const int n_blocks = (n_pts + 63) >> 6;
+    // templates differ in size (600..1000 points): waves claim them one at a time, so no wave idles at the end of the chunk.
+    // The claim and the offsets of the NEXT template are fetched while the current one is processed, and its first code entry
+    // during the current one's drain block, so a wave never waits for global memory between templates.
+    auto claim = [&]() -> int {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&s_next, 1);
+        return g_lo + __builtin_amdgcn_readfirstlane(c);
+    };
+    auto stream_of = [&](int gidx, int& n, int& cf_blk) {
+        n = 0; cf_blk = 0;
+        if (gidx < g_hi) { n = g.tex_off[gidx + 1] - g.tex_off[gidx]; cf_blk = g.tex_cf_blk[gidx]; }
+    };
+    int gi = claim(), n_pts, cf_blk;
+    stream_of(gi, n_pts, cf_blk);
+    uint4 cw_next = make_uint4(0, 0, 0, 0);
+    if (n_pts > 0) cw_next = g.tex_codes_cf[(size_t)cf_blk * 64 + lane];
+    while (gi < g_hi) {
+        const int gi_cur = gi, n_blocks = (n_pts + 63) >> 6, n_cur = n_pts;
+        const uint4* cfp = g.tex_codes_cf + ((size_t)cf_blk * 64 + lane);
+        gi = claim();
+        stream_of(gi, n_pts, cf_blk);                          // the next template
+        const uint4* cfp_next = g.tex_codes_cf + ((size_t)cf_blk * 64 + lane);
+        if (n_cur <= 0) {                                      // empty texture template: nothing to write (the scorer never reads it)
+            if (n_pts > 0) cw_next = cfp_next[0];
+            continue;
+        }
         float best[kTileRows]; int bidx[kTileRows];
 #pragma unroll
         for (int r = 0; r < kTileRows; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; }
@@ -485,33 +363,24 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf2(QueryDev q, Gall
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) P[c][r][i] = v2f{0.0f, 0.0f};
-        uint32_t old0 = 0, old1 = 0;
-
-        auto consume = [&](bool valid, int p) {                // (d1+d2)+(d3+d4), matcher.cpp:592, then the running first maximum
-            if (valid) {
+        v2f S[2][2];                                           // finished sums (d1+d2)+(d3+d4), matcher.cpp:592
+        auto sums = [&]() {
 #pragma unroll
-                for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const v2f sres = (P[0][r][i] + P[2][r][i]) + (P[1][r][i] + P[3][r][i]);
-                        first_max_update(best[r * 4 + 2 * i], bidx[r * 4 + 2 * i], sres.x, p);
-                        first_max_update(best[r * 4 + 2 * i + 1], bidx[r * 4 + 2 * i + 1], sres.y, p);
-                    }
-            }
+                for (int i = 0; i < 2; ++i) S[r][i] = (P[0][r][i] + P[2][r][i]) + (P[1][r][i] + P[3][r][i]);
         };
 
-        uint4 cw_next = make_uint4(0, 0, 0, 0);
-        if (lane < n_pts) cw_next = g.tex_codes_cf[p0 + lane];
-        for (int blk = 0; blk <= n_blocks; ++blk) {            // one extra (drain) block lets the late lanes finish the last point
-            const int p = blk * 64 + lane;
-            const bool have = blk < n_blocks && p < n_pts;
+        // one block = 64 points x 8 rows.  kSteps = 4 for a full block; the drain block after the last one runs only the two
+        // steps the late lanes still need (kSteps = 2).
+        auto block = [&](int blk, auto steps_tag, const uint4* prefetch, bool do_prefetch) {
+            constexpr int kSteps = decltype(steps_tag)::value;
             const uint4 cw = cw_next;
-            cw_next = make_uint4(0, 0, 0, 0);
-            if (blk + 1 < n_blocks && p + 64 < n_pts) cw_next = g.tex_codes_cf[p0 + p + 64];      // prefetch the next block's codes
-            const uint32_t w[4] = {late ? old0 : cw.x, late ? old1 : cw.y, cw.z, cw.w};
-            constexpr int kGroup = kAdcThreads >= 1024 ? 1 : 4;
+            if (do_prefetch) cw_next = *prefetch;              // the next block's codes, or the next template's first entry
+            const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+            constexpr int kGroup = kAdcThreads >= 1024 ? 1 : (kSteps < 4 ? kSteps : 4);
 #pragma unroll
-            for (int jg = 0; jg < 4; jg += kGroup) {
+            for (int jg = 0; jg < kSteps; jg += kGroup) {
                 float4 v[kGroup][4][2];
 #pragma unroll
                 for (int jj = 0; jj < kGroup; ++jj)
@@ -542,12 +411,25 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf2(QueryDev q, Gall
                                 P[c][r][0] -= lo; P[c][r][1] -= hi;
                             }
                         }
-                    if (j == 1) consume(late && blk > 0 && p - 64 < n_pts, p - 64);   // the late lanes have just finished the previous block's point
-                    if (j == 3) consume(!late && have, p);
+                    if (j == 1) sums();                          // the late lanes have just finished the previous block's point
+                    if (j == kSteps - 1) {
+                        if (kSteps == 4 && !late) sums();        // the on-time lanes have finished this block's point
+                        const int p = blk * 64 + lane_pt;        // the point each lane has finished: (blk - pm) * 64 + lane
+                        if ((unsigned)p < (unsigned)n_cur) {     // (in the drain block this is false for every on-time lane)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                                for (int i = 0; i < 2; ++i) {
+                                    first_max_update(best[r * 4 + 2 * i], bidx[r * 4 + 2 * i], S[r][i].x, p);
+                                    first_max_update(best[r * 4 + 2 * i + 1], bidx[r * 4 + 2 * i + 1], S[r][i].y, p);
+                                }
+                        }
+                    }
                 }
             }
-            old0 = cw.x; old1 = cw.y;
-        }
+        };
+        for (int blk = 0; blk < n_blocks; ++blk) block(blk, std::integral_constant<int, 4>{}, cfp + (size_t)(blk + 1) * 64, true);
+        block(n_blocks, std::integral_constant<int, 2>{}, cfp_next, n_pts > 0);
 
         // ---- transposed first-maximum reduction over the wave ------------------------------------------------------
         // physical slot k of a lane holds row (pr ^ (k >> 2)) * 4 + (k & 3)
@@ -577,7 +459,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf2(QueryDev q, Gall
         }
         const int row = row0 + (lane & 1) * 4 + (lane & 2) + ((lane >> 2) & 1);
         if (lane < kTileRows && row < n_lt) {
-            const size_t o = ((size_t)qi * g.G + gi) * q.lt_pad + row;
+            const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row;
             rm_val[o] = rv;
             rm_arg[o] = ri;
         }
@@ -596,10 +478,8 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
     case 0: hipLaunchKernelGGL((k_adc_rowmax<0, 512>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     case 1: hipLaunchKernelGGL((k_adc_rowmax<1, 512>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     case 2: hipLaunchKernelGGL((k_adc_rowmax<0, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
-    case 4: hipLaunchKernelGGL((k_adc_rowmax_cf<512>), dim3((unsigned)blocks), dim3(512), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
-    case 5: hipLaunchKernelGGL((k_adc_rowmax_cf<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
-    case 6: hipLaunchKernelGGL((k_adc_rowmax_cf2<512>), dim3((unsigned)blocks), dim3(512), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
-    case 7: hipLaunchKernelGGL((k_adc_rowmax_cf2<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 6: hipLaunchKernelGGL((k_adc_rowmax_cf<512>), dim3((unsigned)blocks), dim3(512), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
+    case 7: hipLaunchKernelGGL((k_adc_rowmax_cf<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     default: hipLaunchKernelGGL((k_adc_rowmax<1, 1024>), dim3((unsigned)blocks), dim3(threads), 0, stream, q, g, lut_tiles, chunk, n_chunks, rm_val, rm_arg); break;
     }
     return hipGetLastError();

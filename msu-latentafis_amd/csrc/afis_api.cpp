@@ -70,7 +70,7 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_desp, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_empty;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_desp, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_empty;
     int max_nR = 0;
     int64_t total_tex_points = 0;
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n;
@@ -159,7 +159,7 @@ std::vector<float> permute_k(const std::vector<float>& in)
 void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_desp.release();
-    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_empty.release();
+    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_empty.release();
 }
 
 }  // namespace
@@ -301,20 +301,36 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_codes, hg.tcodes, ctx->stream));
-    {   // conflict-free ADC layout: point p of a template belongs to lane class a = p & 15 (pc = (a>>1)&3, pm = a>>3);
-        // dword d holds sub-quantizer group mg = (d + 2*pm) & 3, byte c of it holds chain perm[(c + pc) & 3]  (adc.hip)
-        std::vector<uint8_t> cf(hg.tcodes.size());
+    {   // conflict-free ADC stream (adc.hip): template t owns (blocks + 1) x 64 entries of 16 bytes; entry (block k, lane l)
+        // belongs to lane class a = l & 15 (pc = (a>>1)&3, pm = a>>3).  Dword d carries sub-quantizer group mg = (d + 2*pm) & 3,
+        // byte c of it chain perm[(c + pc) & 3]; lanes with pm = 1 run half a period late, so their dwords 0,1 (mg 2,3) come from
+        // point (k-1)*64 + l and their dwords 2,3 (mg 0,1) from point k*64 + l.  Entries without a point are zero.
+        std::vector<int32_t> cfb(G + 1);
+        int64_t nblk = 0;
+        for (int64_t t = 0; t < G; ++t) { cfb[t] = (int32_t)nblk; const int64_t n = hg.tex_off[t + 1] - hg.tex_off[t]; nblk += n > 0 ? (n + 63) / 64 + 1 : 0; }
+        cfb[G] = (int32_t)nblk;
+        if (nblk > 0x7fffffff / 64) return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for the ADC code stream; split the gallery into more shards");
+        std::vector<uint8_t> cf((size_t)nblk * 64 * kM, 0);
         static const int perm[4] = {0, 2, 1, 3};
         for (int64_t t = 0; t < G; ++t) {
-            for (int64_t pt = hg.tex_off[t]; pt < hg.tex_off[t + 1]; ++pt) {
-                const int a = (int)((pt - hg.tex_off[t]) & 15), pc = (a >> 1) & 3, pm = a >> 3;
-                const uint8_t* src = &hg.tcodes[(size_t)pt * kM];
-                uint8_t* dst = &cf[(size_t)pt * kM];
-                for (int d = 0; d < 4; ++d)
-                    for (int c = 0; c < 4; ++c) dst[d * 4 + c] = src[4 * ((d + 2 * pm) & 3) + perm[(c + pc) & 3]];
-            }
+            const int64_t n = hg.tex_off[t + 1] - hg.tex_off[t];
+            if (n <= 0) continue;
+            const int64_t blocks = (n + 63) / 64;
+            for (int64_t k = 0; k <= blocks; ++k)
+                for (int l = 0; l < 64; ++l) {
+                    const int a = l & 15, pc = (a >> 1) & 3, pm = a >> 3;
+                    uint8_t* dst = &cf[((size_t)(cfb[t] + k) * 64 + l) * kM];
+                    for (int d = 0; d < 4; ++d) {
+                        const int mg = (d + 2 * pm) & 3;
+                        const int64_t pt = (pm && d < 2 ? k - 1 : k) * 64 + l;       // the point this dword belongs to
+                        if (pt < 0 || pt >= n) continue;
+                        const uint8_t* src = &hg.tcodes[(size_t)(hg.tex_off[t] + pt) * kM];
+                        for (int c = 0; c < 4; ++c) dst[d * 4 + c] = src[4 * mg + perm[(c + pc) & 3]];
+                    }
+                }
         }
         HIPCHK(ctx, upload(ctx->g_tex_codes_cf, cf, ctx->stream));
+        HIPCHK(ctx, upload(ctx->g_tex_cf_blk, cfb, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
@@ -323,7 +339,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     g.G = (int32_t)G;
     g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
     g.minu_des = ctx->g_minu_des.as<float>(); g.minu_desp = ctx->g_minu_desp.as<float>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
-    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.empty = ctx->g_empty.as<uint8_t>();
+    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
     ctx->max_nR = max_nR;
     ctx->total_tex_points = (int64_t)hg.tx.size();
     ctx->index_base = index_base;
@@ -460,7 +476,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
             // larger chunks amortise the 128 KB LUT tile load; smaller ones keep enough workgroups in flight on a small gallery
-            const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32));
+            const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 65536 ? 512 : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32)));
             HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
@@ -544,7 +560,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
-    if (n == "adc_variant") { if (value < 0 || value > 7) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..7"); ctx->adc_variant = (int)value; }
+    if (n == "adc_variant") { if (value < 0 || value > 7 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6 or 7"); ctx->adc_variant = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }

@@ -29,7 +29,9 @@ struct GalleryDev {
     const short2*  tex_xy = nullptr;     // [NT]   block coords
     const float*   tex_ori = nullptr;    // [NT]
     const uint4*   tex_codes = nullptr;  // [NT]   16 PQ code bytes per point, byte m = sub-quantizer m
-    const uint4*   tex_codes_cf = nullptr;  // [NT] the same bytes permuted per lane class for the conflict-free ADC kernel (adc.hip)
+    const uint4*   tex_codes_cf = nullptr;  // the same bytes as a per-template stream of (blocks + 1) x 64 lane entries, permuted per
+                                            // lane class and half-period shifted for the conflict-free ADC kernel (adc.hip)
+    const int32_t* tex_cf_blk = nullptr;    // [G+1] offset of each template's stream in tex_codes_cf, in 64-entry blocks
     const uint8_t* empty = nullptr;      // [G] 1 = rolled template has neither minutiae nor texture (score -1)
 };
 

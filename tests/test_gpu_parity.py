@@ -47,7 +47,7 @@ def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7])
 def test_rowmax_bit_exact(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -68,7 +68,7 @@ def _compare(res, orc_parts, tol=1e-3):
     return got, want, err
 
 
-@pytest.mark.parametrize("variant", [0, 1, 5, 7])
+@pytest.mark.parametrize("variant", [0, 1, 7])
 def test_scores_small(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -191,11 +191,11 @@ def test_medium_properties_and_sharding(codebook_bytes, cb, oracle, medium):
     assert np.array_equal(fused.astype(np.float32), r1["scores"])
     assert (r1["scores"] >= 0).all()
     # (5) every ADC variant and the generic minutiae candidate kernel give identical bits
-    for v in (0, 1, 4):
+    for v in (0, 1, 6):
         m.set_option("adc_variant", v)
         r0 = m.search(lats, k=0)
         assert np.array_equal(r0["scores"], r1["scores"]), v
-    m.set_option("adc_variant", 5); m.set_option("minu_generic", 1)
+    m.set_option("adc_variant", 7); m.set_option("minu_generic", 1)
     r0 = m.search(lats, k=0)
     assert np.array_equal(r0["scores"], r1["scores"])
     m.set_option("minu_generic", 0)
