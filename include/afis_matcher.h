@@ -133,6 +133,17 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q,
                          int k, int64_t* topk_idx, float* topk_score);
 void afis_queries_free(afis_ctx* ctx, afis_queries* q);
 
+/* Correspondence export — replaces One2One_matching_selected_templates(..., save_corr = true, corr_file) as called for the
+ * top-24 of One2List_matching (matching/matcher.cpp:321-327, :376-417, :497-505).  For one latent and each of the n listed
+ * gallery templates (indices as reported by afis_search, i.e. including index_base) it re-runs the three minutiae scorers and
+ * returns the correspondences that survive both graph filters, in the reference's order (corr3):
+ *   counts[i*3 + s]                 number of survivors for selected latent template s (0 -> 27th, 1 -> 3rd, 2 -> 12th)
+ *   xy[((i*3 + s)*120 + t)*4 + 0..3] latent x, latent y, rolled x, rolled y of survivor t  (one line of <corr_file>_<s>.csv)
+ * counts is -1 where the reference does not run that scorer and writes no file (latent empty, rolled empty or without a
+ * minutiae template, latent without the selected template), and 0 where it writes an empty file. */
+int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const int64_t* gallery_idx, int n,
+                         int32_t* counts /*[n][3]*/, int16_t* xy /*[n][3][120][4]*/);
+
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
 /* Tunables: "adc_variant" (0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups,
  * 4 = conflict-free lane classes, 5 = 4 with 1024-thread workgroups, 6/7 = 4/5 with one-instruction addressing, VCC-based

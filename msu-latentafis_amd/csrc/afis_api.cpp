@@ -354,9 +354,11 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
 int64_t afis_gallery_size(const afis_ctx* ctx) { return ctx ? (int64_t)ctx->hg.empty.size() : 0; }
 
 // ---------------------------------------------------------------------------------------------------------------------
+static const int kSelected[3] = {27 - 1, 3 - 1, 12 - 1};                   // matcher.cpp:380
+
 static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, QueryGroup& grp, std::vector<int32_t>& status_out)
 {
-    static const int sel[3] = {27 - 1, 3 - 1, 12 - 1};                     // matcher.cpp:380
+    const int* sel = kSelected;
     std::vector<int32_t> lm_off{0}, lt_off{0}, tile_off{0}, tex_slot, status;
     std::vector<short2> lm_xy, lt_xy; std::vector<float> lm_ori, lm_des, lt_ori, lt_des;
     int max_nL = 0, lt_max = 0;
@@ -482,7 +484,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
             HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
-            HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), s));
+            HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
@@ -521,6 +523,70 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     }
     ctx->timing = tm;
     return AFIS_OK;
+}
+
+// Correspondence export (matcher.cpp:321-327 calling :376-417 with save_corr = true, :497-505): the minutiae scorers of the
+// three selected latent templates are re-run against each listed gallery template with the kernels' survivor lists switched on.
+int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const int64_t* gallery_idx, int n, int32_t* counts, int16_t* xy)
+{
+    if (!ctx || !query || n < 0 || (n > 0 && (!gallery_idx || !counts || !xy))) return fail(ctx, AFIS_EINVAL, "afis_correspondences: bad argument");
+    if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_correspondences: commit the gallery first");
+    if (n == 0) return AFIS_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const GalleryDev& g = ctx->gal;
+    for (int i = 0; i < n; ++i)
+        if (gallery_idx[i] < ctx->index_base || gallery_idx[i] >= ctx->index_base + g.G) return fail(ctx, AFIS_EINVAL, "afis_correspondences: gallery index outside this shard");
+    QueryGroup grp;
+    std::vector<int32_t> status;
+    int rc = build_group(ctx, query, 1, grp, status);
+    if (rc != AFIS_OK) { grp.release(); return rc; }
+    for (int i = 0; i < n * 3; ++i) counts[i] = -1;
+    memset(xy, 0, (size_t)n * 3 * kTopMinu * 4 * sizeof(int16_t));
+    DevBuf d_xy, d_n;
+    auto body = [&]() -> int {
+        if (status[0] != AFIS_QUERY_OK) return AFIS_OK;                    // matcher.cpp:383-386: nothing is matched, nothing written
+        const size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+        const int n_wg = 64;
+        HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
+        HIPCHK(ctx, ctx->cands.ensure((size_t)n * 3 * kTopMinu * sizeof(MinuCand)));
+        HIPCHK(ctx, ctx->cand_n.ensure((size_t)n * 3 * 4));
+        HIPCHK(ctx, ctx->parts.ensure((size_t)n * 16));
+        HIPCHK(ctx, d_xy.ensure((size_t)n * 3 * kTopMinu * sizeof(short4)));
+        HIPCHK(ctx, d_n.ensure((size_t)n * 3 * 4));
+        hipStream_t s = ctx->stream;
+        int err = AFIS_OK;
+        for (int i = 0; i < n && err == AFIS_OK; ++i) {
+            const int64_t gi = gallery_idx[i] - ctx->index_base;
+            GalleryDev one = g;                                            // a one-template view: offsets are absolute, so only the CSR bases move
+            one.G = 1; one.minu_off += gi; one.tex_off += gi; one.tex_cf_blk += gi; one.empty += gi;
+            MinuCand* cands = ctx->cands.as<MinuCand>() + (size_t)i * 3 * kTopMinu;
+            int32_t* cand_n = ctx->cand_n.as<int32_t>() + (size_t)i * 3;
+            if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, cands, cand_n, s) != hipSuccess ||
+                launch_graph_minutiae(grp.dev, one, cands, cand_n, ctx->parts.as<float>() + (size_t)i * 4,
+                                      d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, s) != hipSuccess)
+                err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: kernel launch failed");
+        }
+        if (err == AFIS_OK) {
+            if (hipMemcpyAsync(xy, d_xy.p, (size_t)n * 3 * kTopMinu * sizeof(short4), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(counts, d_n.p, (size_t)n * 3 * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: copy back failed");
+            // -1 where the reference does not run the scorer at all (no file): rolled empty (:388-391), rolled without a
+            // minutiae template (:399), latent without the selected template (:402-403)
+            for (int i = 0; i < n && err == AFIS_OK; ++i) {
+                const int64_t gi = gallery_idx[i] - ctx->index_base;
+                int32_t off[2] = {0, 0};
+                if (hipMemcpy(off, g.minu_off + gi, sizeof(off), hipMemcpyDeviceToHost) != hipSuccess) { err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: copy back failed"); break; }
+                for (int sl = 0; sl < 3; ++sl)
+                    if (ctx->hg.empty[(size_t)gi] || off[1] - off[0] <= 0 || query->n_minu <= kSelected[sl]) counts[i * 3 + sl] = -1;
+            }
+        } else (void)hipStreamSynchronize(s);
+        return err;
+    };
+    rc = body();
+    d_xy.release(); d_n.release();
+    grp.release();
+    return rc;
 }
 
 int afis_search(afis_ctx* ctx, const afis_template_view* queries, int n_q, float* scores, float* parts, int32_t* status,

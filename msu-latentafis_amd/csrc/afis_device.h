@@ -72,7 +72,7 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
                              int max_nL, int max_nR, int force_generic, MinuCand* cands, int32_t* cand_n, hipStream_t stream);
 // S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
-                                 float* parts, hipStream_t stream);
+                                 float* parts, short4* corr_out, int32_t* corr_n, hipStream_t stream);
 // S10: fusion -> scores[q*G+g]
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 

@@ -388,11 +388,13 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
 template <class SM, bool LOOKUP, int ITERS>
 __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
-                                             const float* __restrict__ rori)
+                                             const float* __restrict__ rori, int& n_survivors)
 {
+    n_survivors = 0;
     num = dist_filter<SM, LOOKUP, ITERS>(sm, num, table);
     if (num < 2) return 0.0f;
     num = angle_filter(sm, num, lori, rori);
+    n_survivors = num;                                                     // sm.sim/li/ri/xy[0..num) = corr3 in the reference's order
     float score = 0.0f;                                                    // :508-514 / :775-781
     for (int i = 0; i < num; ++i) score += sm.sim[i];
     return score;
@@ -476,7 +478,8 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
         }
         WSYNC();
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0);   // :759, :767
+        int n_surv;
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv);   // :759, :767
         if (lane == 0) *out = score;
         WSYNC();
     }
@@ -497,8 +500,10 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // =====================================================================================================================
 typedef WaveSmem<kTopMinu, 6> MinuGraphSmem;
 
+// corr_out / corr_n (optional): the surviving correspondences of every task as (lx, ly, rx, ry), matcher.cpp:497-505
 __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
-                                                       const int32_t* __restrict__ cand_n, float* __restrict__ parts)
+                                                       const int32_t* __restrict__ cand_n, float* __restrict__ parts,
+                                                       short4* __restrict__ corr_out, int32_t* __restrict__ corr_n)
 {
     __shared__ MinuGraphSmem sm;
     const int lane = threadIdx.x;
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         const int qi = qs / 3, s = qs - qi * 3;
         float* out = parts + ((size_t)qi * g.G + gi) * 4 + s;
         const int num = cand_n[task];
-        if (num <= 0) { if (lane == 0) *out = 0.0f; continue; }             // matcher.cpp:400-404
+        if (num <= 0) { if (lane == 0) { *out = 0.0f; if (corr_n) corr_n[task] = 0; } continue; }   // matcher.cpp:400-404
         const int l0 = q.lm_off[qs], r0 = g.minu_off[gi];
         const MinuCand* c = cands + (size_t)task * kTopMinu;
         for (int t = lane; t < num; t += 64) {
@@ -520,19 +525,27 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
         }
         WSYNC();
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0);   // :492, :495
+        int n_surv;
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, n_surv);   // :492, :495
         if (lane == 0) *out = score;
+        if (corr_out) {
+            for (int t = lane; t < n_surv; t += 64) {
+                const Pt p = unpack_xy(sm.xy[t]);
+                corr_out[(size_t)task * kTopMinu + t] = make_short4((short)p.lx, (short)p.ly, (short)p.rx, (short)p.ry);
+            }
+            if (lane == 0) corr_n[task] = n_surv;
+        }
         WSYNC();
     }
 }
 
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
-                                 float* parts, hipStream_t stream)
+                                 float* parts, short4* corr_out, int32_t* corr_n, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
-    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts);
+    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n);
     return hipGetLastError();
 }
 

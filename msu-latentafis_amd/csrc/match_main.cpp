@@ -14,8 +14,9 @@
 //   * the same stdout lines (gallery size, template counts, rank table, total duration).
 // Differences, all deliberate: the gallery is parsed once and kept in HBM instead of being re-read for every pair
 // (matcher.cpp:173/:278); rank ties are broken by ascending gallery index (the reference's std::sort leaves them unspecified,
-// matcher.cpp:306-309); the correspondence CSVs of the top 24 (hard-coded /LatentAFIS/scores/corr..., matcher.cpp:325-327) are
-// not written.
+// matcher.cpp:306-309); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
+// /LatentAFIS/scores/corr<latent>_<rolled>_<i>.csv (matcher.cpp:325-327, :405, :497-505), go to <score dir>/corr<latent>_<rolled>_<i>.csv
+// (or to the prefix given with -corr).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -123,7 +124,7 @@ int main(int argc, char** argv)
 {
     ArgParser args(argc, argv);
     if (args.cmdOptionExists("-h") || args.cmdOptionExists("--help")) {
-        std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>]\n";
+        std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>]\n";
         return 0;
     }
     const auto config = read_flat_json((fs::current_path().parent_path() / "afis.config").string());
@@ -172,8 +173,19 @@ int main(int argc, char** argv)
         std::ofstream out(score_file);
         out << "filename,score" << std::endl;
         std::cout << "Match Results" << std::endl << "----------------" << std::endl << "Rank     Filename      Score" << std::endl;
+        // correspondence files for the top 24 (matcher.cpp:311-328): one "lx,ly,rx,ry" line per surviving correspondence
+        std::vector<int32_t> counts((size_t)k * 3); std::vector<int16_t> xy((size_t)k * 3 * 120 * 4);
+        CHECK(ctx, afis_correspondences(ctx, &L.view, idx.data(), k, counts.data(), xy.data()));
+        const std::string corr_prefix = args.cmdOptionExists("-corr") ? args.getCmdOption("-corr") : score_path + "corr";
         for (int j = 0; j < k; ++j) {
             out << std::to_string(j + 1) << rolled[idx[j]] << "," << sc[j] << std::endl;
+            for (int i = 0; i < 3; ++i) {
+                const int n = counts[(size_t)j * 3 + i];
+                if (n < 0) continue;
+                std::ofstream cf(corr_prefix + latent_file.stem().string() + "_" + rolled[idx[j]].stem().string() + "_" + std::to_string(i) + ".csv");
+                const int16_t* p = &xy[((size_t)j * 3 + i) * 120 * 4];
+                for (int t = 0; t < n; ++t) cf << p[t * 4] << "," << p[t * 4 + 1] << "," << p[t * 4 + 2] << "," << p[t * 4 + 3] << std::endl;
+            }
             std::cout << std::to_string(j + 1) << "        " << rolled[idx[j]].filename() << "       " << sc[j] << std::endl;
         }
         std::cout << "Total matching duration (ms): " << std::chrono::duration<double, std::milli>(clk::now() - t0).count() << std::endl;

@@ -44,7 +44,7 @@ class Timing(C.Structure):
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -66,6 +66,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_search_dat.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, fp, fp, i32p, C.c_int, i64p, fp]
     lib.afis_queries_upload.argtypes = [vp, C.POINTER(TemplateView), C.c_int, C.POINTER(vp)]
     lib.afis_search_resident.argtypes = [vp, vp, fp, fp, i32p, C.c_int, i64p, fp]
+    lib.afis_correspondences.argtypes = [vp, vp, i64p, C.c_int, i32p, C.POINTER(C.c_int16)]
     lib.afis_queries_free.argtypes = [vp, vp]; lib.afis_queries_free.restype = None
     lib.afis_get_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
@@ -207,6 +208,17 @@ class Matcher:
         scores, parts, status, ti, ts, args = self._alloc(n, k, want_scores, want_parts)
         self._chk(self.lib.afis_search_resident(self.ctx, h, *args))
         return {"scores": scores, "parts": parts, "status": status, "topk_idx": ti, "topk_score": ts}
+
+    def correspondences(self, latent: FPTemplate, gallery_idx: Sequence[int]):
+        """Surviving minutiae correspondences (matcher.cpp:497-505) of one latent against each listed gallery template:
+        a list (one entry per gallery index) of three int16 arrays [n_s][4] = (lx, ly, rx, ry), one per selected template
+        (None where the reference does not run that scorer)."""
+        v = _Views([latent])
+        n = len(gallery_idx)
+        gi = np.asarray(gallery_idx, np.int64).reshape(-1)
+        counts = np.zeros((max(n, 1), 3), np.int32); xy = np.zeros((max(n, 1), 3, 120, 4), np.int16)
+        self._chk(self.lib.afis_correspondences(self.ctx, v.arr, _ptr(gi, C.c_int64) if n else None, n, _ptr(counts, C.c_int32), _ptr(xy, C.c_int16)))
+        return [[xy[i, s, :counts[i, s]].copy() if counts[i, s] >= 0 else None for s in range(3)] for i in range(n)]
 
     def free_queries(self, handle):
         self.lib.afis_queries_free(self.ctx, handle[0])

@@ -93,6 +93,34 @@ def test_scores_small(codebook_bytes, cb, oracle, small, variant):
         assert np.array_equal(res["topk_idx"][qi][pos], order[pos])
 
 
+def test_correspondences_match_oracle(codebook_bytes, cb, oracle, small):
+    """Correspondence export (matcher.cpp:497-505): survivors of both graph filters, as coordinates, in the oracle's order."""
+    lats, gal = small
+    m = _matcher(codebook_bytes, gal)
+    ocb = oracle.codebook(codebook_bytes)
+    hl, hr = cases.to_orc(oracle, ocb, lats, gal)
+    sel = (26, 2, 11)
+    n_nonempty = 0
+    for qi, L in enumerate(lats):
+        got = m.correspondences(L, list(range(len(gal))))
+        for gi, R in enumerate(gal):
+            for s in range(3):
+                tr = oracle.trace(ocb, hl[qi], hr[gi], which=s + 1, stage=2, tie_mode=1)
+                if tr is None or not R.minu:
+                    assert got[gi][s] is None
+                    continue
+                _, li, ri = tr
+                lm, rm = L.minu[sel[s]], R.minu[0]
+                want = np.stack([lm.x[li], lm.y[li], rm.x[ri], rm.y[ri]], axis=1).astype(np.int16) if len(li) else np.zeros((0, 4), np.int16)
+                assert np.array_equal(got[gi][s], want), (qi, gi, s)
+                n_nonempty += len(li) > 0
+    assert n_nonempty >= 3, "planted mates must have surviving correspondences"
+    # out-of-shard index is an error, not a silent zero
+    with pytest.raises(M.AfisError):
+        m.correspondences(lats[0], [len(gal)])
+    m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
@@ -267,6 +295,27 @@ def test_cli_matches_oracle(codebook_bytes, cb, oracle, small, tmp_path):
     assert "Match Results" in out.stdout and "Rank     Filename      Score" in out.stdout
     scores = [float(l.rsplit(",", 1)[1]) for l in lines[1:]]
     assert scores == sorted(scores, reverse=True) and scores[-1] == -1.0
+    # correspondence files of the ranked templates (matcher.cpp:321-327, :497-505): <score dir>/corr<latent>_<rolled>_<i>.csv
+    hl, _ = oracle.latent(ocb, T.write_latent(lats[0]))
+    sel = (26, 2, 11)
+    n_lines = 0
+    for line in lines[1:]:
+        path = line.rsplit(",", 1)[0].split('"')[1]
+        stem = os.path.splitext(os.path.basename(path))[0]
+        hr, _ = oracle.rolled(open(path, "rb").read())
+        for i in range(3):
+            f = tmp_path / "out" / f"corrL0_{stem}_{i}.csv"
+            tr = oracle.trace(ocb, hl, hr, which=i + 1, stage=2, tie_mode=1) if os.path.getsize(path) > 10 else None
+            if tr is None:
+                assert not f.exists(), f
+                continue
+            _, li, ri = tr
+            _, R = T.read_rolled(open(path, "rb").read())
+            lm, rm = lats[0].minu[sel[i]], R.minu[0]
+            want = [f"{lm.x[a]},{lm.y[a]},{rm.x[b]},{rm.y[b]}" for a, b in zip(li, ri)]
+            assert f.read_text().splitlines() == want, f
+            n_lines += len(want)
+    assert n_lines > 0
 
 
 def test_edge_shapes_against_oracle(codebook_bytes, cb, oracle):
