@@ -133,6 +133,17 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q,
                          int k, int64_t* topk_idx, float* topk_score);
 void afis_queries_free(afis_ctx* ctx, afis_queries* q);
 
+/* PQ encoder — replaces TrainedPQEncoder.encode_multi (extraction/descriptor_PQ.py:19-27, scipy.cluster.vq.vq per
+ * sub-space): codes[i][m] = index of the codeword of sub-quantizer m nearest (squared L2, fp32, first minimum) to
+ * des[i][6m .. 6m+5].  des: [n][96] fp32, codes: [n][16] u8, host pointers.  afis_gallery_add calls it for rolled texture
+ * views that carry fp32 descriptors (codes == NULL, des_len == 96). */
+int afis_pq_encode(afis_ctx* ctx, const float* des, int64_t n, uint8_t* codes);
+
+/* The rolled branch of descriptor_PQ.py::encode_PQ (:332-349) for one file: `bytes` is a template with fp32 texture
+ * descriptors in the latent on-disk layout (descriptor_PQ.py:80-175); the result is the same template in the rolled layout
+ * (:178-272), texture descriptors replaced by PQ codes.  out == NULL only reports *out_len.  load_rc: the reader's code. */
+int afis_encode_rolled_dat(afis_ctx* ctx, const void* bytes, size_t len, void* out, size_t out_cap, size_t* out_len, int* load_rc);
+
 /* Correspondence export — replaces One2One_matching_selected_templates(..., save_corr = true, corr_file) as called for the
  * top-24 of One2List_matching (matching/matcher.cpp:321-327, :376-417, :497-505).  For one latent and each of the n listed
  * gallery templates (indices as reported by afis_search, i.e. including index_base) it re-runs the three minutiae scorers and

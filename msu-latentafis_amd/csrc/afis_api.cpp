@@ -103,7 +103,8 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
     return e;
 }
 
-void append_entry(HostGallery& hg, const afis_minutiae_view* m, const afis_texture_view* t)
+// t->codes == NULL: `encoded` holds the PQ codes the device made from t->des (afis_gallery_add)
+void append_entry(HostGallery& hg, const afis_minutiae_view* m, const afis_texture_view* t, const uint8_t* encoded = nullptr)
 {
     if (m && m->n > 0) {
         hg.mx.insert(hg.mx.end(), m->x, m->x + m->n); hg.my.insert(hg.my.end(), m->y, m->y + m->n);
@@ -115,7 +116,8 @@ void append_entry(HostGallery& hg, const afis_minutiae_view* m, const afis_textu
         const int n = std::min(t->n, kTexMax);                              // matcher.cpp:546-547
         hg.tx.insert(hg.tx.end(), t->x, t->x + n); hg.ty.insert(hg.ty.end(), t->y, t->y + n);
         hg.tori.insert(hg.tori.end(), t->ori, t->ori + n);
-        hg.tcodes.insert(hg.tcodes.end(), t->codes, t->codes + (size_t)n * kM);
+        const uint8_t* codes = t->codes ? t->codes : encoded;
+        hg.tcodes.insert(hg.tcodes.end(), codes, codes + (size_t)n * kM);
     }
     hg.tex_off.push_back((int64_t)hg.tx.size());
     hg.empty.push_back((!(m && m->n > 0) && !(t && t->n > 0)) ? 1 : 0);
@@ -131,8 +133,9 @@ int check_rolled(afis_ctx* ctx, const afis_template_view& t)
     }
     if (t.n_tex > 0) {
         const afis_texture_view& x = t.tex[0];
-        if (x.n <= 0 || x.n > 2000 || !x.x || !x.y || !x.ori || !x.codes) return fail(ctx, AFIS_EINVAL, "rolled texture template: bad view (n must be 1..2000, codes required)");
-        if (x.des_len != kM) return fail(ctx, AFIS_EINVAL, "rolled texture template: des_len must be 16 (PQ codes)");
+        if (x.n <= 0 || x.n > 2000 || !x.x || !x.y || !x.ori || (!x.codes && !x.des)) return fail(ctx, AFIS_EINVAL, "rolled texture template: bad view (n must be 1..2000, codes or des required)");
+        if (x.codes ? x.des_len != kM : x.des_len != kDes)
+            return fail(ctx, AFIS_EINVAL, "rolled texture template: des_len must be 16 with PQ codes, 96 with fp32 descriptors (encoded on the device)");
     }
     return AFIS_OK;
 }
@@ -226,8 +229,62 @@ int afis_gallery_add(afis_ctx* ctx, const afis_template_view* t, int n)
     if (!ctx || (n > 0 && !t)) return fail(ctx, AFIS_EINVAL, "afis_gallery_add: null argument");
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add: gallery already committed");
     for (int i = 0; i < n; ++i) { int rc = check_rolled(ctx, t[i]); if (rc) return rc; }
-    for (int i = 0; i < n; ++i)
-        append_entry(ctx->hg, t[i].n_minu > 0 ? &t[i].minu[0] : nullptr, t[i].n_tex > 0 ? &t[i].tex[0] : nullptr);
+    std::vector<uint8_t> enc;
+    for (int i = 0; i < n; ++i) {
+        const afis_texture_view* x = t[i].n_tex > 0 ? &t[i].tex[0] : nullptr;
+        if (x && !x->codes) {                                               // fp32 descriptors: PQ-encode on the device
+            enc.resize((size_t)x->n * kM);
+            int rc = afis_pq_encode(ctx, x->des, x->n, enc.data());
+            if (rc != AFIS_OK) return rc;
+        }
+        append_entry(ctx->hg, t[i].n_minu > 0 ? &t[i].minu[0] : nullptr, x, enc.data());
+    }
+    return AFIS_OK;
+}
+
+// PQ encoder: TrainedPQEncoder.encode_multi (extraction/descriptor_PQ.py:19-27) on the device, in slices that fit a fixed
+// staging buffer.
+int afis_pq_encode(afis_ctx* ctx, const float* des, int64_t n, uint8_t* codes)
+{
+    if (!ctx || n < 0 || (n > 0 && (!des || !codes))) return fail(ctx, AFIS_EINVAL, "afis_pq_encode: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t slice = 1 << 20;                                          // 1 Mi points = 384 MiB of descriptors per launch
+    DevBuf d_des, d_codes;
+    int rc = AFIS_OK;
+    for (int64_t i0 = 0; i0 < n && rc == AFIS_OK; i0 += slice) {
+        const int64_t m = std::min(slice, n - i0);
+        if (d_des.ensure((size_t)m * kDes * 4) != hipSuccess || d_codes.ensure((size_t)m * kM) != hipSuccess ||
+            hipMemcpyAsync(d_des.p, des + i0 * kDes, (size_t)m * kDes * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            launch_pq_encode(d_des.as<float>(), m, ctx->codewords.as<float>(), d_codes.as<uint8_t>(), ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(codes + i0 * kM, d_codes.p, (size_t)m * kM, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = fail(ctx, AFIS_EDEVICE, std::string("afis_pq_encode: ") + hipGetErrorString(hipGetLastError()));
+    }
+    d_des.release(); d_codes.release();
+    return rc;
+}
+
+// The rolled branch of descriptor_PQ.py::encode_PQ (:332-349): a template whose texture descriptors are fp32 (the latent
+// on-disk layout, descriptor_PQ.py:80-175) is rewritten in the rolled layout (:178-272) with every texture template's
+// descriptors replaced by their PQ codes.
+int afis_encode_rolled_dat(afis_ctx* ctx, const void* bytes, size_t len, void* out, size_t out_cap, size_t* out_len, int* load_rc)
+{
+    if (!ctx || !out_len || (len > 0 && !bytes)) return fail(ctx, AFIS_EINVAL, "afis_encode_rolled_dat: bad argument");
+    HostTemplate t;
+    const int rc = parse_latent_dat(bytes, len, t);
+    if (load_rc) *load_rc = rc;
+    if (rc < 0) { t.minu.clear(); t.tex.clear(); }
+    for (HostTexture& x : t.tex) {
+        if (x.des_len != kDes) return fail(ctx, AFIS_EINVAL, "afis_encode_rolled_dat: texture descriptors must be 96-d fp32");
+        x.codes.resize((size_t)x.n() * kM);
+        const int e = afis_pq_encode(ctx, x.des.data(), x.n(), x.codes.data());
+        if (e != AFIS_OK) return e;
+        x.des.clear(); x.des_len = kM;
+    }
+    const std::vector<uint8_t> w = write_rolled_dat(t);
+    *out_len = w.size();
+    if (!out || out_cap < w.size()) return out ? fail(ctx, AFIS_EINVAL, "afis_encode_rolled_dat: output buffer too small") : AFIS_OK;
+    memcpy(out, w.data(), w.size());
     return AFIS_OK;
 }
 

@@ -77,6 +77,7 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 
 // optional in-kernel phase timers (build with PHASE_TIMING=1); zeros otherwise
+hipError_t launch_pq_encode(const float* des, long long n, const float* codewords, uint8_t* codes, hipStream_t stream);
 hipError_t read_phase_cycles(unsigned long long* out32, bool reset);
 
 // debug tap: LUT in the reference layout [n][16][256]

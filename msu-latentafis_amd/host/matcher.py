@@ -44,7 +44,7 @@ class Timing(C.Structure):
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -68,6 +68,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_search_resident.argtypes = [vp, vp, fp, fp, i32p, C.c_int, i64p, fp]
     lib.afis_correspondences.argtypes = [vp, vp, i64p, C.c_int, i32p, C.POINTER(C.c_int16)]
     lib.afis_queries_free.argtypes = [vp, vp]; lib.afis_queries_free.restype = None
+    lib.afis_pq_encode.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint8)]
+    lib.afis_encode_rolled_dat.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), i32p]
     lib.afis_get_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.afis_debug_lut.argtypes = [vp, C.POINTER(TemplateView), fp, i32p]
@@ -219,6 +221,21 @@ class Matcher:
         counts = np.zeros((max(n, 1), 3), np.int32); xy = np.zeros((max(n, 1), 3, 120, 4), np.int16)
         self._chk(self.lib.afis_correspondences(self.ctx, v.arr, _ptr(gi, C.c_int64) if n else None, n, _ptr(counts, C.c_int32), _ptr(xy, C.c_int16)))
         return [[xy[i, s, :counts[i, s]].copy() if counts[i, s] >= 0 else None for s in range(3)] for i in range(n)]
+
+    def pq_encode(self, des: np.ndarray) -> np.ndarray:
+        """TrainedPQEncoder.encode_multi (descriptor_PQ.py:19-27) on the device: [n][96] fp32 -> [n][16] u8."""
+        des = np.ascontiguousarray(des, np.float32).reshape(-1, 96)
+        codes = np.zeros((des.shape[0], 16), np.uint8)
+        self._chk(self.lib.afis_pq_encode(self.ctx, _ptr(des, C.c_float), des.shape[0], _ptr(codes, C.c_uint8)))
+        return codes
+
+    def encode_rolled_dat(self, buf: bytes):
+        """A template with fp32 texture descriptors (latent layout) -> (reader rc, the rolled-layout file with PQ codes)."""
+        need = C.c_size_t(0); rc = C.c_int32(0)
+        self._chk(self.lib.afis_encode_rolled_dat(self.ctx, buf, len(buf), None, 0, C.byref(need), C.byref(rc)))
+        out = C.create_string_buffer(max(1, need.value))
+        self._chk(self.lib.afis_encode_rolled_dat(self.ctx, buf, len(buf), out, need.value, C.byref(need), C.byref(rc)))
+        return rc.value, out.raw[:need.value]
 
     def free_queries(self, handle):
         self.lib.afis_queries_free(self.ctx, handle[0])

@@ -623,6 +623,26 @@ void orc_build_lut(void* cb, const float* des, int n, int des_len, float* out)
     memcpy(out, lut.data(), lut.size() * sizeof(float));
 }
 
+// PQ encoder: TrainedPQEncoder.encode_multi, extraction/descriptor_PQ.py:19-27 — per sub-space the index of the
+// nearest codeword, computed by scipy.cluster.vq.vq (third-party, version unpinned by the reference).  Restated as: squared L2
+// in fp32 with the SAME arithmetic as the matcher's own table (include.h:327-359, build_lut above), first minimum on ties — so
+// a point's code is the codeword its own ADC table ranks nearest.  Pinned against scipy 1.15.3's vq (float32 path) run in the
+// build container: tests/golden/golden_pq.npz, 0 differences on 8192 (point, sub-space) cases (tests/test_oracle.py).
+void orc_pq_encode(void* cbp, const float* des, int n, int des_len, unsigned char* codes)
+{
+    const Codebook& cb = *(Codebook*)cbp;
+    std::vector<float> lut;
+    for (int i = 0; i < n; ++i) {
+        build_lut(des + (size_t)i * des_len, 1, des_len, cb, lut);
+        for (int j = 0; j < cb.M; ++j) {
+            const float* row = lut.data() + (size_t)j * cb.K;
+            int best = 0;
+            for (int q = 1; q < cb.K; ++q) if (row[q] < row[best]) best = q;
+            codes[(size_t)i * cb.M + j] = (unsigned char)best;
+        }
+    }
+}
+
 // S10: per-pair scores out[5] = s0,s1,s2,tex,final
 int orc_pair_score(void* cb, void* lat, void* rol, int tie_mode, float* out)
 {

@@ -121,6 +121,58 @@ def test_correspondences_match_oracle(codebook_bytes, cb, oracle, small):
     m.close()
 
 
+def test_pq_encoder_bit_exact(codebook_bytes, cb, oracle, tmp_path):
+    """GPU nearest-codeword encoder vs the scipy golden, the oracle, and through the file / gallery entry points."""
+    import os, subprocess
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_pq.npz"))
+    m = M.Matcher(codebook_bytes)
+    assert np.array_equal(m.pq_encode(g["des"]), g["codes"])                      # scipy.cluster.vq.vq's answers
+    rng = np.random.default_rng(8)
+    ocb = oracle.codebook(codebook_bytes)
+    for n in (1, 63, 64, 65, 5000):                                                 # tile remainders
+        des = rng.standard_normal((n, 96)).astype(np.float32) * rng.choice([0.05, 0.1, 0.3], (n, 1)).astype(np.float32)
+        des[::7, :6] = cb.words[0][3]                                               # exact hits; duplicated codewords would tie -> first
+        assert np.array_equal(m.pq_encode(des), oracle.pq_encode(ocb, des)), n
+    assert m.pq_encode(np.zeros((0, 96), np.float32)).shape == (0, 16)
+    # file entry point: latent-layout template (fp32 texture descriptors) -> rolled-layout template with codes
+    src = S.make_latent(rng, n_tex_lo=300, n_tex_hi=340)
+    src = T.FPTemplate(minu=src.minu[:1], tex=src.tex[:1])
+    rc, out = m.encode_rolled_dat(T.write_latent(src))
+    assert rc == 0
+    rrc, R = T.read_rolled(out)
+    assert rrc == 0 and len(R.minu) == 1 and len(R.tex) == 1
+    assert np.array_equal(R.tex[0].codes, oracle.pq_encode(ocb, src.tex[0].des))
+    assert np.array_equal(R.tex[0].x, src.tex[0].x) and np.array_equal(R.tex[0].ori, src.tex[0].ori)
+    assert np.array_equal(R.minu[0].des, src.minu[0].des)
+    assert oracle.rolled(out)[1] == 0                                               # the oracle's reader accepts the file
+    # gallery entry point: fp32 texture descriptors are encoded at afis_gallery_add; same scores as the pre-encoded template
+    lat = S.make_latent(rng)
+    m2 = M.Matcher(codebook_bytes); m2.gallery_add([R]); m2.gallery_commit(0)
+    m3 = M.Matcher(codebook_bytes); m3.gallery_add([T.FPTemplate(minu=src.minu[:1], tex=src.tex[:1])]); m3.gallery_commit(0)
+    assert np.array_equal(m2.search([lat], k=0)["scores"], m3.search([lat], k=0)["scores"])
+    m2.close(); m3.close(); m.close()
+    # command line (descriptor_PQ.py's arguments): directory in, directory out, digit order, 2-byte file for a template without texture
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "pq_encode")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(M.LIB_PATH), "pq_encode"], check=True)
+    (tmp_path / "in").mkdir(); (tmp_path / "work").mkdir()
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    (tmp_path / "in" / "r10.dat").write_bytes(T.write_latent(src))
+    (tmp_path / "in" / "r9.dat").write_bytes(T.write_latent(T.FPTemplate(minu=src.minu[:1], tex=[])))
+    out = subprocess.run([exe, "--fprint_type", "rolled", "--input_dir", str(tmp_path / "in") + "/", "--output_dir", str(tmp_path / "enc") + "/", "-c", str(cbp)],
+                         capture_output=True, text=True, cwd=tmp_path / "work")
+    assert out.returncode == 0, out.stderr
+    pq_lines = [l for l in out.stdout.splitlines() if l.startswith("PQ: ")]
+    assert [os.path.basename(l) for l in pq_lines] == ["r9.dat", "r10.dat"]         # sorted by the digits, not lexicographically
+    assert (tmp_path / "enc" / "r9.dat").read_bytes() == b"\x00\x00"
+    rrc2, R2 = T.read_rolled((tmp_path / "enc" / "r10.dat").read_bytes())
+    assert rrc2 == 0 and np.array_equal(R2.tex[0].codes, R.tex[0].codes)
+    out = subprocess.run([exe, "--fprint_type", "rolled", "--input_file", "x.dat", "--output_dir", str(tmp_path / "enc") + "/"], capture_output=True, text=True, cwd=tmp_path / "work")
+    assert "Single template PQ is not available for rolled prints" in out.stdout
+    out = subprocess.run([exe, "--fprint_type", "rolled"], capture_output=True, text=True, cwd=tmp_path / "work")
+    assert "Missing args." in out.stdout
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)

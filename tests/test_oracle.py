@@ -149,3 +149,19 @@ def test_zero_minutiae_templates_are_dropped_and_indices_shift(oracle, codebook_
     assert rc == 0 and oracle.counts(h) == (28, 1)
     rc2, t = T.read_latent(T.write_latent(holey))
     assert rc2 == 0 and len(t.minu) == 28
+
+
+def test_pq_encoder_pinned_to_scipy_golden(oracle, codebook_bytes, templates_mod):
+    """the oracle's encoder against codes produced by scipy.cluster.vq.vq — the routine the reference's
+    TrainedPQEncoder.encode_multi calls (descriptor_PQ.py:25-26) — on the reference's codebook (tests/golden/make_golden_pq.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_pq.npz"))
+    ocb = oracle.codebook(codebook_bytes)
+    cb = templates_mod.Codebook.from_bytes(codebook_bytes)
+    got = oracle.pq_encode(ocb, g["des"])
+    assert np.array_equal(got, g["codes"])
+    # rows 0..63 are exact codewords (distance 0): decoding the codes gives them back
+    dec = np.concatenate([cb.words[m][got[:64, m]] for m in range(16)], axis=1)
+    assert np.array_equal(dec, g["des"][:64])
+    # the host-side numpy helper used by the synthetic generator agrees as well
+    assert np.array_equal(cb.encode(g["des"]), g["codes"])
