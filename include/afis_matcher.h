@@ -133,6 +133,20 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q,
                          int k, int64_t* topk_idx, float* topk_score);
 void afis_queries_free(afis_ctx* ctx, afis_queries* q);
 
+/* Packed gallery container (no reference counterpart: the reference re-parses every rolled .dat for every pair,
+ * matching/matcher.cpp:173,:278).  One mmap-able file holding the staged gallery's SoA arrays (layout: csrc/template_io.h), so a
+ * 100k-1M template gallery is loaded — whole, or one contiguous shard per GPU — without touching 100k-1M small files.
+ * afis_gallery_save   writes the templates staged so far (before afis_gallery_commit); names[i] (optional) = the path template
+ *                     i was read from, kept for the score files.
+ * afis_gallery_load   appends templates [first, first+count) of the file (count < 0: to the end) to the staged gallery.
+ * afis_gallery_file_info  template / point totals, and (optional) the texture point count of every template, the quantity shards
+ *                     are balanced by.
+ * afis_gallery_file_names  the names of a range as consecutive NUL-terminated strings; buf == NULL only reports *need. */
+int afis_gallery_save(afis_ctx* ctx, const char* path, const char* const* names);
+int afis_gallery_load(afis_ctx* ctx, const char* path, int64_t first, int64_t count);
+int afis_gallery_file_info(const char* path, int64_t* G, int64_t* n_minutiae, int64_t* n_tex_points, int32_t* tex_counts /*[G] or NULL*/);
+int afis_gallery_file_names(const char* path, int64_t first, int64_t count, char* buf, size_t cap, size_t* need);
+
 /* PQ encoder — replaces TrainedPQEncoder.encode_multi (extraction/descriptor_PQ.py:19-27, scipy.cluster.vq.vq per
  * sub-space): codes[i][m] = index of the codeword of sub-quantizer m nearest (squared L2, fp32, first minimum) to
  * des[i][6m .. 6m+5].  des: [n][96] fp32, codes: [n][16] u8, host pointers.  afis_gallery_add calls it for rolled texture

@@ -33,14 +33,6 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-struct HostGallery {
-    std::vector<int64_t> minu_off{0}, tex_off{0};
-    std::vector<int16_t> mx, my, tx, ty;
-    std::vector<float> mori, mdes, tori;
-    std::vector<uint8_t> tcodes;
-    std::vector<uint8_t> empty;
-    int64_t size() const { return (int64_t)empty.size(); }
-};
 
 }  // namespace
 
@@ -330,6 +322,73 @@ int afis_gallery_add_packed(afis_ctx* ctx, int64_t n, const int64_t* minu_off, c
         hg.empty.push_back((minu_off[i + 1] == minu_off[i] && nt == 0) ? 1 : 0);
     }
     (void)t0;
+    return AFIS_OK;
+}
+
+// ---- packed gallery container (layout in template_io.h) ---------------------------------------------------
+int afis_gallery_save(afis_ctx* ctx, const char* path, const char* const* names)
+{
+    if (!ctx || !path) return fail(ctx, AFIS_EINVAL, "afis_gallery_save: null argument");
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_save: the host staging copy is released at commit; save before afis_gallery_commit");
+    std::vector<std::string> nm;
+    if (names) for (int64_t i = 0; i < ctx->hg.size(); ++i) nm.emplace_back(names[i] ? names[i] : "");
+    std::string err;
+    if (!write_gallery_container(path, ctx->hg, nm, err)) return fail(ctx, AFIS_EFORMAT, "afis_gallery_save: " + err);
+    return AFIS_OK;
+}
+
+int afis_gallery_load(afis_ctx* ctx, const char* path, int64_t first, int64_t count)
+{
+    if (!ctx || !path) return fail(ctx, AFIS_EINVAL, "afis_gallery_load: null argument");
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_load: gallery already committed");
+    std::string err;
+    HostGallery add;                                                       // parsed aside so a bad file leaves the staged gallery untouched
+    if (!read_gallery_container(path, first, count, add, nullptr, nullptr, err)) return fail(ctx, AFIS_EFORMAT, "afis_gallery_load: " + err);
+    const int64_t n = add.size();
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t nm = add.minu_off[i + 1] - add.minu_off[i], nt = add.tex_off[i + 1] - add.tex_off[i];
+        if (nm > 2000 || nt > kTexMax || (add.empty[i] != 0) != (nm == 0 && nt == 0)) return fail(ctx, AFIS_EFORMAT, "afis_gallery_load: template counts out of range");
+    }
+    HostGallery& hg = ctx->hg;
+    const int64_t mb = hg.minu_off.back(), tb = hg.tex_off.back();
+    hg.mx.insert(hg.mx.end(), add.mx.begin(), add.mx.end()); hg.my.insert(hg.my.end(), add.my.begin(), add.my.end());
+    hg.mori.insert(hg.mori.end(), add.mori.begin(), add.mori.end()); hg.mdes.insert(hg.mdes.end(), add.mdes.begin(), add.mdes.end());
+    hg.tx.insert(hg.tx.end(), add.tx.begin(), add.tx.end()); hg.ty.insert(hg.ty.end(), add.ty.begin(), add.ty.end());
+    hg.tori.insert(hg.tori.end(), add.tori.begin(), add.tori.end()); hg.tcodes.insert(hg.tcodes.end(), add.tcodes.begin(), add.tcodes.end());
+    for (int64_t i = 0; i < n; ++i) { hg.minu_off.push_back(mb + add.minu_off[i + 1]); hg.tex_off.push_back(tb + add.tex_off[i + 1]); hg.empty.push_back(add.empty[i]); }
+    return AFIS_OK;
+}
+
+int afis_gallery_file_info(const char* path, int64_t* G, int64_t* n_minutiae, int64_t* n_tex_points, int32_t* tex_counts)
+{
+    if (!path) return fail(nullptr, AFIS_EINVAL, "afis_gallery_file_info: null argument");
+    std::string err;
+    GalleryFileInfo info;
+    if (!gallery_container_info(path, info, err)) return fail(nullptr, AFIS_EFORMAT, "afis_gallery_file_info: " + err);
+    if (G) *G = info.G;
+    if (n_minutiae) *n_minutiae = info.n_minu;
+    if (n_tex_points) *n_tex_points = info.n_tex;
+    if (tex_counts) {
+        HostGallery none; std::vector<int32_t> tc;
+        if (!read_gallery_container(path, 0, 0, none, nullptr, &tc, err)) return fail(nullptr, AFIS_EFORMAT, "afis_gallery_file_info: " + err);
+        memcpy(tex_counts, tc.data(), tc.size() * sizeof(int32_t));
+    }
+    return AFIS_OK;
+}
+
+int afis_gallery_file_names(const char* path, int64_t first, int64_t count, char* buf, size_t cap, size_t* need)
+{
+    if (!path || !need) return fail(nullptr, AFIS_EINVAL, "afis_gallery_file_names: null argument");
+    std::string err;
+    HostGallery none; std::vector<std::string> names;
+    if (!read_gallery_container(path, first, count, none, &names, nullptr, err)) return fail(nullptr, AFIS_EFORMAT, "afis_gallery_file_names: " + err);
+    size_t total = 0;
+    for (const std::string& n : names) total += n.size() + 1;
+    *need = total;
+    if (!buf) return AFIS_OK;
+    if (cap < total) return fail(nullptr, AFIS_EINVAL, "afis_gallery_file_names: buffer too small");
+    char* w = buf;
+    for (const std::string& n : names) { memcpy(w, n.c_str(), n.size() + 1); w += n.size() + 1; }
     return AFIS_OK;
 }
 

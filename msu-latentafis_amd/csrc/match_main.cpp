@@ -17,6 +17,8 @@
 // matcher.cpp:306-309); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
 // /LatentAFIS/scores/corr<latent>_<rolled>_<i>.csv (matcher.cpp:325-327, :405, :497-505), go to <score dir>/corr<latent>_<rolled>_<i>.csv
 // (or to the prefix given with -corr).
+// Additions: -g may name a packed gallery container (one file, include/afis_matcher.h: afis_gallery_load) instead of a directory;
+// -pack <file> writes the gallery given by -g as such a container (alone: pack and exit).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -106,13 +108,37 @@ struct Latent {
 
 #define CHECK(ctx, call) do { int rc_ = (call); if (rc_ != AFIS_OK) { std::cerr << "match: " #call " failed (" << rc_ << "): " << afis_last_error(ctx) << std::endl; return 2; } } while (0)
 
-int load_gallery(afis_ctx* ctx, const std::vector<fs::path>& files)
+// -g is either the reference's directory of rolled .dat files or ONE packed gallery container (afis_gallery_save); the container
+// carries the paths the templates came from, so the score files read the same either way.
+std::vector<fs::path> list_gallery(const std::string& g)
 {
-    std::vector<uint8_t> b;
-    for (const fs::path& f : files) {
-        read_file(f.string(), b);
-        int load_rc = 0;
-        CHECK(ctx, afis_gallery_add_dat(ctx, b.data(), b.size(), &load_rc));
+    if (!fs::is_regular_file(fs::path(g))) return list_dat(g);
+    std::vector<fs::path> files;
+    size_t need = 0;
+    if (afis_gallery_file_names(g.c_str(), 0, -1, nullptr, 0, &need) != AFIS_OK) { std::cerr << "match: " << afis_last_error(nullptr) << std::endl; return files; }
+    std::vector<char> buf(need + 1);
+    if (afis_gallery_file_names(g.c_str(), 0, -1, buf.data(), need, &need) != AFIS_OK) return files;
+    for (size_t at = 0; at < need; at += strlen(&buf[at]) + 1) files.emplace_back(std::string(&buf[at]));
+    return files;
+}
+
+int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path>& files, const std::string& pack_to)
+{
+    if (fs::is_regular_file(fs::path(g))) {
+        CHECK(ctx, afis_gallery_load(ctx, g.c_str(), 0, -1));
+    } else {
+        std::vector<uint8_t> b;
+        for (const fs::path& f : files) {
+            read_file(f.string(), b);
+            int load_rc = 0;
+            CHECK(ctx, afis_gallery_add_dat(ctx, b.data(), b.size(), &load_rc));
+        }
+    }
+    if (!pack_to.empty()) {
+        std::vector<std::string> names; std::vector<const char*> np;
+        for (const fs::path& f : files) names.push_back(f.string());
+        for (const std::string& n : names) np.push_back(n.c_str());
+        CHECK(ctx, afis_gallery_save(ctx, pack_to.c_str(), np.data()));
     }
     CHECK(ctx, afis_gallery_commit(ctx, 0));
     return 0;
@@ -124,7 +150,7 @@ int main(int argc, char** argv)
 {
     ArgParser args(argc, argv);
     if (args.cmdOptionExists("-h") || args.cmdOptionExists("--help")) {
-        std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>]\n";
+        std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>] [-pack <gallery container to write>]\n       -g may name a packed gallery container instead of a directory\n";
         return 0;
     }
     const auto config = read_flat_json((fs::current_path().parent_path() / "afis.config").string());
@@ -154,16 +180,25 @@ int main(int argc, char** argv)
 
     using clk = std::chrono::high_resolution_clock;
     int ret = 0;
+    const std::string pack_to = args.cmdOptionExists("-pack") ? args.getCmdOption("-pack") : "";
+    if (!pack_to.empty() && !args.cmdOptionExists("-l") && !args.cmdOptionExists("-ldir")) {          // pack only
+        std::vector<fs::path> rolled = list_gallery(gallery_path);
+        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; afis_destroy(ctx); return -1; }
+        ret = load_gallery(ctx, gallery_path, rolled, pack_to);
+        if (ret == 0) std::cout << "Packed " << rolled.size() << " templates into " << pack_to << std::endl;
+        afis_destroy(ctx);
+        return ret;
+    }
     if (args.cmdOptionExists("-l")) {
         // ---- One2List_matching, matcher.cpp:216-337 ----
         const fs::path latent_file(args.getCmdOption("-l"));
         const std::string score_file = score_path + latent_file.stem().string() + ".csv";
-        std::vector<fs::path> rolled = list_dat(gallery_path);
+        std::vector<fs::path> rolled = list_gallery(gallery_path);
         if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; afis_destroy(ctx); return -1; }
         const auto t0 = clk::now();
         std::cout << "Latent Query: " << latent_file << std::endl;
         std::cout << "Gallery size: " << rolled.size() << std::endl;
-        if ((ret = load_gallery(ctx, rolled)) != 0) { afis_destroy(ctx); return ret; }
+        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to)) != 0) { afis_destroy(ctx); return ret; }
         Latent L; L.load(latent_file);
         if (L.view.n_minu <= 0 && L.view.n_tex <= 0) { std::ofstream out(score_file); out << 0 << std::endl; }       // :260-268
         const int k = (int)std::min<size_t>(24, rolled.size());
@@ -200,12 +235,12 @@ int main(int argc, char** argv)
         std::vector<fs::path> latents = list_dat(latent_dir);
         for (const fs::path& p : latents) std::cout << "latent template file" << p << std::endl;
         if (latents.empty()) { std::cout << "No latent templates found in directory: " << latent_dir << std::endl; afis_destroy(ctx); return -1; }
-        std::vector<fs::path> rolled = list_dat(gallery_path);
+        std::vector<fs::path> rolled = list_gallery(gallery_path);
         for (const fs::path& p : rolled) std::cout << "rolled template file" << p << std::endl;
         if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; afis_destroy(ctx); return -1; }
         std::cout << "Gallery size: " << rolled.size() << std::endl;
         const auto t0 = clk::now();
-        if ((ret = load_gallery(ctx, rolled)) != 0) { afis_destroy(ctx); return ret; }
+        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to)) != 0) { afis_destroy(ctx); return ret; }
         const size_t G = rolled.size();
         const size_t batch = 16;
         for (size_t i0 = 0; i0 < latents.size(); i0 += batch) {

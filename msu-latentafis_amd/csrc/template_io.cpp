@@ -1,5 +1,11 @@
 #include "template_io.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <type_traits>
+
 #include <cstdio>
 #include <cstring>
 
@@ -169,6 +175,142 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out)
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     if (n > 0) { out.resize((size_t)n); if (fread(out.data(), 1, (size_t)n, f) != (size_t)n) { fclose(f); out.clear(); return false; } }
     fclose(f);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// packed gallery container (layout in template_io.h)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr char kGalMagic[8] = {'A', 'F', 'I', 'S', 'G', 'A', 'L', '1'};
+constexpr int kGalSections = 13;
+struct GalHeader {
+    char magic[8];
+    uint32_t version, des_len, code_len, reserved;
+    int64_t G, n_minu, n_tex, names_bytes;
+    uint64_t off[kGalSections];
+};
+static_assert(sizeof(GalHeader) == 56 + 8 * kGalSections, "container header layout");
+
+struct Mapped {                       // read-only mmap of a whole file
+    const uint8_t* p = nullptr; size_t len = 0; int fd = -1;
+    bool open_file(const std::string& path, std::string& err)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { err = "cannot open " + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < (off_t)sizeof(GalHeader)) { err = path + ": not a gallery container (too small)"; return false; }
+        len = (size_t)st.st_size;
+        void* m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { err = "mmap failed for " + path; return false; }
+        p = (const uint8_t*)m;
+        return true;
+    }
+    ~Mapped() { if (p) munmap((void*)p, len); if (fd >= 0) ::close(fd); }
+};
+
+bool check_header(const Mapped& m, const std::string& path, GalHeader& h, size_t sizes[kGalSections], std::string& err)
+{
+    memcpy(&h, m.p, sizeof(h));
+    if (memcmp(h.magic, kGalMagic, 8) != 0 || h.version != 1) { err = path + ": not an AFISGAL1 container"; return false; }
+    if (h.des_len != 96 || h.code_len != 16 || h.G < 0 || h.n_minu < 0 || h.n_tex < 0 || h.names_bytes < 0) { err = path + ": unsupported container geometry"; return false; }
+    const size_t G = (size_t)h.G, NM = (size_t)h.n_minu, NT = (size_t)h.n_tex;
+    const size_t want[kGalSections] = {(G + 1) * 8, (G + 1) * 8, G, NM * 2, NM * 2, NM * 4, NM * 96 * 4, NT * 2, NT * 2, NT * 4, NT * 16, (G + 1) * 8, (size_t)h.names_bytes};
+    for (int i = 0; i < kGalSections; ++i) {
+        sizes[i] = want[i];
+        if (h.off[i] % 64 != 0 || h.off[i] > m.len || want[i] > m.len - h.off[i]) { err = path + ": truncated or corrupt container"; return false; }
+    }
+    return true;
+}
+}  // namespace
+
+void gallery_append_template(HostGallery& g, const HostTemplate& t)
+{
+    if (!t.minu.empty()) {
+        const HostMinutiae& m = t.minu[0];
+        g.mx.insert(g.mx.end(), m.x.begin(), m.x.end()); g.my.insert(g.my.end(), m.y.begin(), m.y.end());
+        g.mori.insert(g.mori.end(), m.ori.begin(), m.ori.end()); g.mdes.insert(g.mdes.end(), m.des.begin(), m.des.end());
+    }
+    g.minu_off.push_back((int64_t)g.mx.size());
+    if (!t.tex.empty()) {
+        const HostTexture& x = t.tex[0];
+        const int n = x.n() < 1000 ? x.n() : 1000;                           // matcher.cpp:546-547
+        g.tx.insert(g.tx.end(), x.x.begin(), x.x.begin() + n); g.ty.insert(g.ty.end(), x.y.begin(), x.y.begin() + n);
+        g.tori.insert(g.tori.end(), x.ori.begin(), x.ori.begin() + n); g.tcodes.insert(g.tcodes.end(), x.codes.begin(), x.codes.begin() + (size_t)n * 16);
+    }
+    g.tex_off.push_back((int64_t)g.tx.size());
+    g.empty.push_back(t.minu.empty() && t.tex.empty() ? 1 : 0);
+}
+
+bool write_gallery_container(const std::string& path, const HostGallery& g, const std::vector<std::string>& names, std::string& err)
+{
+    const size_t G = (size_t)g.size(), NM = g.mx.size(), NT = g.tx.size();
+    if (!names.empty() && names.size() != G) { err = "write_gallery_container: names must be empty or one per template"; return false; }
+    std::vector<int64_t> name_off(G + 1, 0);
+    std::string blob;
+    for (size_t i = 0; i < G; ++i) { if (!names.empty()) blob += names[i]; name_off[i + 1] = (int64_t)blob.size(); }
+    GalHeader h = {};
+    memcpy(h.magic, kGalMagic, 8);
+    h.version = 1; h.des_len = 96; h.code_len = 16;
+    h.G = (int64_t)G; h.n_minu = (int64_t)NM; h.n_tex = (int64_t)NT; h.names_bytes = (int64_t)blob.size();
+    const void* ptr[kGalSections] = {g.minu_off.data(), g.tex_off.data(), g.empty.data(), g.mx.data(), g.my.data(), g.mori.data(), g.mdes.data(),
+                                     g.tx.data(), g.ty.data(), g.tori.data(), g.tcodes.data(), name_off.data(), blob.data()};
+    const size_t sz[kGalSections] = {(G + 1) * 8, (G + 1) * 8, G, NM * 2, NM * 2, NM * 4, NM * 96 * 4, NT * 2, NT * 2, NT * 4, NT * 16, (G + 1) * 8, blob.size()};
+    if (g.minu_off.size() != G + 1 || g.tex_off.size() != G + 1 || g.mdes.size() != NM * 96 || g.tcodes.size() != NT * 16) { err = "write_gallery_container: inconsistent gallery"; return false; }
+    uint64_t pos = (sizeof(GalHeader) + 63) / 64 * 64;
+    for (int i = 0; i < kGalSections; ++i) { h.off[i] = pos; pos = (pos + sz[i] + 63) / 64 * 64; }
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { err = "cannot create " + path; return false; }
+    static const char zeros[64] = {0};
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    uint64_t at = sizeof(h);
+    for (int i = 0; i < kGalSections && ok; ++i) {
+        if (h.off[i] > at) { ok = fwrite(zeros, 1, (size_t)(h.off[i] - at), f) == (size_t)(h.off[i] - at); at = h.off[i]; }
+        if (sz[i] && ok) ok = fwrite(ptr[i], 1, sz[i], f) == sz[i];
+        at += sz[i];
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) err = "write failed for " + path;
+    return ok;
+}
+
+bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std::string& err)
+{
+    Mapped m; GalHeader h; size_t sizes[kGalSections];
+    if (!m.open_file(path, err) || !check_header(m, path, h, sizes, err)) return false;
+    info.G = h.G; info.n_minu = h.n_minu; info.n_tex = h.n_tex;
+    return true;
+}
+
+bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
+                            std::vector<int32_t>* tex_counts, std::string& err)
+{
+    Mapped m; GalHeader h; size_t sizes[kGalSections];
+    if (!m.open_file(path, err) || !check_header(m, path, h, sizes, err)) return false;
+    if (count < 0) count = h.G - first;
+    if (first < 0 || count < 0 || first + count > h.G) { err = path + ": template range outside the container"; return false; }
+    const int64_t* mo = (const int64_t*)(m.p + h.off[0]); const int64_t* to = (const int64_t*)(m.p + h.off[1]);
+    for (int64_t i = 0; i < h.G; ++i)
+        if (mo[i + 1] < mo[i] || to[i + 1] < to[i] || mo[i + 1] > h.n_minu || to[i + 1] > h.n_tex || mo[0] != 0 || to[0] != 0) { err = path + ": corrupt offsets"; return false; }
+    if (tex_counts) { tex_counts->resize((size_t)h.G); for (int64_t i = 0; i < h.G; ++i) (*tex_counts)[(size_t)i] = (int32_t)(to[i + 1] - to[i]); }
+    const int64_t m0 = mo[first], m1 = mo[first + count], t0 = to[first], t1 = to[first + count];
+    auto app = [&](auto& vec, int sec, int64_t a, int64_t b, size_t per) {
+        typedef typename std::remove_reference<decltype(vec)>::type V;
+        const typename V::value_type* src = (const typename V::value_type*)(m.p + h.off[sec]);
+        vec.insert(vec.end(), src + (size_t)a * per, src + (size_t)b * per);
+    };
+    app(out.mx, 3, m0, m1, 1); app(out.my, 4, m0, m1, 1); app(out.mori, 5, m0, m1, 1); app(out.mdes, 6, m0, m1, 96);
+    app(out.tx, 7, t0, t1, 1); app(out.ty, 8, t0, t1, 1); app(out.tori, 9, t0, t1, 1); app(out.tcodes, 10, t0, t1, 16);
+    const int64_t mb = out.minu_off.back() - m0, tb = out.tex_off.back() - t0;
+    const uint8_t* emp = m.p + h.off[2];
+    for (int64_t i = first; i < first + count; ++i) { out.minu_off.push_back(mo[i + 1] + mb); out.tex_off.push_back(to[i + 1] + tb); out.empty.push_back(emp[i]); }
+    if (names) {
+        const int64_t* no = (const int64_t*)(m.p + h.off[11]); const char* blob = (const char*)(m.p + h.off[12]);
+        for (int64_t i = first; i < first + count; ++i) {
+            if (no[i + 1] < no[i] || no[i + 1] > h.names_bytes) { err = path + ": corrupt name table"; return false; }
+            names->emplace_back(blob + no[i], (size_t)(no[i + 1] - no[i]));
+        }
+    }
     return true;
 }
 

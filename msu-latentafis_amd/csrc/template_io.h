@@ -35,6 +35,36 @@ struct HostCodebook {            // matcher.cpp:70-93
     std::vector<float> words;    // [M][K][dsub]
 };
 
+// The staged gallery shard in host memory (what afis_gallery_add* accumulate and afis_gallery_commit uploads): only rolled
+// minutiae template 0 and texture template 0 of every file (the ones the matcher reads, matcher.cpp:406,413), texture counts
+// clamped to 1000 (matcher.cpp:546-547), points of all templates concatenated with CSR offsets.
+struct HostGallery {
+    std::vector<int64_t> minu_off{0}, tex_off{0};
+    std::vector<int16_t> mx, my, tx, ty;
+    std::vector<float> mori, mdes, tori;
+    std::vector<uint8_t> tcodes;
+    std::vector<uint8_t> empty;  // 1 = the file had neither template (status 2, score -1)
+    int64_t size() const { return (int64_t)empty.size(); }
+};
+
+// Packed gallery container: ONE file instead of 100k-1M tiny .dat files, the SoA arrays of HostGallery as they
+// are, every section 64-byte aligned so the file can be mmap-ed and a contiguous template range [first, first+count) — a
+// shard — read without touching the rest.  Little-endian.
+//   0   char[8]  "AFISGAL1"      8  u32 version (1), u32 des_len (96), u32 code_len (16), u32 0
+//   24  i64 G, i64 n_minutiae, i64 n_texture_points, i64 names_bytes
+//   56  u64 offset[13]: minu_off i64[G+1] | tex_off i64[G+1] | empty u8[G] | minu_x i16[] | minu_y i16[] | minu_ori f32[] |
+//       minu_des f32[][96] | tex_x i16[] | tex_y i16[] | tex_ori f32[] | tex_codes u8[][16] | name_off i64[G+1] | names char[]
+// names[i] = the path of the .dat file template i came from (what the score files print).
+// appends one parsed rolled template the way afis_gallery_add_dat does: minutiae template 0, texture template 0 clamped to 1000
+void gallery_append_template(HostGallery& g, const HostTemplate& t);
+struct GalleryFileInfo { int64_t G = 0, n_minu = 0, n_tex = 0; };
+bool write_gallery_container(const std::string& path, const HostGallery& g, const std::vector<std::string>& names, std::string& err);
+bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std::string& err);
+// appends templates [first, first+count) (count < 0: to the end) to `out`; names / tex_counts (texture points of EVERY template in
+// the file, for balanced sharding) are optional
+bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
+                            std::vector<int32_t>* tex_counts, std::string& err);
+
 // Return codes of the two parsers are the reference's: 0 ok, 1 empty file (latent: size <= 0, rolled: size <= 10),
 // 2 too many minutiae in a minutiae template, 4 ridge-flow block too large, -1 too many points in a texture template.
 // On a non-zero code `out` holds whatever had been parsed before the error, exactly as the reference leaves it.

@@ -3,6 +3,7 @@
 // parsed template and reports whether the bytes are identical.  Used by tests/test_host.py to cross-check the C++ parser/writer
 // against the Python mirror and the oracle's parser.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,8 +21,40 @@ static unsigned long long fnv(const void* p, size_t n, unsigned long long h = 14
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: tio_check latent|rolled|codebook|roundtrip-latent|roundtrip-rolled <file>\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: tio_check latent|rolled|codebook|roundtrip-latent|roundtrip-rolled <file>\n"
+                                    "       tio_check gallery-pack <out container> <rolled .dat>...\n"
+                                    "       tio_check gallery-dump <container> [first count]\n"); return 2; }
     const std::string mode = argv[1];
+    if (mode == "gallery-pack") {                        // the host half of `match -pack`: rolled .dat files -> one container
+        HostGallery g; std::vector<std::string> names; std::vector<uint8_t> fb;
+        for (int i = 3; i < argc; ++i) {
+            HostTemplate t;
+            if (!read_file(argv[i], fb)) { printf("rc=io\n"); return 1; }
+            if (parse_rolled_dat(fb.data(), fb.size(), t) < 0) { t.minu.clear(); t.tex.clear(); }
+            gallery_append_template(g, t); names.push_back(argv[i]);
+        }
+        std::string err;
+        if (!write_gallery_container(argv[2], g, names, err)) { printf("error=%s\n", err.c_str()); return 1; }
+        printf("ok G=%lld\n", (long long)g.size());
+        return 0;
+    }
+    if (mode == "gallery-dump") {
+        const long long first = argc > 4 ? atoll(argv[3]) : 0, count = argc > 4 ? atoll(argv[4]) : -1;
+        HostGallery g; std::vector<std::string> names; std::vector<int32_t> tc; std::string err; GalleryFileInfo info;
+        if (!gallery_container_info(argv[2], info, err) || !read_gallery_container(argv[2], first, count, g, &names, &tc, err)) { printf("error=%s\n", err.c_str()); return 1; }
+        printf("G=%lld n_minu=%lld n_tex=%lld range=%lld\n", (long long)info.G, (long long)info.n_minu, (long long)info.n_tex, (long long)g.size());
+        unsigned long long h = fnv(g.minu_off.data(), g.minu_off.size() * 8); h = fnv(g.tex_off.data(), g.tex_off.size() * 8, h); h = fnv(g.empty.data(), g.empty.size(), h);
+        printf("offsets hash=%016llx\n", h);
+        h = fnv(g.mx.data(), g.mx.size() * 2); h = fnv(g.my.data(), g.my.size() * 2, h); h = fnv(g.mori.data(), g.mori.size() * 4, h); h = fnv(g.mdes.data(), g.mdes.size() * 4, h);
+        printf("minutiae hash=%016llx\n", h);
+        h = fnv(g.tx.data(), g.tx.size() * 2); h = fnv(g.ty.data(), g.ty.size() * 2, h); h = fnv(g.tori.data(), g.tori.size() * 4, h); h = fnv(g.tcodes.data(), g.tcodes.size(), h);
+        printf("texture hash=%016llx\n", h);
+        h = 1469598103934665603ull; for (const std::string& n : names) h = fnv(n.c_str(), n.size() + 1, h);
+        printf("names hash=%016llx\n", h);
+        h = fnv(tc.data(), tc.size() * 4);
+        printf("tex_counts hash=%016llx\n", h);
+        return 0;
+    }
     std::vector<uint8_t> b;
     if (!read_file(argv[2], b)) { printf("rc=io\n"); return 1; }
     if (mode == "codebook") {

@@ -43,7 +43,8 @@ class Timing(C.Structure):
 
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
-           "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_search", "afis_search_dat", "afis_queries_upload",
+           "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
+           "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
            "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
 
 
@@ -61,6 +62,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_gallery_add_packed.argtypes = [vp, C.c_int64, i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, fp,
                                             i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, C.POINTER(C.c_uint8)]
     lib.afis_gallery_commit.argtypes = [vp, C.c_int64]
+    lib.afis_gallery_save.argtypes = [vp, C.c_char_p, C.POINTER(C.c_char_p)]
+    lib.afis_gallery_load.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64]
+    lib.afis_gallery_file_info.argtypes = [C.c_char_p, i64p, i64p, i64p, i32p]
+    lib.afis_gallery_file_names.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.afis_gallery_size.argtypes = [vp]; lib.afis_gallery_size.restype = C.c_int64
     lib.afis_search.argtypes = [vp, C.POINTER(TemplateView), C.c_int, fp, fp, i32p, C.c_int, i64p, fp]
     lib.afis_search_dat.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, fp, fp, i32p, C.c_int, i64p, fp]
@@ -162,6 +167,36 @@ class Matcher:
         self._chk(self.lib.afis_gallery_add_packed(self.ctx, len(mo) - 1, _ptr(mo, C.c_int64), _ptr(a[0], C.c_int16), _ptr(a[1], C.c_int16),
                                                    _ptr(a[2], C.c_float), _ptr(a[3], C.c_float), _ptr(to, C.c_int64), _ptr(a[4], C.c_int16),
                                                    _ptr(a[5], C.c_int16), _ptr(a[6], C.c_float), _ptr(a[7], C.c_uint8)))
+
+    def gallery_save(self, path: str, names: Sequence[str] = None):
+        """Write the staged gallery as one packed container (before gallery_commit)."""
+        arr = None
+        if names is not None:
+            arr = (C.c_char_p * max(1, len(names)))(*[n.encode() for n in names])
+        self._chk(self.lib.afis_gallery_save(self.ctx, path.encode(), arr))
+
+    def gallery_load(self, path: str, first: int = 0, count: int = -1):
+        """Append templates [first, first+count) of a packed container to the staged gallery."""
+        self._chk(self.lib.afis_gallery_load(self.ctx, path.encode(), first, count))
+
+    def gallery_file_info(self, path: str):
+        """-> (G, minutiae, texture points, per-template texture point counts) of a packed container."""
+        G = C.c_int64(0); nm = C.c_int64(0); nt = C.c_int64(0)
+        if self.lib.afis_gallery_file_info(path.encode(), C.byref(G), C.byref(nm), C.byref(nt), None) != 0:
+            raise AfisError(self.lib.afis_last_error(None).decode())
+        tc = np.zeros(max(1, G.value), np.int32)
+        if self.lib.afis_gallery_file_info(path.encode(), None, None, None, _ptr(tc, C.c_int32)) != 0:
+            raise AfisError(self.lib.afis_last_error(None).decode())
+        return G.value, nm.value, nt.value, tc[:G.value]
+
+    def gallery_file_names(self, path: str, first: int = 0, count: int = -1) -> List[str]:
+        need = C.c_size_t(0)
+        if self.lib.afis_gallery_file_names(path.encode(), first, count, None, 0, C.byref(need)) != 0:
+            raise AfisError(self.lib.afis_last_error(None).decode())
+        buf = C.create_string_buffer(max(1, need.value))
+        if self.lib.afis_gallery_file_names(path.encode(), first, count, buf, need.value, C.byref(need)) != 0:
+            raise AfisError(self.lib.afis_last_error(None).decode())
+        return [b.decode() for b in buf.raw[:need.value].split(b"\0")[:-1]] if need.value else []
 
     def gallery_commit(self, index_base: int = 0):
         self._chk(self.lib.afis_gallery_commit(self.ctx, index_base))
@@ -267,6 +302,11 @@ class Matcher:
     # ---- the reference's drivers (matching/matcher.cpp:96-337) ---------------------------------------------------
     def load_gallery_dir(self, rolled_path: str) -> List[str]:
         """Directory scan for *.dat as One2List/List2List do (matcher.cpp:120-130, directory order)."""
+        if os.path.isfile(rolled_path):                   # a packed gallery container instead of a directory
+            self.gallery_load(rolled_path)
+            self.gallery_files = self.gallery_file_names(rolled_path)
+            self.gallery_commit(0)
+            return self.gallery_files
         files = [os.path.join(rolled_path, f) for f in os.listdir(rolled_path) if os.path.splitext(f)[1] == ".dat"]
         for f in files:
             with open(f, "rb") as fh:

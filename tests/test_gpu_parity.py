@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 T = importlib.import_module("msu-latentafis_amd.host.templates")
 S = importlib.import_module("msu-latentafis_amd.host.synth")
 M = importlib.import_module("msu-latentafis_amd.host.matcher")
+SH = importlib.import_module("msu-latentafis_amd.host.sharding")
 
 
 @pytest.fixture(scope="module")
@@ -171,6 +172,60 @@ def test_pq_encoder_bit_exact(codebook_bytes, cb, oracle, tmp_path):
     assert "Single template PQ is not available for rolled prints" in out.stdout
     out = subprocess.run([exe, "--fprint_type", "rolled"], capture_output=True, text=True, cwd=tmp_path / "work")
     assert "Missing args." in out.stdout
+
+
+def test_gallery_container_equals_directory(codebook_bytes, cb, small, tmp_path):
+    """a gallery loaded from one packed container (whole, and as two shards) scores exactly like the same gallery
+    loaded from its .dat files; the CLI prints the same score files from either."""
+    import os, subprocess
+    lats, gal = small
+    (tmp_path / "gal").mkdir(); (tmp_path / "lat").mkdir(); (tmp_path / "o1").mkdir(); (tmp_path / "o2").mkdir(); (tmp_path / "work").mkdir()
+    files = []
+    for j, g in enumerate(gal[:12]):
+        p = tmp_path / "gal" / f"R{j:03d}.dat"; p.write_bytes(T.write_rolled(g)); files.append(str(p))
+    p = tmp_path / "gal" / "R_empty.dat"; p.write_bytes(b""); files.append(str(p))
+    m = M.Matcher(codebook_bytes)
+    for f in files:
+        m.gallery_add_dat(open(f, "rb").read())
+    box = str(tmp_path / "g.afisgal")
+    m.gallery_save(box, files)
+    m.gallery_commit(0)
+    with pytest.raises(M.AfisError):
+        m.gallery_save(box, files)                                  # the staging copy is gone after commit
+    want = m.search(lats[:2], k=5)
+    G, nm, nt, tc = m.gallery_file_info(box)
+    assert G == 13 and nt == tc.sum() and tc[-1] == 0 and m.gallery_file_names(box, 3, 2) == files[3:5]
+    m1 = M.Matcher(codebook_bytes); m1.gallery_load(box); m1.gallery_commit(0)
+    got = m1.search(lats[:2], k=5)
+    assert np.array_equal(got["scores"], want["scores"]) and np.array_equal(got["topk_idx"], want["topk_idx"])
+    bounds = SH.shard_bounds(tc, 2)                                 # two shards straight from the file, balanced by texture points
+    parts = []
+    for lo, hi in bounds:
+        ms = M.Matcher(codebook_bytes); ms.gallery_load(box, lo, hi - lo); ms.gallery_commit(lo)
+        parts.append(ms.search(lats[:2], k=5)); ms.close()
+    assert np.array_equal(np.concatenate([p["scores"] for p in parts], axis=1), want["scores"])
+    with pytest.raises(M.AfisError):
+        m1.gallery_load(box)                                        # committed
+    m2 = M.Matcher(codebook_bytes)
+    with pytest.raises(M.AfisError):
+        m2.gallery_load(box, 10, 9)                                 # range outside the file
+    m.close(); m1.close(); m2.close()
+    # CLI: -pack writes the container, -g <container> gives the same outputs as -g <directory>
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    for i, L in enumerate(lats[:2]):
+        (tmp_path / "lat" / f"L{i}.dat").write_bytes(T.write_latent(L))
+    box2 = str(tmp_path / "cli.afisgal")
+    out = subprocess.run([exe, "-g", str(tmp_path / "gal"), "-pack", box2, "-s", str(tmp_path / "o1") + "/", "-c", str(cbp)], capture_output=True, text=True, cwd=tmp_path / "work")
+    assert out.returncode == 0 and "Packed 13 templates" in out.stdout, out.stderr
+    for mode in (["-ldir", str(tmp_path / "lat")], ["-l", str(tmp_path / "lat" / "L0.dat")]):
+        o1 = subprocess.run([exe] + mode + ["-g", str(tmp_path / "gal"), "-s", str(tmp_path / "o1") + "/", "-c", str(cbp)], capture_output=True, text=True, cwd=tmp_path / "work")
+        o2 = subprocess.run([exe] + mode + ["-g", box2, "-s", str(tmp_path / "o2") + "/", "-c", str(cbp)], capture_output=True, text=True, cwd=tmp_path / "work")
+        assert o1.returncode == 0 and o2.returncode == 0, (o1.stderr, o2.stderr)
+        names = sorted(os.listdir(tmp_path / "o1"))
+        assert names == sorted(os.listdir(tmp_path / "o2")) and len(names) >= 2
+        for n in names:
+            assert (tmp_path / "o1" / n).read_bytes() == (tmp_path / "o2" / n).read_bytes(), n
 
 
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):

@@ -150,3 +150,81 @@ def test_synthetic_gallery_is_shard_consistent(cb):
     nm, nt = S.gallery_counts(9, G)
     assert nm.min() >= 20 and nm.max() <= 200 and nt.min() >= 600 and nt.max() <= 1000
     assert np.allclose(np.linalg.norm(full.minu_des[:100], axis=1), 1.73, atol=1e-4)
+
+
+# ---- packed gallery container: C++ writer/reader (tio_check, host only) against the Python mirror -------------
+def _small_gallery(cb, n=7, seed=3):
+    rng = np.random.default_rng(seed)
+    ts = [S.make_rolled(rng, cb, n_tex=int(rng.integers(20, 60)), n_minu=int(rng.integers(5, 15))) for _ in range(n)]
+    ts[2] = T.FPTemplate(minu=ts[2].minu, tex=[])            # no texture template
+    ts[4] = T.FPTemplate()                                   # empty file
+    big = S.make_rolled(rng, cb, n_tex=1100, n_minu=8)       # above the 1000-point clamp (matcher.cpp:546-547)
+    ts.append(big)
+    return ts
+
+
+def _pack(ts):
+    mo, to = [0], [0]; mx, my, mori, mdes, tx, ty, tori, tc = [], [], [], [], [], [], [], []
+    for t in ts:
+        if t.minu:
+            m = t.minu[0]; mx.append(m.x); my.append(m.y); mori.append(m.ori); mdes.append(m.des)
+        mo.append(mo[-1] + (t.minu[0].n if t.minu else 0))
+        n = min(t.tex[0].n, 1000) if t.tex else 0
+        if n:
+            x = t.tex[0]; tx.append(x.x[:n]); ty.append(x.y[:n]); tori.append(x.ori[:n]); tc.append(x.codes[:n])
+        to.append(to[-1] + n)
+    cat = lambda a, dt, shape=(0,): np.concatenate(a).astype(dt) if a else np.zeros(shape, dt)
+    return S.PackedGallery(np.array(mo, np.int64), cat(mx, np.int16), cat(my, np.int16), cat(mori, np.float32), cat(mdes, np.float32, (0, 96)),
+                           np.array(to, np.int64), cat(tx, np.int16), cat(ty, np.int16), cat(tori, np.float32), cat(tc, np.uint8, (0, 16)))
+
+
+def _dump_hashes(out):
+    return {k: v for k, v in re.findall(r"(\w+) hash=([0-9a-f]+)", out)}
+
+
+def _want_hashes(g, names, tex_counts):
+    empty = ((np.diff(g.minu_off) == 0) & (np.diff(g.tex_off) == 0)).astype(np.uint8)
+    return {"offsets": "%016x" % fnv([g.minu_off.astype("<i8").tobytes(), g.tex_off.astype("<i8").tobytes(), empty.tobytes()]),
+            "minutiae": "%016x" % fnv([g.minu_x.tobytes(), g.minu_y.tobytes(), g.minu_ori.tobytes(), g.minu_des.tobytes()]),
+            "texture": "%016x" % fnv([g.tex_x.tobytes(), g.tex_y.tobytes(), g.tex_ori.tobytes(), g.tex_codes.tobytes()]),
+            "names": "%016x" % fnv([n.encode() + b"\0" for n in names]),
+            "tex_counts": "%016x" % fnv([np.asarray(tex_counts, "<i4").tobytes()])}
+
+
+def test_gallery_container_cpp_and_python_agree(cb, tio, tmp_path):
+    CT = importlib.import_module("msu-latentafis_amd.host.container")
+    ts = _small_gallery(cb)
+    files = []
+    for i, t in enumerate(ts):
+        p = tmp_path / f"R{i:02d}.dat"; p.write_bytes(T.write_rolled(t)); files.append(str(p))
+    g = _pack(ts)
+    tex_counts = np.diff(g.tex_off)
+    # C++ packs the .dat files; Python reads the container back
+    cpp = tmp_path / "cpp.afisgal"
+    out = subprocess.run([tio, "gallery-pack", str(cpp)] + files, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == f"ok G={len(ts)}"
+    g2, names2, tc2 = CT.read_container(str(cpp))
+    for f in ("minu_off", "minu_x", "minu_y", "minu_ori", "minu_des", "tex_off", "tex_x", "tex_y", "tex_ori", "tex_codes"):
+        assert np.array_equal(getattr(g2, f), getattr(g, f)), f
+    assert names2 == files and np.array_equal(tc2, tex_counts) and tc2.max() == 1000
+    # Python writes; C++ reads (whole file and a shard range) and reports hashes of what it loaded
+    py = tmp_path / "py.afisgal"
+    CT.write_container(str(py), g, files)
+    assert py.read_bytes() == cpp.read_bytes()                         # the two writers produce the same file
+    out = subprocess.run([tio, "gallery-dump", str(py)], capture_output=True, text=True, check=True).stdout
+    assert f"G={len(ts)} n_minu={len(g.minu_x)} n_tex={len(g.tex_x)} range={len(ts)}" in out
+    assert _dump_hashes(out) == _want_hashes(g, files, tex_counts)
+    first, count = 2, 4
+    out = subprocess.run([tio, "gallery-dump", str(py), str(first), str(count)], capture_output=True, text=True, check=True).stdout
+    sub, sub_names, _ = CT.read_container(str(py), first, count)
+    assert np.array_equal(sub.minu_des, _pack(ts[first:first + count]).minu_des)
+    assert _dump_hashes(out) == _want_hashes(sub, sub_names, tex_counts)
+    # damaged files are rejected, not read past their end
+    bad = tmp_path / "bad.afisgal"; bad.write_bytes(py.read_bytes()[:-100])
+    assert "error=" in subprocess.run([tio, "gallery-dump", str(bad)], capture_output=True, text=True).stdout
+    bad.write_bytes(b"NOTAGAL1" + py.read_bytes()[8:])
+    assert "error=" in subprocess.run([tio, "gallery-dump", str(bad)], capture_output=True, text=True).stdout
+    out = subprocess.run([tio, "gallery-dump", str(py), "5", "9"], capture_output=True, text=True).stdout
+    assert "error=" in out and "range" in out
+    with pytest.raises(ValueError):
+        CT.read_container(str(bad))
