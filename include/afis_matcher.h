@@ -147,6 +147,14 @@ int afis_gallery_load(afis_ctx* ctx, const char* path, int64_t first, int64_t co
 int afis_gallery_file_info(const char* path, int64_t* G, int64_t* n_minutiae, int64_t* n_tex_points, int32_t* tex_counts /*[G] or NULL*/);
 int afis_gallery_file_names(const char* path, int64_t first, int64_t count, char* buf, size_t cap, size_t* need);
 
+/* Matcher::One2One_matching_all_templates (matching/matcher.cpp:339-374) for one latent against the whole resident gallery:
+ * scores[g][i] for i < n_minu = latent minutiae template i vs rolled minutiae template 0, scores[g][n_minu + t] = latent texture
+ * template t vs rolled texture template 0; zero where the reference leaves the zero-filled vector untouched.
+ *   scores        [G][query->n_minu + query->n_tex]
+ *   rolled_status [G] or NULL : 0, or 2 = rolled template empty (the reference returns 2 before scoring, :350-353)
+ *   query_status  NULL or out : AFIS_QUERY_LATENT_EMPTY when the latent has no template at all (:345-348) */
+int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, float* scores, int32_t* rolled_status, int32_t* query_status);
+
 /* PQ encoder — replaces TrainedPQEncoder.encode_multi (extraction/descriptor_PQ.py:19-27, scipy.cluster.vq.vq per
  * sub-space): codes[i][m] = index of the codeword of sub-quantizer m nearest (squared L2, fp32, first minimum) to
  * des[i][6m .. 6m+5].  des: [n][96] fp32, codes: [n][16] u8, host pointers.  afis_gallery_add calls it for rolled texture

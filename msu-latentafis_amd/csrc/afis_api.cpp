@@ -472,19 +472,23 @@ int64_t afis_gallery_size(const afis_ctx* ctx) { return ctx ? (int64_t)ctx->hg.e
 // ---------------------------------------------------------------------------------------------------------------------
 static const int kSelected[3] = {27 - 1, 3 - 1, 12 - 1};                   // matcher.cpp:380
 
-static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, QueryGroup& grp, std::vector<int32_t>& status_out)
+// spec == NULL: the reference's selection for every query (templates 27, 3, 12 and texture template 0, matcher.cpp:380-415).
+// spec != NULL (afis_match_all_templates): query i uses latent minutiae templates spec[i*4 + 0..2] (-1 = none) and latent texture
+// template spec[i*4 + 3] (-1 = none), and is never "latent empty".
+static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, QueryGroup& grp, std::vector<int32_t>& status_out, const int* spec = nullptr)
 {
-    const int* sel = kSelected;
     std::vector<int32_t> lm_off{0}, lt_off{0}, tile_off{0}, tex_slot, status;
     std::vector<short2> lm_xy, lt_xy; std::vector<float> lm_ori, lm_des, lt_ori, lt_des;
     int max_nL = 0, lt_max = 0;
     for (int i = 0; i < nq; ++i) {
         const afis_template_view& t = qs[i];
         if (t.n_minu < 0 || t.n_tex < 0 || (t.n_minu > 0 && !t.minu) || (t.n_tex > 0 && !t.tex)) return fail(ctx, AFIS_EINVAL, "latent template: bad view");
-        const bool latent_empty = (t.n_minu <= sel[0] && t.n_tex <= 0);     // matcher.cpp:383-386
+        const int* sel = spec ? spec + (size_t)i * 4 : kSelected;
+        const int tex_ind = spec ? spec[(size_t)i * 4 + 3] : 0;
+        const bool latent_empty = !spec && (t.n_minu <= sel[0] && t.n_tex <= 0);     // matcher.cpp:383-386
         status.push_back(latent_empty ? AFIS_QUERY_LATENT_EMPTY : AFIS_QUERY_OK);
         for (int s = 0; s < 3; ++s) {
-            if (!latent_empty && t.n_minu > sel[s]) {
+            if (!latent_empty && sel[s] >= 0 && t.n_minu > sel[s]) {
                 const afis_minutiae_view& m = t.minu[sel[s]];
                 if (m.n <= 0 || m.n > 2000 || !m.x || !m.y || !m.ori || !m.des) return fail(ctx, AFIS_EINVAL, "latent minutiae template: bad view (n must be 1..2000)");
                 if (m.des_len != kDes) return fail(ctx, AFIS_EINVAL, "latent minutiae template: des_len must be 96 (the reference asserts equal descriptor lengths, matcher.cpp:433)");
@@ -496,8 +500,8 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
             lm_off.push_back((int32_t)lm_xy.size());
         }
         int n_lt = 0;
-        if (!latent_empty && t.n_tex > 0) {
-            const afis_texture_view& x = t.tex[0];
+        if (!latent_empty && tex_ind >= 0 && t.n_tex > tex_ind) {
+            const afis_texture_view& x = t.tex[tex_ind];
             if (x.n <= 0 || x.n > 2000 || !x.x || !x.y || !x.ori || !x.des) return fail(ctx, AFIS_EINVAL, "latent texture template: bad view (n must be 1..2000, des required)");
             if (x.des_len != kDes) return fail(ctx, AFIS_EINVAL, "latent texture template: des_len must be 96");
             n_lt = std::min(x.n, kTexMax);                                   // matcher.cpp:544-545
@@ -507,7 +511,7 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
         }
         lt_off.push_back((int32_t)lt_xy.size());
         tile_off.push_back(tile_off.back() + (n_lt + kTileRows - 1) / kTileRows);
-        tex_slot.push_back(t.n_tex > 0 ? t.n_minu : -1);
+        tex_slot.push_back(tex_ind >= 0 && t.n_tex > tex_ind ? t.n_minu : -1);
         lt_max = std::max(lt_max, n_lt);
         grp.h_lt_n.push_back(n_lt);
     }
@@ -703,6 +707,56 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
     d_xy.release(); d_n.release();
     grp.release();
     return rc;
+}
+
+// One2One_matching_all_templates (matcher.cpp:339-374) for one latent against the whole resident gallery: EVERY latent minutiae
+// template vs rolled minutiae template 0 and EVERY latent texture template vs rolled texture template 0.  The kernels are the
+// same; the latent is presented as ceil(max(n_minu/3, n_tex)) pseudo-queries whose three "selected" slots are templates
+// 3j, 3j+1, 3j+2 and whose texture template is j, and the per-part scores are scattered back into the reference's score vector.
+int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, float* scores, int32_t* rolled_status, int32_t* query_status)
+{
+    if (!ctx || !query || !scores) return fail(ctx, AFIS_EINVAL, "afis_match_all_templates: null argument");
+    if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_match_all_templates: commit the gallery first");
+    const int n_minu = query->n_minu, n_tex = query->n_tex;
+    if (n_minu < 0 || n_tex < 0) return fail(ctx, AFIS_EINVAL, "afis_match_all_templates: bad view");
+    const int64_t G = ctx->gal.G;
+    const int width = n_minu + n_tex;
+    if (query_status) *query_status = (n_minu <= 0 && n_tex <= 0) ? AFIS_QUERY_LATENT_EMPTY : AFIS_QUERY_OK;     // :345-348
+    if (rolled_status) for (int64_t g = 0; g < G; ++g) rolled_status[g] = ctx->hg.empty[(size_t)g] ? 2 : 0;        // :350-353
+    for (size_t i = 0; i < (size_t)G * width; ++i) scores[i] = 0.0f;                                             // :342-343
+    if (width == 0 || G == 0) return AFIS_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int n_pq = std::max((n_minu + 2) / 3, n_tex);
+    const int64_t by_mem = std::max<int64_t>(1, ctx->rowmax_budget_bytes / (std::max<int64_t>(1, G) * kTexMax * 8));
+    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch, by_mem));
+    std::vector<float> parts;
+    for (int j0 = 0; j0 < n_pq; j0 += per) {
+        const int nq = std::min(per, n_pq - j0);
+        std::vector<afis_template_view> views((size_t)nq, *query);
+        std::vector<int> spec((size_t)nq * 4);
+        for (int j = 0; j < nq; ++j) {
+            for (int s = 0; s < 3; ++s) spec[(size_t)j * 4 + s] = 3 * (j0 + j) + s < n_minu ? 3 * (j0 + j) + s : -1;
+            spec[(size_t)j * 4 + 3] = j0 + j < n_tex ? j0 + j : -1;
+        }
+        afis_queries q; q.n_q = nq;
+        q.groups.emplace_back();
+        int rc = build_group(ctx, views.data(), nq, q.groups.back(), q.status, spec.data());
+        if (rc == AFIS_OK) {
+            parts.resize((size_t)nq * G * 4);
+            rc = afis_search_resident(ctx, &q, nullptr, parts.data(), nullptr, 0, nullptr, nullptr);
+        }
+        q.groups.back().release();
+        if (rc != AFIS_OK) return rc;
+        for (int j = 0; j < nq; ++j)
+            for (int64_t g = 0; g < G; ++g) {
+                if (ctx->hg.empty[(size_t)g]) continue;                      // rolled empty: the vector stays zero (return 2 before any scorer)
+                const float* p = &parts[((size_t)j * G + g) * 4];
+                float* o = scores + (size_t)g * width;
+                for (int s = 0; s < 3; ++s) if (3 * (j0 + j) + s < n_minu) o[3 * (j0 + j) + s] = p[s];
+                if (j0 + j < n_tex) o[n_minu + j0 + j] = p[3];
+            }
+    }
+    return AFIS_OK;
 }
 
 int afis_search(afis_ctx* ctx, const afis_template_view* queries, int n_q, float* scores, float* parts, int32_t* status,

@@ -45,7 +45,7 @@ class Timing(C.Structure):
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -73,6 +73,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_search_resident.argtypes = [vp, vp, fp, fp, i32p, C.c_int, i64p, fp]
     lib.afis_correspondences.argtypes = [vp, vp, i64p, C.c_int, i32p, C.POINTER(C.c_int16)]
     lib.afis_queries_free.argtypes = [vp, vp]; lib.afis_queries_free.restype = None
+    lib.afis_match_all_templates.argtypes = [vp, vp, fp, i32p, i32p]
     lib.afis_pq_encode.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint8)]
     lib.afis_encode_rolled_dat.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), i32p]
     lib.afis_get_timing.argtypes = [vp, C.POINTER(Timing)]
@@ -256,6 +257,14 @@ class Matcher:
         counts = np.zeros((max(n, 1), 3), np.int32); xy = np.zeros((max(n, 1), 3, 120, 4), np.int16)
         self._chk(self.lib.afis_correspondences(self.ctx, v.arr, _ptr(gi, C.c_int64) if n else None, n, _ptr(counts, C.c_int32), _ptr(xy, C.c_int16)))
         return [[xy[i, s, :counts[i, s]].copy() if counts[i, s] >= 0 else None for s in range(3)] for i in range(n)]
+
+    def One2One_matching_all_templates(self, latent: FPTemplate):
+        """matcher.cpp:339-374 against every gallery template: (query status, rolled status [G], scores [G][n_minu + n_tex])."""
+        v = _Views([latent])
+        G = self.gallery_size; width = len(latent.minu) + len(latent.tex)
+        scores = np.zeros((max(G, 1), max(width, 1)), np.float32); rs = np.zeros(max(G, 1), np.int32); qs = C.c_int32(0)
+        self._chk(self.lib.afis_match_all_templates(self.ctx, v.arr, _ptr(scores, C.c_float), _ptr(rs, C.c_int32), C.byref(qs)))
+        return qs.value, rs[:G], scores[:G, :width] if width else np.zeros((G, 0), np.float32)
 
     def pq_encode(self, des: np.ndarray) -> np.ndarray:
         """TrainedPQEncoder.encode_multi (descriptor_PQ.py:19-27) on the device: [n][96] fp32 -> [n][16] u8."""

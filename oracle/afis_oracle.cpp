@@ -534,6 +534,20 @@ int pair_score(const Latent& L, const Rolled& R, const Codebook& cb, int tie_mod
     return 0;
 }
 
+// One2One_matching_all_templates, matcher.cpp:339-374: score[i] = minutiae scorer of latent template i vs rolled template 0 for
+// every i (while the rolled print has a minutiae template), score[nLm + t] = texture scorer of latent texture template t vs
+// rolled texture template 0; 1 = latent without any template, 2 = rolled without any template (vector stays zero).
+int all_templates_score(const Latent& L, const Rolled& R, const Codebook& cb, int tie_mode, std::vector<float>& score)
+{
+    int nLm = (int)L.minu.size(), nLt = (int)L.tex.size(), nRm = (int)R.minu.size(), nRt = (int)R.tex.size();
+    score.assign(nLm + nLt, 0.f);
+    if (nLm <= 0 && nLt <= 0) return 1;
+    if (nRm <= 0 && nRt <= 0) return 2;
+    for (int i = 0; i < nLm && nRm; ++i) score[i] = minutiae_score(L.minu[i], R.minu[0], cb, tie_mode, nullptr);
+    for (int i = 0; i < nLt && nRt > 0; ++i) score[i + nLm] = texture_score(L.tex[i], R.tex[0], cb, tie_mode, nullptr);
+    return 0;
+}
+
 static bool read_file(const char* path, std::vector<uint8_t>& buf)
 {
     std::ifstream is(path, std::ifstream::binary);
@@ -641,6 +655,15 @@ void orc_pq_encode(void* cbp, const float* des, int n, int des_len, unsigned cha
             codes[(size_t)i * cb.M + j] = (unsigned char)best;
         }
     }
+}
+
+// matcher.cpp:339-374; out capacity >= n_minu + n_tex of the latent; returns the reference's code (0, 1, 2)
+int orc_all_templates(void* cb, void* lat, void* rol, int tie_mode, float* out)
+{
+    std::vector<float> sc;
+    int rc = all_templates_score(*(Latent*)lat, *(Rolled*)rol, *(Codebook*)cb, tie_mode, sc);
+    memcpy(out, sc.data(), sc.size() * sizeof(float));
+    return rc;
 }
 
 // S10: per-pair scores out[5] = s0,s1,s2,tex,final

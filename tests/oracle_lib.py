@@ -37,6 +37,7 @@ class Oracle:
         L.orc_rolled_codes.restype = C.POINTER(C.c_uint8); L.orc_rolled_codes.argtypes = [vp, C.c_int]
         L.orc_points.restype = C.c_int; L.orc_points.argtypes = [vp, C.c_int, C.c_int, ip, ip, fp]
         L.orc_build_lut.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+        L.orc_all_templates.restype = C.c_int; L.orc_all_templates.argtypes = [vp, vp, vp, C.c_int, fp]
         L.orc_pq_encode.restype = None; L.orc_pq_encode.argtypes = [vp, fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
         L.orc_pair_score.restype = C.c_int; L.orc_pair_score.argtypes = [vp, vp, vp, C.c_int, fp]
         L.orc_texture_rowmax.restype = C.c_int; L.orc_texture_rowmax.argtypes = [vp, vp, vp, fp, ip]
@@ -94,6 +95,11 @@ class Oracle:
         codes = np.zeros((des.shape[0], 16), np.uint8)
         self.lib.orc_pq_encode(cb, des.ctypes.data_as(C.POINTER(C.c_float)), des.shape[0], des.shape[1], codes.ctypes.data_as(C.POINTER(C.c_ubyte)))
         return codes
+
+    def all_templates(self, cb, lat, rol, width, tie_mode=1):
+        out = np.zeros(max(1, width), np.float32)
+        rc = self.lib.orc_all_templates(cb, lat, rol, tie_mode, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return rc, out[:width]
 
     def trace(self, cb, lat, rol, which, stage, tie_mode=1):
         sim = np.zeros(256, np.float32); li = np.zeros(256, np.int32); ri = np.zeros(256, np.int32)

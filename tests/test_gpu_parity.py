@@ -228,6 +228,45 @@ def test_gallery_container_equals_directory(codebook_bytes, cb, small, tmp_path)
             assert (tmp_path / "o1" / n).read_bytes() == (tmp_path / "o2" / n).read_bytes(), n
 
 
+def test_all_templates_mode(codebook_bytes, cb, oracle, small):
+    """One2One_matching_all_templates (matcher.cpp:339-374) — every latent minutiae template and every latent
+    texture template — against the oracle, incl. a latent with two texture templates, one without texture, and empty prints."""
+    lats, gal = small
+    rng = np.random.default_rng(77)
+    two_tex = T.FPTemplate(minu=lats[0].minu[:7], tex=[lats[0].tex[0], S.make_latent(rng, n_tex_lo=200, n_tex_hi=260).tex[0]])
+    no_tex = T.FPTemplate(minu=lats[1].minu[:4], tex=[])
+    g = list(gal[:6]) + [T.FPTemplate(), T.FPTemplate(minu=gal[0].minu, tex=[]), T.FPTemplate(minu=[], tex=gal[1].tex)]
+    m = M.Matcher(codebook_bytes)
+    for r in g:                                          # through the file format, as the oracle (a rolled file without minutiae
+        m.gallery_add_dat(T.write_rolled(r))             # templates carries no texture either, descriptor_PQ.py:190-193)
+    m.gallery_commit(0)
+    ocb = oracle.codebook(codebook_bytes)
+    hr = [oracle.rolled(T.write_rolled(r))[0] for r in g]
+    for L in (lats[0], two_tex, no_tex):
+        qs, rs, sc = m.One2One_matching_all_templates(L)
+        hl, _ = oracle.latent(ocb, T.write_latent(L))
+        width = len(L.minu) + len(L.tex)
+        assert qs == 0 and sc.shape == (len(g), width)
+        n_pos = 0
+        for gi in range(len(g)):
+            rc, want = oracle.all_templates(ocb, hl, hr[gi], width, tie_mode=1)
+            assert rs[gi] == (2 if rc == 2 else 0)
+            err = np.abs(sc[gi] - want) / np.maximum(1, np.abs(want))
+            assert (err <= 1e-3).all(), (gi, sc[gi], want)
+            assert np.array_equal(sc[gi].view(np.uint32), want.view(np.uint32))
+            n_pos += int((want > 0).sum())
+        assert n_pos > 0
+    qs, rs, sc = m.One2One_matching_all_templates(T.FPTemplate())
+    assert qs == 1 and sc.shape == (len(g), 0)
+    # the selected-template scores are columns 26, 2, 11 and n_minu of the all-template vector
+    r = m.search([lats[0]], k=0, want_parts=True)
+    qs, rs, sc = m.One2One_matching_all_templates(lats[0])
+    p = r["parts"].reshape(len(g), 4)
+    ok = rs == 0
+    assert np.array_equal(p[ok][:, :3], sc[ok][:, [26, 2, 11]]) and np.array_equal(p[ok][:, 3], sc[ok][:, len(lats[0].minu)])
+    m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
