@@ -71,14 +71,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test mode: every rank uses GPU 0 (validates the N>1 path on a 1-GPU box)")
+    ap.add_argument("--force-dist", action="store_true", help="test mode: initialise torch.distributed and run the exchange step even when WORLD_SIZE is 1")
     a = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     gpu = 0 if a.share_gpu else local
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":       # RCCL's version banner goes to stdout; keep stdout to the one JSON line
+            del os.environ["NCCL_DEBUG"]
         torch.cuda.set_device(gpu)
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
@@ -113,12 +118,12 @@ def main():
 
     def step():
         r = m.search_resident(qh, k=a.k)
-        idx, sc = SH.gather_topk(r["topk_idx"], r["topk_score"], a.k, device=dev)
+        idx, sc = SH.gather_topk(r["topk_idx"], r["topk_score"], a.k, device=dev, force=a.force_dist)
         return idx, sc
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -133,7 +138,7 @@ def main():
         tm_acc = tm if tm_acc is None else {k_: tm_acc[k_] + v for k_, v in tm.items()}
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -184,12 +189,13 @@ def main():
             out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": cores, "kind": "port", "sample": sample,
                                    "pairs_per_s": round(pps, 1), "reference_setting_8_threads_static16_queries_per_s": round(pps8 / G, 6)}
             out["speedup_vs_cpu_baseline"] = round(value / (pps / G), 1)
-        print(json.dumps(out), flush=True)
     m.free_queries(qh)
     m.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)                              # the last (and only) line on stdout
 
 
 if __name__ == "__main__":

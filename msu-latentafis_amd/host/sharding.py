@@ -43,12 +43,12 @@ def merge_topk(idx: np.ndarray, score: np.ndarray, k: int) -> Tuple[np.ndarray, 
     return out_i, out_s
 
 
-def gather_topk(idx: np.ndarray, score: np.ndarray, k: int, device=None):
+def gather_topk(idx: np.ndarray, score: np.ndarray, k: int, device=None, force: bool = False):
     """The one exchange step: all_gather of [Q, kk] (int64 idx, f32 score) from every rank, then merge on every rank.
     Messages are tiny (24 x 12 B per query per rank); this is latency-, not bandwidth-bound."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return merge_topk(idx[None], score[None], k)
     world = dist.get_world_size()
     dev = device if device is not None else "cpu"
