@@ -811,6 +811,9 @@ int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, read_phase_cycles(out32, reset != 0));
+    unsigned long long gph[16];                          // graph.hip phases (only in PHASE_TIMING builds) reported in slots 0..15 + 32.. is not
+    HIPCHK(ctx, read_graph_phase_cycles(gph, reset != 0)); // possible with a 32-slot array: they overlay the unused slots 5..15 and 21..25
+    for (int i = 0; i < 8; ++i) { out32[5 + i] = gph[i]; out32[21 + i] = gph[8 + i]; }
     return AFIS_OK;
 }
 

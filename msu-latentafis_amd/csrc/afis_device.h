@@ -79,6 +79,7 @@ hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* part
 // optional in-kernel phase timers (build with PHASE_TIMING=1); zeros otherwise
 hipError_t launch_pq_encode(const float* des, long long n, const float* codewords, uint8_t* codes, hipStream_t stream);
 hipError_t read_phase_cycles(unsigned long long* out32, bool reset);
+hipError_t read_graph_phase_cycles(unsigned long long* out16, bool reset);
 
 // debug tap: LUT in the reference layout [n][16][256]
 hipError_t launch_lut_reference_layout(const float* des, int n, const float* codewords, float* out, hipStream_t stream);

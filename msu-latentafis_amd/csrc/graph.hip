@@ -29,6 +29,18 @@ namespace afis {
 #define AFIS_PI 3.1415926   /* matching/include.h:22 — a double literal; comparisons against it are in double */
 typedef unsigned long long u64;
 
+// optional per-phase cycle accounting (make PHASE_TIMING=1): slots 0..7 minutiae lists, 8..15 texture lists.  The counters
+// are global atomics, and a global LOAD that follows them (the orientation gather of the angle stage) waits for them to retire,
+// so that phase reads far too high; the distance stage's split (pair predicate ~25 %, power iterations ~60 %) is reliable.
+#ifdef AFIS_PHASE_TIMING
+__device__ u64 g_graph_phase[16];
+#define GPH_INIT() u64 gph_t0 = __builtin_readcyclecounter()
+#define GPH(i) do { if (threadIdx.x == 0) { const u64 t1_ = __builtin_readcyclecounter(); atomicAdd(&g_graph_phase[(i)], t1_ - gph_t0); gph_t0 = t1_; } } while (0)
+#else
+#define GPH_INIT() do {} while (0)
+#define GPH(i) do {} while (0)
+#endif
+
 __device__ __forceinline__ uint32_t g_ord_f32(float v)
 {
     v = v + 0.0f;                                   // -0 -> +0 so that equal floats get equal keys
@@ -223,6 +235,8 @@ template <class SM, bool LOOKUP, int ITERS>
 __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
 {
     constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX, CACHE = SM::CACHE;
+    constexpr int PH = LOOKUP ? 8 : 0;
+    GPH_INIT();
     const int lane = threadIdx.x;
     for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
     Pt me[U];
@@ -253,6 +267,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
         }
     }
     WSYNC();
+    GPH(PH + 0);
     // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle)
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -288,7 +303,9 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
         for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; if (t < num) sm.b[t] = sm.cc[t] * scale; }
         WSYNC();
     }
+    GPH(PH + 1);
     sort_scores(sm, num);
+    GPH(PH + 2);
     const int nsel = greedy(sm, num, 0.0001, [&sm, table](int a, int o) {
         if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
         float dist;
@@ -296,6 +313,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
         return !((double)h_value(dist) < 0.00001);
     });
     compact(sm, nsel);
+    GPH(PH + 3);
     return nsel;
 }
 
@@ -343,6 +361,8 @@ template <class SM>
 __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori)
 {
     constexpr int W = SM::W;
+    constexpr int PH = SM::NMAX > 128 ? 8 : 0;
+    GPH_INIT();
     const int lane = threadIdx.x;
     for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
     for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
@@ -364,6 +384,7 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
         }
     }
     WSYNC();
+    GPH(PH + 4);
     for (int it = 0; it < 5; ++it) {                                       // :1563-1581
         for (int t = lane; t < num; t += 64) {
             float s1 = 0.0f;
@@ -379,9 +400,11 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
         for (int t = lane; t < num; t += 64) sm.b[t] = sm.cc[t] * sum;
         WSYNC();
     }
+    GPH(PH + 5);
     sort_scores(sm, num);
     const int nsel = greedy(sm, num, 0.001, [&sm](int a, int o) { return (sm.hb[a][o >> 5] >> (o & 31)) & 1u; });
     compact(sm, nsel);
+    GPH(PH + 6);
     return nsel;
 }
 
@@ -403,7 +426,10 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
 // =====================================================================================================================
 // texture lists: S7 (top-200 rows of the ADC row maxima) + S8b + S9
 // =====================================================================================================================
-typedef WaveSmem<kTopTex, 4> TexSmem;
+#ifndef AFIS_TEX_CACHE
+#define AFIS_TEX_CACHE 4
+#endif
+typedef WaveSmem<kTopTex, AFIS_TEX_CACHE> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
 
 __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
@@ -498,7 +524,10 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // =====================================================================================================================
 // minutiae lists (produced by k_minu_cands, already in rank order): S8a + S9
 // =====================================================================================================================
-typedef WaveSmem<kTopMinu, 6> MinuGraphSmem;
+#ifndef AFIS_MINU_CACHE
+#define AFIS_MINU_CACHE 6
+#endif
+typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE> MinuGraphSmem;
 
 // corr_out / corr_n (optional): the surviving correspondences of every task as (lx, ly, rx, ry), matcher.cpp:497-505
 __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
@@ -547,6 +576,19 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
     hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n);
     return hipGetLastError();
+}
+
+hipError_t read_graph_phase_cycles(unsigned long long* out16, bool reset)
+{
+#ifdef AFIS_PHASE_TIMING
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_graph_phase), 16 * sizeof(u64));
+    if (e != hipSuccess) return e;
+    if (reset) { u64 z[16] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_graph_phase), z, sizeof(z)); }
+    return e;
+#else
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    return hipSuccess;
+#endif
 }
 
 }  // namespace afis

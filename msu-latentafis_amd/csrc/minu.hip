@@ -251,11 +251,12 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 //       exactly "norm descending, index ascending" and no tie handling is needed.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kFastU = kFastN / kThreads;            // 32 keys per lane at most
+constexpr int kStage1Cap = 160;                      // stage-1 survivors per wave: a superset of the wave's 120 largest keys
 struct FastSmem {
     float simi[kFastN];                               // 32 KB
     float rowsum[kFastL];
     float colsum[kFastR];
-    u64 list[kWaves * kTopMinu];                      // stage-1 survivors
+    u64 list[kWaves * kStage1Cap];                    // stage-1 survivors
     u64 top[128];                                     // stage-2 survivors
     int counts[kWaves];
 };
@@ -303,20 +304,32 @@ __device__ __forceinline__ int wave_stage1(const FastSmem& sm, u64* list, int n,
         }
     }
     const int Kw = n_own < kTopMinu ? n_own : kTopMinu;
+    int n_out = 0;
     if (Kw > 0) {
-        // norm lies in [0, 1): every key is in [0x80000000, 0xBF800000), so bit 31 is set and bit 30 clear
+        // norm lies in [0, 1): every key is in [0x80000000, 0xBF800000), so bit 31 is set and bit 30 clear.
+        // Stage 2 only needs a SUPERSET of the wave's Kw largest keys, so the bit-by-bit threshold search stops as soon as the
+        // keys >= T fit the wave's list (kStage1Cap): typically after 10-14 of the 30 bits.
         uint32_t T = 0x80000000u;
-        for (int bit = 29; bit >= 0; --bit) {
+        int c_ge = n_own;                                                // keys >= T (padding keys are 0 < T)
+        for (int bit = 29; bit >= 0 && c_ge > kStage1Cap; --bit) {
             const uint32_t cand = T | (1u << bit);
             int cnt = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) cnt += wave_popc(rk[u] >= cand);
-            if (cnt >= Kw) T = cand;
+            if (cnt >= Kw) { T = cand; c_ge = cnt; }
         }
+        int need = kStage1Cap;                                           // of the keys equal to T (all of them if everything fits)
         int n_gt = 0;
+        if (c_ge > kStage1Cap) {                                         // T is exact and too many keys equal it: keep the lowest indices
 #pragma unroll
-        for (int u = 0; u < U; ++u) n_gt += wave_popc(rk[u] > T);
-        const int need = Kw - n_gt;                                      // keys equal to T: keep the lowest element indices
+            for (int u = 0; u < U; ++u) n_gt += wave_popc(rk[u] > T);
+            need = Kw - n_gt;
+            n_out = Kw;
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) n_gt += wave_popc(rk[u] > T);
+            n_out = c_ge;
+        }
         int base_gt = 0, base_eq = 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {                                    // (u, lane) ascending = element index ascending
@@ -330,7 +343,7 @@ __device__ __forceinline__ int wave_stage1(const FastSmem& sm, u64* list, int n,
             base_gt += __popcll(mg); base_eq += __popcll(me);
         }
     }
-    return Kw;
+    return n_out;
 }
 
 __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
@@ -417,16 +430,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, Gal
         const int topN = n < kTopMinu ? n : kTopMinu;
         // number of key slots per lane actually needed: 8 (n <= 2048), 16 (n <= 4096) or 32
         int Kw;
-        if (n <= 8 * kThreads) Kw = wave_stage1<8>(sm, sm.list + wave * kTopMinu, n, nR, wave, lane);
-        else if (n <= 16 * kThreads) Kw = wave_stage1<16>(sm, sm.list + wave * kTopMinu, n, nR, wave, lane);
-        else Kw = wave_stage1<kFastU>(sm, sm.list + wave * kTopMinu, n, nR, wave, lane);
+        if (n <= 8 * kThreads) Kw = wave_stage1<8>(sm, sm.list + wave * kStage1Cap, n, nR, wave, lane);
+        else if (n <= 16 * kThreads) Kw = wave_stage1<16>(sm, sm.list + wave * kStage1Cap, n, nR, wave, lane);
+        else Kw = wave_stage1<kFastU>(sm, sm.list + wave * kStage1Cap, n, nR, wave, lane);
         PHASE(18);
         if (lane == 0) sm.counts[wave] = Kw;
         __syncthreads();
         PHASE(19);
-        // ---- stage 2 (wave 0): the topN largest of the <= 480 survivors, then rank them ----
+        // ---- stage 2 (wave 0): the topN largest of the <= 640 survivors, then rank them ----
         if (wave == 0) {
-            constexpr int V = kWaves * kTopMinu / 64 + 1;                     // 8 keys per lane
+            constexpr int V = kWaves * kStage1Cap / 64;                       // 10 keys per lane
             u64 d[V];
             int off[kWaves + 1]; off[0] = 0;
 #pragma unroll
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, Gal
                 const int p = v * 64 + lane;                                  // position in the concatenation of the four lists
                 u64 key = 0;
 #pragma unroll
-                for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.list[w * kTopMinu + p - off[w]];
+                for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.list[w * kStage1Cap + p - off[w]];
                 d[v] = key;
             }
             // topN largest composites = norm key descending, element index ascending.  Threshold search on the 32-bit keys;

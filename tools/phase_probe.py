@@ -1,12 +1,27 @@
+"""Per-phase cycle shares of the tail kernels.  Needs a library built with -DAFIS_PHASE_TIMING:
+     cd msu-latentafis_amd/csrc && for f in graph minu; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
+        -DAFIS_PHASE_TIMING -c $f.hip -o /tmp/${f}_ph.o; done && hipcc --offload-arch=gfx950 -shared -fPIC adc.o /tmp/graph_ph.o \
+        /tmp/minu_ph.o pq_encode.o afis_api.o template_io.o -o ../../tools/libafis_phase.so
+   Caveat (graph kernels): the counters are global atomics; a global load that follows them waits for them, so the angle
+   stage's share is inflated.  Use the shares inside the distance stage and inside the candidate kernel."""
 import sys, importlib
 sys.path.insert(0, "/root/repo")
-import numpy as np
 T = importlib.import_module("msu-latentafis_amd.host.templates"); S = importlib.import_module("msu-latentafis_amd.host.synth"); M = importlib.import_module("msu-latentafis_amd.host.matcher")
-cbb = open("/root/repo/tests/golden/codebook_EmbeddingSize_96_stride_16_subdim_6.dat","rb").read(); cb = T.Codebook.from_bytes(cbb)
+cbb = open("/root/repo/tests/golden/codebook_EmbeddingSize_96_stride_16_subdim_6.dat", "rb").read(); cb = T.Codebook.from_bytes(cbb)
 G, Q = 10000, 4
 lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb); S.plant_mates(1, gal, cb, lats)
-m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0); qh = m.upload_queries(lats)
+m = M.Matcher(cbb, lib_path=sys.argv[1] if len(sys.argv) > 1 else "/root/repo/tools/libafis_phase.so")
+m.gallery_add_packed(gal); m.gallery_commit(0); qh = m.upload_queries(lats)
 m.search_resident(qh); m.phase_cycles(True)
 m.search_resident(qh); ph = m.phase_cycles(True); tm = m.timing()
-tot = sum(ph); print("timing", {k: round(v,2) for k,v in tm.items() if k.endswith("ms")})
-print("phase Mcycles:", [round(p/1e6) for p in ph[:24]])
+print("timing", {k: round(v, 2) for k, v in tm.items() if k.endswith("ms")})
+names = {16: "fast: load+gemm", 17: "fast: sums/norm", 18: "fast: stage1", 19: "fast: barrier", 20: "fast: stage2 (wave 0)",
+         5: "minu graph: dist H bits", 6: "minu graph: dist power iters", 7: "minu graph: dist sort", 8: "minu graph: dist greedy+compact",
+         9: "minu graph: angle H bits (inflated)", 10: "minu graph: angle iters", 11: "minu graph: angle sort+greedy",
+         21: "tex graph: dist H bits", 22: "tex graph: dist power iters", 23: "tex graph: dist sort", 24: "tex graph: dist greedy+compact",
+         25: "tex graph: angle H bits (inflated)", 26: "tex graph: angle iters", 27: "tex graph: angle sort+greedy"}
+for grp, idxs in (("minutiae candidates", (16, 17, 18, 19, 20)), ("minutiae graph", range(5, 12)), ("texture graph", range(21, 28))):
+    tot = sum(ph[i] for i in idxs) or 1
+    print(grp, "total Mcycles", round(tot / 1e6))
+    for i in idxs:
+        print("   %-36s %6.1f %%" % (names[i], 100.0 * ph[i] / tot))
