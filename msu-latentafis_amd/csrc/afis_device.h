@@ -56,6 +56,23 @@ struct QueryDev {
 
 // ---- launchers (each enqueues on `stream`, returns hipGetLastError()) ------------------------------------------
 // S4: LUT tiles.  variant selects the in-tile layout the ADC kernel of the same variant reads.
+#ifdef __HIPCC__
+// Correctly rounded fp32 square root for x == 0 or 1 <= x < 2^64 (squared distances): the hardware v_sqrt_f32 is only accurate to
+// 1 ulp (and HIP's __fsqrt_rn IS that instruction, not a correctly rounded sqrt), so the result is settled between its two
+// neighbours with two exact residuals — the core of LLVM's own correctly rounded sqrtf expansion, without the denormal scaling
+// and the inf/nan handling this argument range does not need.  Checked against the definition of round-to-nearest for every
+// float in the range by tools/ubench/sqrt_exact.hip.
+__device__ __forceinline__ float sqrt_rn_pos(float x)
+{
+    float r = __builtin_amdgcn_sqrtf(x);
+    const float dn = __int_as_float(__float_as_int(r) - 1), up = __int_as_float(__float_as_int(r) + 1);
+    const float e_dn = __builtin_fmaf(-dn, r, x), e_up = __builtin_fmaf(-up, r, x);
+    r = e_dn <= 0.0f ? dn : r;
+    r = e_up > 0.0f ? up : r;
+    return r;
+}
+#endif
+
 hipError_t launch_lut_build(const QueryDev& q, const float* codewords, float* lut_tiles, int variant, hipStream_t stream);
 // S5+S6: ADC similarity + per-row (max, first argmax) for queries [q0, q0+nq) against gallery templates.
 hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,

@@ -204,14 +204,14 @@ __device__ __forceinline__ bool pair_dist(const Pt& a, const Pt& o, const float*
         // table_dist[dx*50+dy] = (float)sqrt((16 dx)^2 + (16 dy)^2) (matcher.cpp:45-56).  The argument is an exact integer
         // < 2^24, and a double sqrt rounded to float equals the correctly rounded float sqrt, so the table entry is
         // recomputed bit-exactly instead of being fetched (tests/test_host.py checks all 2500 entries).
-        d1 = __fsqrt_rn((float)(256 * (dx1 * dx1 + dy1 * dy1)));
-        d2 = __fsqrt_rn((float)(256 * (dx2 * dx2 + dy2 * dy2)));
+        d1 = sqrt_rn_pos((float)(256 * (dx1 * dx1 + dy1 * dy1)));
+        d2 = sqrt_rn_pos((float)(256 * (dx2 * dx2 + dy2 * dy2)));
         (void)table;
     } else {
         const float dx1 = (float)(a.lx - o.lx), dx2 = (float)(a.rx - o.rx), dy1 = (float)(a.ly - o.ly), dy2 = (float)(a.ry - o.ry);
         const float p = dx1 * dx1, q = dy1 * dy1, r = dx2 * dx2, s = dy2 * dy2;
-        d1 = __fsqrt_rn(p + q);                                                                      // correctly rounded, as sqrtf
-        d2 = __fsqrt_rn(r + s);
+        d1 = sqrt_rn_pos(p + q);                                                                     // correctly rounded, as sqrtf
+        d2 = sqrt_rn_pos(r + s);
     }
     dist = fabsf(d1 - d2);
     return ok;
