@@ -192,6 +192,13 @@ int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, i
 int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, int64_t g,
                               float* val, int32_t* arg, int32_t* n_rows);
 
+/* S3 / S7 / S8 / S9: the correspondence list of (query, gallery template g) inside one scorer, as (sim, latent index, rolled
+ * index) triples in list order.  which: 0 = texture scorer, 1..3 = minutiae scorer of selected latent template 27 / 3 / 12;
+ * stage: 0 = the candidates (top 120 / top 200), 1 = after the distance filter, 2 = after the angle filter.  Capacity 200.
+ * *n = -1 when the reference does not run that scorer for the pair. */
+int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_t g, int which, int stage,
+                          float* sim, int32_t* li, int32_t* ri, int32_t* n);
+
 /* In-kernel phase timers (only when the library is built with PHASE_TIMING=1; all zeros otherwise): 32 cycle counters
  * accumulated since the last reset.  Development aid. */
 int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset);

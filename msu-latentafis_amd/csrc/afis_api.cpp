@@ -601,10 +601,10 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 65536 ? 512 : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32)));
             HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-            HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), s));
+            HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
             HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
-            HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, s));
+            HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
@@ -683,7 +683,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
             int32_t* cand_n = ctx->cand_n.as<int32_t>() + (size_t)i * 3;
             if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, cands, cand_n, s) != hipSuccess ||
                 launch_graph_minutiae(grp.dev, one, cands, cand_n, ctx->parts.as<float>() + (size_t)i * 4,
-                                      d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, s) != hipSuccess)
+                                      d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, nullptr, nullptr, 2, s) != hipSuccess)
                 err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: kernel launch failed");
         }
         if (err == AFIS_OK) {
@@ -863,6 +863,63 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
     }
     grp.release();
     return AFIS_OK;
+}
+
+// Parity tap: the correspondence list of one (latent, gallery template) pair after a stage of a scorer.
+//   which 0 = texture scorer, 1..3 = minutiae scorer of selected template 27 / 3 / 12;  stage 0 = candidates (S3 / S7),
+//   1 = after the distance filter (S8), 2 = after the angle filter (S9).  *n = -1 when the scorer is not run for the pair.
+int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_t gidx, int which, int stage,
+                          float* sim, int32_t* li, int32_t* ri, int32_t* n)
+{
+    if (!ctx || !query || !sim || !li || !ri || !n || which < 0 || which > 3 || stage < 0 || stage > 2) return fail(ctx, AFIS_EINVAL, "afis_debug_stage_list: bad argument");
+    if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_debug_stage_list: commit the gallery first");
+    if (gidx < 0 || gidx >= ctx->gal.G) return fail(ctx, AFIS_EINVAL, "afis_debug_stage_list: gallery index out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    QueryGroup grp; std::vector<int32_t> st;
+    int rc = build_group(ctx, query, 1, grp, st);
+    if (rc != AFIS_OK) { grp.release(); return rc; }
+    *n = -1;
+    DevBuf d_out, d_n;
+    auto body = [&]() -> int {
+        if (st[0] != AFIS_QUERY_OK) return AFIS_OK;
+        const QueryDev& d = grp.dev;
+        GalleryDev one = ctx->gal;
+        one.G = 1; one.minu_off += gidx; one.tex_off += gidx; one.tex_cf_blk += gidx; one.empty += gidx;
+        hipStream_t s = ctx->stream;
+        HIPCHK(ctx, d_out.ensure(3 * (size_t)kTopTex * sizeof(MinuCand)));
+        HIPCHK(ctx, d_n.ensure(3 * 4));
+        HIPCHK(ctx, hipMemsetAsync(d_n.p, 0xff, 12, s));
+        HIPCHK(ctx, ctx->parts.ensure(16));
+        int slot = 0, cap = kTopTex;
+        if (which == 0) {
+            if (d.n_tiles <= 0) return AFIS_OK;
+            HIPCHK(ctx, ctx->lut.ensure((size_t)d.n_tiles * kTileFloats * 4));
+            HIPCHK(ctx, ctx->rm_val.ensure((size_t)d.lt_pad * 4)); HIPCHK(ctx, ctx->rm_arg.ensure((size_t)d.lt_pad * 4));
+            HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
+            HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+            HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(),
+                                             d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
+        } else {
+            slot = which - 1; cap = kTopMinu;
+            const size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+            HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * 64));
+            HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12));
+            HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, grp.max_nL, ctx->max_nR, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
+            HIPCHK(ctx, launch_graph_minutiae(d, one, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr,
+                                              d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
+        }
+        std::vector<MinuCand> h((size_t)3 * kTopTex); int32_t hn[3] = {-1, -1, -1};
+        HIPCHK(ctx, hipMemcpyAsync(h.data(), d_out.p, h.size() * sizeof(MinuCand), hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(hn, d_n.p, 12, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        if (ctx->hg.empty[(size_t)gidx]) return AFIS_OK;                   // rolled empty: no scorer runs
+        *n = hn[slot];
+        for (int t = 0; t < hn[slot]; ++t) { const MinuCand& c = h[(size_t)slot * cap + t]; sim[t] = c.sim; li[t] = c.li; ri[t] = c.ri; }
+        return AFIS_OK;
+    };
+    rc = body();
+    d_out.release(); d_n.release(); grp.release();
+    return rc;
 }
 
 }  // extern "C"

@@ -81,7 +81,7 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
 struct MinuCand { float sim; short li, ri; };
 // S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
-                                const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream);
+                                const float* rm_val, const int32_t* rm_arg, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
 // (task = (q*3+s)*G + g)
 // Pairs with <= 64 latent and <= 128 rolled minutiae go through an LDS/scalar-cache fast kernel, the rest through the tiled generic one.
@@ -89,7 +89,7 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
                              int max_nL, int max_nR, int force_generic, MinuCand* cands, int32_t* cand_n, hipStream_t stream);
 // S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
-                                 float* parts, short4* corr_out, int32_t* corr_n, hipStream_t stream);
+                                 float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S10: fusion -> scores[q*G+g]
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 

@@ -411,16 +411,29 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
 template <class SM, bool LOOKUP, int ITERS>
 __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
-                                             const float* __restrict__ rori, int& n_survivors)
+                                             const float* __restrict__ rori, int& n_survivors, int stop_after = 2)
 {
-    n_survivors = 0;
+    n_survivors = num;                                                     // stop_after 0: the candidate list itself (S3 / S7)
+    if (stop_after == 0) return 0.0f;
     num = dist_filter<SM, LOOKUP, ITERS>(sm, num, table);
+    n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
+    if (stop_after == 1) return 0.0f;
+    n_survivors = 0;
     if (num < 2) return 0.0f;
     num = angle_filter(sm, num, lori, rori);
     n_survivors = num;                                                     // sm.sim/li/ri/xy[0..num) = corr3 in the reference's order
     float score = 0.0f;                                                    // :508-514 / :775-781
     for (int i = 0; i < num; ++i) score += sm.sim[i];
     return score;
+}
+
+// parity tap (tests only): the list a task holds after stage `stage` (0 = candidates, 1 = after S8, 2 = after S9)
+struct GraphTap { MinuCand* out; int32_t* n; int stage; };
+template <class SM>
+__device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, long long task, int n, int cap)
+{
+    for (int t = threadIdx.x; t < n; t += 64) { MinuCand c; c.sim = sm.sim[t]; c.li = sm.li[t]; c.ri = sm.ri[t]; tap.out[(size_t)task * cap + t] = c; }
+    if (threadIdx.x == 0) tap.n[task] = n;
 }
 
 // =====================================================================================================================
@@ -434,7 +447,7 @@ constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the
 
 __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
                                                       const float* __restrict__ rm_val, const int32_t* __restrict__ rm_arg,
-                                                      float* __restrict__ parts)
+                                                      float* __restrict__ parts, GraphTap tap)
 {
     __shared__ TexSmem sm;
     const int lane = threadIdx.x;
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
         const int l0 = q.lt_off[qi], n_lt = q.lt_off[qi + 1] - l0;
         const int r0 = g.tex_off[gi], n_rt = g.tex_off[gi + 1] - r0;
         float* out = parts + (size_t)task * 4 + 3;
-        if (n_lt <= 0 || n_rt <= 0) { if (lane == 0) *out = 0.0f; continue; }   // matcher.cpp:411: scorer not called
+        if (n_lt <= 0 || n_rt <= 0) { if (lane == 0) { *out = 0.0f; if (tap.out) tap.n[task] = -1; } continue; }   // matcher.cpp:411: scorer not called
         const size_t o = (size_t)task * q.lt_pad;
         int num;
         if (n_lt > kTopTex) {                                            // :736-747: the 200 rows with the largest maxima
@@ -505,19 +518,20 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
         }
         WSYNC();
         int n_surv;
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv);   // :759, :767
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv, tap.out ? tap.stage : 2);   // :759, :767
         if (lane == 0) *out = score;
+        if (tap.out) tap_write(tap, sm, task, n_surv, kTopTex);
         WSYNC();
     }
 }
 
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
-                                const float* rm_val, const int32_t* rm_arg, float* parts, hipStream_t stream)
+                                const float* rm_val, const int32_t* rm_arg, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * g.G;
     if (n_tasks <= 0) return hipSuccess;
     const int grid = (int)(n_tasks < 16384 ? n_tasks : 16384);
-    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, parts);
+    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, parts, GraphTap{tap_out, tap_n, tap_stage});
     return hipGetLastError();
 }
 
@@ -532,7 +546,7 @@ typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE> MinuGraphSmem;
 // corr_out / corr_n (optional): the surviving correspondences of every task as (lx, ly, rx, ry), matcher.cpp:497-505
 __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
                                                        const int32_t* __restrict__ cand_n, float* __restrict__ parts,
-                                                       short4* __restrict__ corr_out, int32_t* __restrict__ corr_n)
+                                                       short4* __restrict__ corr_out, int32_t* __restrict__ corr_n, GraphTap tap)
 {
     __shared__ MinuGraphSmem sm;
     const int lane = threadIdx.x;
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         const int qi = qs / 3, s = qs - qi * 3;
         float* out = parts + ((size_t)qi * g.G + gi) * 4 + s;
         const int num = cand_n[task];
-        if (num <= 0) { if (lane == 0) { *out = 0.0f; if (corr_n) corr_n[task] = 0; } continue; }   // matcher.cpp:400-404
+        if (num <= 0) { if (lane == 0) { *out = 0.0f; if (corr_n) corr_n[task] = 0; if (tap.out) tap.n[task] = -1; } continue; }   // matcher.cpp:400-404
         const int l0 = q.lm_off[qs], r0 = g.minu_off[gi];
         const MinuCand* c = cands + (size_t)task * kTopMinu;
         for (int t = lane; t < num; t += 64) {
@@ -555,8 +569,9 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         }
         WSYNC();
         int n_surv;
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, n_surv);   // :492, :495
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, n_surv, tap.out ? tap.stage : 2);   // :492, :495
         if (lane == 0) *out = score;
+        if (tap.out) tap_write(tap, sm, task, n_surv, kTopMinu);
         if (corr_out) {
             for (int t = lane; t < n_surv; t += 64) {
                 const Pt p = unpack_xy(sm.xy[t]);
@@ -569,12 +584,12 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
 }
 
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
-                                 float* parts, short4* corr_out, int32_t* corr_n, hipStream_t stream)
+                                 float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
-    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n);
+    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, GraphTap{tap_out, tap_n, tap_stage});
     return hipGetLastError();
 }
 

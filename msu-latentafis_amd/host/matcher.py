@@ -45,7 +45,7 @@ class Timing(C.Structure):
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_phase_cycles"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -74,6 +74,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_correspondences.argtypes = [vp, vp, i64p, C.c_int, i32p, C.POINTER(C.c_int16)]
     lib.afis_queries_free.argtypes = [vp, vp]; lib.afis_queries_free.restype = None
     lib.afis_match_all_templates.argtypes = [vp, vp, fp, i32p, i32p]
+    lib.afis_debug_stage_list.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, fp, i32p, i32p, i32p]
     lib.afis_pq_encode.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint8)]
     lib.afis_encode_rolled_dat.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), i32p]
     lib.afis_get_timing.argtypes = [vp, C.POINTER(Timing)]
@@ -295,6 +296,15 @@ class Matcher:
         return list(out)
 
     # ---- parity taps ------------------------------------------------------------------------------------------
+    def debug_stage_list(self, latent: FPTemplate, g: int, which: int, stage: int):
+        """(sim, li, ri) of the scorer's correspondence list after a stage (None when the scorer is not run)."""
+        v = _Views([latent])
+        sim = np.zeros(200, np.float32); li = np.zeros(200, np.int32); ri = np.zeros(200, np.int32); n = C.c_int32(0)
+        self._chk(self.lib.afis_debug_stage_list(self.ctx, v.arr, g, which, stage, _ptr(sim, C.c_float), _ptr(li, C.c_int32), _ptr(ri, C.c_int32), C.byref(n)))
+        if n.value < 0:
+            return None
+        return sim[:n.value], li[:n.value], ri[:n.value]
+
     def debug_lut(self, latent: FPTemplate) -> np.ndarray:
         v = _Views([latent])
         n = latent.tex[0].n if latent.tex else 0

@@ -267,6 +267,34 @@ def test_all_templates_mode(codebook_bytes, cb, oracle, small):
     m.close()
 
 
+def test_stage_lists_match_oracle_traces(codebook_bytes, cb, oracle, small):
+    """Every scorer's correspondence list after every stage — candidates (S3 / S7), distance filter (S8), angle filter (S9) —
+    against the oracle's traces: same members, same order, same raw similarities (bit for bit).  Final scores alone would not
+    notice a 1-ulp slip inside the graph stages; this does as soon as a selection changes."""
+    lats, gal = small
+    m = _matcher(codebook_bytes, gal)
+    ocb = oracle.codebook(codebook_bytes)
+    hl, hr = cases.to_orc(oracle, ocb, lats, gal)
+    n_lists = n_nonempty_final = 0
+    for qi in range(len(lats)):
+        for gi in range(len(gal)):
+            for which in range(4):
+                for stage in range(3):
+                    want = oracle.trace(ocb, hl[qi], hr[gi], which=which, stage=stage, tie_mode=1)
+                    got = m.debug_stage_list(lats[qi], gi, which, stage)
+                    if want is None:
+                        assert got is None, (qi, gi, which, stage)
+                        continue
+                    assert got is not None, (qi, gi, which, stage)
+                    ws, wl, wr = want
+                    assert np.array_equal(got[1], wl) and np.array_equal(got[2], wr), (qi, gi, which, stage)
+                    assert np.array_equal(got[0].view(np.uint32), ws.view(np.uint32)), (qi, gi, which, stage)
+                    n_lists += 1
+                    n_nonempty_final += int(stage == 2 and len(wl) > 0)
+    assert n_lists >= 100 and n_nonempty_final >= 6
+    m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
