@@ -64,7 +64,10 @@ struct __attribute__((aligned(16))) WaveSmem {
     static constexpr int N4 = (NMAX + 3) / 4 * 4;
     static constexpr int U = (NMAX + 63) / 64;
     float b[N4];                           // 16-byte aligned: read as float4 broadcasts
-    float cc[N4];
+    union {                                // cc lives during the power iterations, order / sel from the sort that follows them
+        float cc[N4];
+        struct { short order[NMAX]; short sel[NMAX]; } os;     // rank -> candidate index; accepted candidates
+    } y;
     float sim[NMAX];
     short li[NMAX], ri[NMAX];
     int2 xy[NMAX];                         // .x = lx | ly << 16 (latent point), .y = rx | ry << 16 (rolled point)
@@ -75,8 +78,6 @@ struct __attribute__((aligned(16))) WaveSmem {
         struct { u64 keys[N4]; float lo[NMAX], ro[NMAX]; } s;                       // sorts (after the iterations); orientations (angle stage only)
         struct { u64 keys[N4]; float tval[NMAX]; short te[NMAX], targ[NMAX]; } pick;   // texture rows picked by S7, before they are ranked
     } x;
-    short order[NMAX];                     // rank -> candidate index
-    short sel[NMAX];
     int nsel;
 };
 
@@ -109,14 +110,14 @@ __device__ __forceinline__ void sort_scores(SM& sm, int num)
     WSYNC();
     rank_keys<SM::U>(sm.x.s.keys, num, mine, r);
 #pragma unroll
-    for (int u = 0; u < SM::U; ++u) { const int t = lane + 64 * u; if (t < num) sm.order[r[u]] = (short)t; }
+    for (int u = 0; u < SM::U; ++u) { const int t = lane + 64 * u; if (t < num) sm.y.os.order[r[u]] = (short)t; }
     WSYNC();
 }
 
 // Greedy selection, matcher.cpp:1304-1344 / :1425-1465 / :1593-1633: walk the candidates by descending S; stop at S < thr;
 // skip a candidate whose latent or rolled point is already used or that is incompatible with ANY accepted one.
 // The wave holds the candidates in rank order (lane l: ranks l, l+64, ...).  Each round accepts the first alive candidate and
-// kills every later one that conflicts with it.  Accepted indices go to sm.sel[0..nsel) in acceptance (= rank) order.
+// kills every later one that conflicts with it.  Accepted indices go to sm.y.os.sel[0..nsel) in acceptance (= rank) order.
 template <class SM, class Compat>
 __device__ int greedy(SM& sm, int num, double thr, Compat compatible)
 {
@@ -129,7 +130,7 @@ __device__ int greedy(SM& sm, int num, double thr, Compat compatible)
         const int p = lane + 64 * u;
         idx[u] = 0; li[u] = -1; ri[u] = -1; alive[u] = false;
         if (p < num) {
-            idx[u] = sm.order[p];
+            idx[u] = sm.y.os.order[p];
             li[u] = sm.li[idx[u]]; ri[u] = sm.ri[idx[u]];
             alive[u] = !((double)sm.b[idx[u]] < thr);          // sorted descending: everything after the first S < thr is < thr too
         }
@@ -147,7 +148,7 @@ __device__ int greedy(SM& sm, int num, double thr, Compat compatible)
             }
         }
         if (first < 0) break;
-        if (lane == 0) sm.sel[nsel] = (short)cidx;
+        if (lane == 0) sm.y.os.sel[nsel] = (short)cidx;
         ++nsel;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -170,7 +171,7 @@ __device__ void compact(SM& sm, int n)
 #pragma unroll
     for (int u = 0; u < SM::U; ++u) {
         const int t = lane + 64 * u;
-        if (t < n) { const int s = sm.sel[t]; sim[u] = sm.sim[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; }
+        if (t < n) { const int s = sm.y.os.sel[t]; sim[u] = sm.sim[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; }
     }
     WSYNC();
 #pragma unroll
@@ -186,7 +187,7 @@ template <class SM>
 __device__ __forceinline__ float seq_sum(const SM& sm, int num)
 {
     float sum = 0.0f;
-    const float4* c4 = reinterpret_cast<const float4*>(sm.cc);
+    const float4* c4 = reinterpret_cast<const float4*>(sm.y.cc);
 #pragma unroll 4
     for (int k = 0; k < (num + 3) / 4; ++k) { const float4 v = c4[k]; sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
     return sum;
@@ -216,6 +217,31 @@ __device__ __forceinline__ bool pair_dist(const Pt& a, const Pt& o, const float*
     dist = fabsf(d1 - d2);
     return ok;
 }
+// "H != 0" for a pair, i.e. in range and |d1 - d2| < 30 with d1, d2 the correctly rounded distances — decided from the 1-ulp
+// hardware square roots whenever the outcome cannot depend on their last bit: each d is within one ulp of its exact value, so
+// |d1 - d2| is within 3 ulp(max(d1, d2)) <= max(d1, d2) * 2^-21 of the exact difference (incl. the subtraction's own rounding);
+// only pairs closer than that to the threshold (about one in 10^5) take the exact evaluation.
+template <bool LOOKUP>
+__device__ __forceinline__ bool pair_compatible(const Pt& a, const Pt& o, const float* __restrict__ table)
+{
+    float s1, s2; bool ok = true;
+    if (LOOKUP) {
+        const int dx1 = abs(a.lx - o.lx), dx2 = abs(a.rx - o.rx), dy1 = abs(a.ly - o.ly), dy2 = abs(a.ry - o.ry);
+        ok = !((dx1 >= kDistN) | (dx2 >= kDistN) | (dy1 >= kDistN) | (dy2 >= kDistN));              // :1257
+        s1 = (float)(256 * (dx1 * dx1 + dy1 * dy1)); s2 = (float)(256 * (dx2 * dx2 + dy2 * dy2));
+    } else {
+        const float dx1 = (float)(a.lx - o.lx), dx2 = (float)(a.rx - o.rx), dy1 = (float)(a.ly - o.ly), dy2 = (float)(a.ry - o.ry);
+        const float p = dx1 * dx1, q = dy1 * dy1, r = dx2 * dx2, s = dy2 * dy2;
+        s1 = p + q; s2 = r + s;
+    }
+    const float d1 = __builtin_amdgcn_sqrtf(s1), d2 = __builtin_amdgcn_sqrtf(s2);
+    const float dist = fabsf(d1 - d2);
+    const float slack = fmaxf(d1, d2) * 4.76837158e-7f;                  // 2^-21
+    if (fabsf(dist - 30.0f) > slack) return ok && dist < 30.0f;
+    float exact;
+    pair_dist<LOOKUP>(a, o, table, exact);
+    return ok && exact < 30.0f;
+}
 // H = clamp((30 - dist)/(25.0), 0, 1) for dist <= 30 (matcher.cpp:1268-1272 / :1389-1393): float numerator, double divide,
 // float store.  (float)((double)x/25.0) == x/25.0f (double rounding through 53 bits is innocuous for a quotient of two
 // 24-bit values), and for every float x in [0, 30] the fma sequence below equals x/25.0f — checked exhaustively over all
@@ -243,7 +269,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int t = lane + 64 * u;
-        if (t < SM::N4) { sm.b[t] = t < num ? sm.sim[t] : 0.0f; sm.cc[t] = 0.0f; }
+        if (t < SM::N4) { sm.b[t] = t < num ? sm.sim[t] : 0.0f; sm.y.cc[t] = 0.0f; }
         me[u] = unpack_xy(t < num ? sm.xy[t] : make_int2(0, 0));
     }
     WSYNC();
@@ -257,9 +283,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
             const int t = lane + 64 * u;
             if (t < num && !(d == half && even && t >= half)) {       // even num: the antipodal pairs belong to the lower half
                 int k = t + d; if (k >= num) k -= num;
-                float dist;
-                const bool ok = pair_dist<LOOKUP>(me[u], unpack_xy(sm.xy[k]), table, dist);
-                if (ok && dist < 30.0f) {
+                if (pair_compatible<LOOKUP>(me[u], unpack_xy(sm.xy[k]), table)) {
                     atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
                     atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
                 }
@@ -293,14 +317,14 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
                         ++n;
                     }
                 }
-                sm.cc[t] = acc;
+                sm.y.cc[t] = acc;
             }
         }
         WSYNC();
         const float sum = seq_sum(sm, num);
         const float scale = (float)(1.0 / ((double)sum + 0.00001));
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; if (t < num) sm.b[t] = sm.cc[t] * scale; }
+        for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; if (t < num) sm.b[t] = sm.y.cc[t] * scale; }
         WSYNC();
     }
     GPH(PH + 1);
@@ -367,7 +391,7 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
     for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
     for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
     const float s0 = (float)(1.0 / num);                                   // :1558
-    for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.cc[t] = 0.0f; }
+    for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.y.cc[t] = 0.0f; }
     WSYNC();
     // row t visits the pairs (t, t+d mod num), d = 1..num/2: every unordered pair once, evaluated as (lower, higher) index
     const int half = num >> 1;
@@ -392,12 +416,12 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
                 uint32_t bits = sm.hb[t][w];
                 while (bits) { const int k = w * 32 + __ffs(bits) - 1; bits &= bits - 1; s1 += sm.b[k]; }
             }
-            sm.cc[t] = s1;
+            sm.y.cc[t] = s1;
         }
         WSYNC();
         float sum = seq_sum(sm, num);
         sum = (float)(1.0 / ((double)sum + 0.00001));
-        for (int t = lane; t < num; t += 64) sm.b[t] = sm.cc[t] * sum;
+        for (int t = lane; t < num; t += 64) sm.b[t] = sm.y.cc[t] * sum;
         WSYNC();
     }
     GPH(PH + 5);
@@ -440,7 +464,7 @@ __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, lon
 // texture lists: S7 (top-200 rows of the ADC row maxima) + S8b + S9
 // =====================================================================================================================
 #ifndef AFIS_TEX_CACHE
-#define AFIS_TEX_CACHE 4
+#define AFIS_TEX_CACHE 3
 #endif
 typedef WaveSmem<kTopTex, AFIS_TEX_CACHE> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
@@ -539,7 +563,7 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // minutiae lists (produced by k_minu_cands, already in rank order): S8a + S9
 // =====================================================================================================================
 #ifndef AFIS_MINU_CACHE
-#define AFIS_MINU_CACHE 6
+#define AFIS_MINU_CACHE 10
 #endif
 typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE> MinuGraphSmem;
 
