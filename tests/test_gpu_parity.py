@@ -295,6 +295,46 @@ def test_stage_lists_match_oracle_traces(codebook_bytes, cb, oracle, small):
     m.close()
 
 
+def test_c_abi_error_behaviour(codebook_bytes, cb, small):
+    """The boundary fails loudly and leaves the context usable: state errors, bad views, bad options, bad files."""
+    import ctypes as C
+    lats, gal = small
+    m = M.Matcher(codebook_bytes)
+    lib = m.lib
+    with pytest.raises(M.AfisError, match="commit"):
+        m.search(lats[:1])                                           # search before commit
+    with pytest.raises(M.AfisError, match="commit"):
+        m.correspondences(lats[0], [0])
+    m.gallery_add(gal[:3])
+    bad = T.FPTemplate(minu=[T.MinutiaeTemplate(gal[0].minu[0].x, gal[0].minu[0].y, gal[0].minu[0].ori, gal[0].minu[0].des[:, :64].copy())], tex=[])
+    with pytest.raises(M.AfisError, match="96"):
+        m.gallery_add([bad])                                         # the reference asserts equal descriptor lengths (matcher.cpp:433)
+    assert m.gallery_size == 3                                       # a rejected template adds nothing
+    m.gallery_commit(0)
+    with pytest.raises(M.AfisError, match="committed"):
+        m.gallery_add(gal[:1])
+    with pytest.raises(M.AfisError, match="committed"):
+        m.gallery_commit(0)
+    with pytest.raises(M.AfisError):
+        m.set_option("adc_variant", 4)                               # removed variants
+    with pytest.raises(M.AfisError):
+        m.set_option("no_such_option", 1)
+    with pytest.raises(M.AfisError, match="96"):
+        m.search([T.FPTemplate(minu=[bad.minu[0]] * 28, tex=[])])
+    with pytest.raises(M.AfisError):
+        m.gallery_file_info("/nonexistent/gallery.afisgal")
+    assert lib.afis_search(m.ctx, None, 1, None, None, None, 0, None, None) != 0         # NULL queries with n_q > 0
+    assert lib.afis_search(m.ctx, None, 0, None, None, None, 0, None, None) == 0         # an empty batch is fine
+    assert lib.afis_destroy(None) is None                                                  # no-op
+    ctx2 = C.c_void_p()
+    assert lib.afis_create_from_codebook(C.byref(ctx2), b"\x00" * 20, 20, 0) != 0 and not ctx2.value      # not a codebook
+    assert lib.afis_create_from_codebook(C.byref(ctx2), codebook_bytes, len(codebook_bytes), 99) != 0      # no such device
+    assert b"device" in lib.afis_last_error(None)
+    r = m.search(lats[:1], k=5)                                      # still works after all of the above; k > G pads with -1
+    assert list(r["topk_idx"][0][3:]) == [-1, -1] and (r["topk_idx"][0][:3] >= 0).all()
+    m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
