@@ -252,13 +252,21 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kFastU = kFastN / kThreads;            // 32 keys per lane at most
 constexpr int kStage1Cap = 160;                      // stage-1 survivors per wave: a superset of the wave's 120 largest keys
+constexpr int kHistBins = 2048;                      // histogram path: key bits 29..19 (7 exponent + 4 mantissa bits; norm < 1)
+constexpr int kBndCap = 128;                         // keys that may share the threshold bin before the two-stage path takes over
+constexpr int kHistMinN = 512;                       // below this the two-stage path is as cheap
 struct FastSmem {
     float simi[kFastN];                               // 32 KB
     float rowsum[kFastL];
     float colsum[kFastR];
-    u64 list[kWaves * kStage1Cap];                    // stage-1 survivors
-    u64 top[128];                                     // stage-2 survivors
+    union {
+        u64 list[kWaves * kStage1Cap];                // two-stage path: stage-1 survivors
+        struct { uint32_t hist[kHistBins / 2]; u64 bnd[kBndCap]; } h;   // histogram path: 2048 16-bit bins; keys of the threshold bin
+    } sel;
+    u64 top[128];                                     // the selected keys (unordered on the histogram path)
     int counts[kWaves];
+    int wave_tot[kWaves];
+    int thr_bin, c_above, n_top, n_bnd;
 };
 
 // K-th largest of the wave's composite keys c[0..U) (0 = padding), K >= 1 and K <= number of non-zero keys
@@ -346,6 +354,89 @@ __device__ __forceinline__ int wave_stage1(const FastSmem& sm, u64* list, int n,
     return n_out;
 }
 
+// Top-120 selection by histogram (all four waves, no serial stage): a 2048-bin histogram of the norm keys' bits 29..19 in LDS,
+// a suffix scan that finds the bin in which the 120th largest key lies, then every key in a higher bin is selected outright and
+// the (few) keys of the threshold bin are ranked among themselves as 45-bit composites (norm key, then lowest element index), so
+// the result is exactly the 120 largest in the reference's order.  Returns false — uniformly for the workgroup — when the
+// threshold bin is the zero bin or holds more than kBndCap keys; the caller then runs the two-stage path.
+template <int U>
+__device__ __forceinline__ bool select_hist(FastSmem& sm, int n, int nR, int wave, int lane, int tid)
+{
+    uint32_t rk[U];
+    {
+        int e = wave * 64 + lane;
+        int i = e / nR, j = e - i * nR;
+        const int si = kThreads / nR, sj = kThreads - si * nR;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint32_t key = 0;
+            if (e < n) {
+                const float sv = sm.simi[e];
+                float f = sm.rowsum[i] + sm.colsum[j];
+                f = f - sv;
+                key = ord_f32((float)((double)sv / ((double)f + 0.000001)));                    // matcher.cpp:467
+            }
+            rk[u] = key;
+            e += kThreads; i += si; j += sj; if (j >= nR) { j -= nR; ++i; }
+        }
+    }
+    for (int w = tid; w < kHistBins / 2; w += kThreads) sm.sel.h.hist[w] = 0u;
+    if (tid == 0) { sm.n_top = 0; sm.n_bnd = 0; sm.thr_bin = -1; sm.c_above = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = (u * kWaves + wave) * 64 + lane;
+        if (e < n) { const uint32_t bin = (rk[u] >> 19) & (kHistBins - 1); atomicAdd(&sm.sel.h.hist[bin >> 1], 1u << ((bin & 1) * 16)); }
+    }
+    __syncthreads();
+    // thread tid owns bins 8*tid .. 8*tid+7; higher thread = larger keys
+    int cnt[8], own = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t x = sm.sel.h.hist[4 * tid + w];
+        cnt[2 * w] = (int)(x & 0xffffu); cnt[2 * w + 1] = (int)(x >> 16);
+        own += cnt[2 * w] + cnt[2 * w + 1];
+    }
+    int suf = own;                                                       // keys in the bins of lanes >= this one (within the wave)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_down(suf, off); if (lane + off < 64) suf += t; }
+    if (lane == 0) sm.wave_tot[wave] = suf;
+    __syncthreads();
+    int above = suf - own;                                               // keys in all higher bins
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) if (w > wave) above += sm.wave_tot[w];
+#pragma unroll
+    for (int b = 7; b >= 0; --b) {
+        if (above < kTopMinu && above + cnt[b] >= kTopMinu) { sm.thr_bin = 8 * tid + b; sm.c_above = above; }
+        above += cnt[b];
+    }
+    __syncthreads();
+    const int B = sm.thr_bin, c_above = sm.c_above;
+    if (B <= 0) return false;                                            // the 120th key is a zero norm: index order decides, two-stage path
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = (u * kWaves + wave) * 64 + lane;
+        if (e < n) {
+            const int bin = (int)((rk[u] >> 19) & (kHistBins - 1));
+            const u64 comp = ((u64)rk[u] << 13) | (u64)(8191 - e);
+            if (bin > B) sm.top[atomicAdd(&sm.n_top, 1)] = comp;
+            else if (bin == B) { const int p = atomicAdd(&sm.n_bnd, 1); if (p < kBndCap) sm.sel.h.bnd[p] = comp; }
+        }
+    }
+    __syncthreads();
+    const int n_bnd = sm.n_bnd;
+    if (n_bnd > kBndCap) return false;
+    const int need = kTopMinu - c_above;                                 // 1 <= need <= n_bnd
+    if (tid < n_bnd) {
+        const u64 mine = sm.sel.h.bnd[tid];
+        int r = 0;
+        for (int k = 0; k < n_bnd; ++k) r += sm.sel.h.bnd[k] > mine;
+        if (r < need) sm.top[c_above + r] = mine;
+    }
+    __syncthreads();
+    return true;
+}
+
 __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
                                                               const float* __restrict__ rol_desp,   // k-permuted descriptor copies
                                                               MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
@@ -426,13 +517,40 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, Gal
         }
         __syncthreads();
         PHASE(17);
-        // ---- S3 (:461-488) stage 1: element e = (u*4 + wave)*64 + lane belongs to this wave ----
+        // ---- S3 (:461-488): the 120 largest norm values, ties by lowest element index; element e = (u*4 + wave)*64 + lane ----
         const int topN = n < kTopMinu ? n : kTopMinu;
-        // number of key slots per lane actually needed: 8 (n <= 2048), 16 (n <= 4096) or 32
+        bool selected = false;
+        if (n >= kHistMinN) {                                                 // histogram path (all waves); falls through when it declines
+            if (n <= 8 * kThreads) selected = select_hist<8>(sm, n, nR, wave, lane, tid);
+            else if (n <= 16 * kThreads) selected = select_hist<16>(sm, n, nR, wave, lane, tid);
+            else selected = select_hist<kFastU>(sm, n, nR, wave, lane, tid);
+        }
+        if (selected) {
+            PHASE(18);
+            // rank by counting, two threads per key: each counts the larger keys in one half of the list
+            const int ki = tid >> 1, half = tid & 1;
+            const u64 mine = ki < kTopMinu ? sm.top[ki] : 0ull;
+            int r = 0;
+            const int k0 = half * (kTopMinu / 2);
+#pragma unroll 4
+            for (int k = k0; k < k0 + kTopMinu / 2; ++k) r += sm.top[k] > mine;
+            r += __shfl_xor(r, 1);
+            if (half == 0 && ki < kTopMinu) {
+                const int e = 8191 - (int)(mine & 8191);
+                const int i1 = e / nR, i2 = e - i1 * nR;
+                MinuCand cd; cd.sim = sm.simi[e]; cd.li = (short)i1; cd.ri = (short)i2;
+                cands[(size_t)task * kTopMinu + r] = cd;
+            }
+            if (tid == 0) cand_n[task] = kTopMinu;
+            __syncthreads();
+            PHASE(20);
+            continue;
+        }
+        // two-stage path: number of key slots per lane actually needed: 8 (n <= 2048), 16 (n <= 4096) or 32
         int Kw;
-        if (n <= 8 * kThreads) Kw = wave_stage1<8>(sm, sm.list + wave * kStage1Cap, n, nR, wave, lane);
-        else if (n <= 16 * kThreads) Kw = wave_stage1<16>(sm, sm.list + wave * kStage1Cap, n, nR, wave, lane);
-        else Kw = wave_stage1<kFastU>(sm, sm.list + wave * kStage1Cap, n, nR, wave, lane);
+        if (n <= 8 * kThreads) Kw = wave_stage1<8>(sm, sm.sel.list + wave * kStage1Cap, n, nR, wave, lane);
+        else if (n <= 16 * kThreads) Kw = wave_stage1<16>(sm, sm.sel.list + wave * kStage1Cap, n, nR, wave, lane);
+        else Kw = wave_stage1<kFastU>(sm, sm.sel.list + wave * kStage1Cap, n, nR, wave, lane);
         PHASE(18);
         if (lane == 0) sm.counts[wave] = Kw;
         __syncthreads();
@@ -449,7 +567,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, Gal
                 const int p = v * 64 + lane;                                  // position in the concatenation of the four lists
                 u64 key = 0;
 #pragma unroll
-                for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.list[w * kStage1Cap + p - off[w]];
+                for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.sel.list[w * kStage1Cap + p - off[w]];
                 d[v] = key;
             }
             // topN largest composites = norm key descending, element index ascending.  Threshold search on the 32-bit keys;
