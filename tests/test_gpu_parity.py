@@ -335,6 +335,53 @@ def test_c_abi_error_behaviour(codebook_bytes, cb, small):
     m.close()
 
 
+def test_candidate_selection_degenerate_keys(codebook_bytes, cb, oracle):
+    """S3 with keys that defeat the histogram path of k_minu_cands_fast (n >= 512): (a) fewer than 120 non-zero similarities, so
+    the 120th candidate is a zero decided by element index; (b) every similarity identical, so all keys share one bin and the
+    whole top-120 is decided by index; (c) a block of exact ties straddling the 120th place.  Candidate lists (members, order,
+    similarity bits) and scores against the oracle."""
+    rng = np.random.default_rng(5)
+    base = S.make_latent(rng)
+    d = rng.standard_normal(96).astype(np.float32); d *= np.float32(1.73) / np.linalg.norm(d)
+    e = rng.standard_normal(96).astype(np.float32); e -= d * (e @ d) / (d @ d); e *= np.float32(1.73) / np.linalg.norm(e)     # orthogonal to d
+
+    def latent_with(des_rows):
+        L = T.FPTemplate(minu=list(base.minu), tex=list(base.tex))
+        m0 = base.minu[26]
+        n = len(des_rows)
+        L.minu[26] = T.MinutiaeTemplate(rng.integers(50, 700, n).astype(np.int16), rng.integers(50, 700, n).astype(np.int16),
+                                        rng.uniform(-3, 3, n).astype(np.float32), np.stack(des_rows).astype(np.float32))
+        return L
+
+    def rolled_with(des_rows):
+        n = len(des_rows)
+        R = S.make_rolled(rng, cb, n_minu=n, n_tex=300)
+        R.minu[0] = T.MinutiaeTemplate(R.minu[0].x, R.minu[0].y, R.minu[0].ori, np.stack(des_rows).astype(np.float32))
+        return R
+
+    cases_ = [
+        (latent_with([d] * 30), rolled_with([-d] * 37 + [d] * 3)),                      # (a) 90 non-zero of 1200
+        (latent_with([d] * 32), rolled_with([d] * 40)),                                  # (b) 1280 identical keys
+        (latent_with([d] * 10 + [e] * 22), rolled_with([d] * 10 + [0.5 * d + 0.5 * e] * 30)),   # (c) a few levels, large tie blocks
+    ]
+    ocb = oracle.codebook(codebook_bytes)
+    for ci, (L, R) in enumerate(cases_):
+        m = M.Matcher(codebook_bytes); m.gallery_add([R]); m.gallery_commit(0)
+        hl, _ = oracle.latent(ocb, T.write_latent(L)); hr, _ = oracle.rolled(T.write_rolled(R))
+        for stage in (0, 1, 2):
+            want = oracle.trace(ocb, hl, hr, which=1, stage=stage, tie_mode=1)
+            got = m.debug_stage_list(L, 0, 1, stage)
+            assert want is not None and got is not None
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (ci, stage)
+            assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (ci, stage)
+            if stage == 0:
+                assert len(want[1]) == 120
+        rc, want_sc = oracle.pair(ocb, hl, hr, 1)
+        got_sc = m.search([L], k=0, want_parts=True)
+        assert np.array_equal(got_sc["parts"][0, 0].view(np.uint32), want_sc[:4].view(np.uint32)), ci
+        m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
