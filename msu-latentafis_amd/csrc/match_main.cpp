@@ -17,6 +17,11 @@
 // matcher.cpp:306-309); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
 // /LatentAFIS/scores/corr<latent>_<rolled>_<i>.csv (matcher.cpp:325-327, :405, :497-505), go to <score dir>/corr<latent>_<rolled>_<i>.csv
 // (or to the prefix given with -corr).
+// Multi-GPU: started once per GPU with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment
+// (e.g. `python -m torch.distributed.run --no-python --nproc-per-node 8 ./match ...`), every rank loads one contiguous shard of
+// the gallery (balanced by texture points when -g is a container, by template count for a directory), scores all latents against
+// it, and ONE RCCL all-gather per batch brings the per-shard top-24 lists (-l) or score columns (-ldir) together; rank 0 merges
+// (score descending, index ascending) and writes exactly the files a single process writes (rank_exchange.h).
 // Additions: -g may name a packed gallery container (one file, include/afis_matcher.h: afis_gallery_load) instead of a directory;
 // -pack <file> writes the gallery given by -g as such a container (alone: pack and exit).
 #include <algorithm>
@@ -33,6 +38,7 @@
 #include <vector>
 
 #include "../../include/afis_matcher.h"
+#include "rank_exchange.h"
 #include "template_io.h"
 
 namespace fs = std::filesystem;
@@ -122,14 +128,16 @@ std::vector<fs::path> list_gallery(const std::string& g)
     return files;
 }
 
-int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path>& files, const std::string& pack_to)
+// loads templates [lo, hi) of the gallery and commits them with global indices
+int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path>& files, const std::string& pack_to, int64_t lo = 0, int64_t hi = -1)
 {
+    if (hi < 0) hi = (int64_t)files.size();
     if (fs::is_regular_file(fs::path(g))) {
-        CHECK(ctx, afis_gallery_load(ctx, g.c_str(), 0, -1));
+        CHECK(ctx, afis_gallery_load(ctx, g.c_str(), lo, hi - lo));
     } else {
         std::vector<uint8_t> b;
-        for (const fs::path& f : files) {
-            read_file(f.string(), b);
+        for (int64_t i = lo; i < hi; ++i) {
+            read_file(files[(size_t)i].string(), b);
             int load_rc = 0;
             CHECK(ctx, afis_gallery_add_dat(ctx, b.data(), b.size(), &load_rc));
         }
@@ -140,7 +148,43 @@ int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path
         for (const std::string& n : names) np.push_back(n.c_str());
         CHECK(ctx, afis_gallery_save(ctx, pack_to.c_str(), np.data()));
     }
-    CHECK(ctx, afis_gallery_commit(ctx, 0));
+    CHECK(ctx, afis_gallery_commit(ctx, lo));
+    return 0;
+}
+
+// the ranks of one job: identical gallery listing on every rank (checked), shard bounds, the exchange
+struct Job {
+    RankWorld w;
+    bool multi = false;
+    std::vector<std::pair<int64_t, int64_t>> bounds{{0, 0}};
+    int64_t lo = 0, hi = 0, g_max = 0;
+    bool root() const { return w.rank == 0; }
+    int owner(int64_t idx) const { for (int r = 0; r < (int)bounds.size(); ++r) if (idx >= bounds[(size_t)r].first && idx < bounds[(size_t)r].second) return r; return -1; }
+};
+
+#define JOBCHK(call) do { std::string e_; if (!(call)) { std::cerr << "match[rank " << job.w.rank << "]: " << e_ << std::endl; return 2; } } while (0)
+
+int plan_shards(Job& job, const std::string& gallery_path, const std::vector<fs::path>& rolled)
+{
+    const int64_t G = (int64_t)rolled.size();
+    std::vector<int32_t> weights;
+    if (job.multi && fs::is_regular_file(fs::path(gallery_path))) {          // balance by texture points, the cost driver
+        weights.resize((size_t)G);
+        int64_t g2 = 0;
+        if (afis_gallery_file_info(gallery_path.c_str(), &g2, nullptr, nullptr, weights.data()) != AFIS_OK || g2 != G) { std::cerr << "match: " << afis_last_error(nullptr) << std::endl; return 2; }
+    }
+    job.bounds = shard_bounds(G, weights, job.w.world);
+    job.lo = job.bounds[(size_t)job.w.rank].first; job.hi = job.bounds[(size_t)job.w.rank].second;
+    job.g_max = 0;
+    for (const auto& b : job.bounds) job.g_max = std::max(job.g_max, b.second - b.first);
+    if (job.multi) {                                                          // every rank must see the same gallery in the same order
+        uint64_t h[2] = {(uint64_t)G, 1469598103934665603ull};
+        for (const fs::path& p : rolled) for (char c : p.string()) { h[1] ^= (unsigned char)c; h[1] *= 1099511628211ull; }
+        std::vector<uint64_t> all((size_t)job.w.world * 2);
+        JOBCHK(world_all_gather(job.w, h, all.data(), sizeof(h), e_));
+        for (int r = 0; r < job.w.world; ++r)
+            if (all[(size_t)r * 2] != h[0] || all[(size_t)r * 2 + 1] != h[1]) { std::cerr << "match[rank " << job.w.rank << "]: rank " << r << " lists a different gallery" << std::endl; return 2; }
+    }
     return 0;
 }
 
@@ -149,6 +193,26 @@ int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path
 int main(int argc, char** argv)
 {
     ArgParser args(argc, argv);
+    if (args.cmdOptionExists("-selftest-exchange")) {                           // rendezvous only (no GPU): rank 0's 128 bytes reach every rank
+        RankWorld w; world_from_env(w);
+        unsigned char id[128];
+        for (int i = 0; i < 128; ++i) id[i] = w.rank == 0 ? (unsigned char)(i * 7 + 3) : 0;
+        std::string err;
+        if (!tcp_broadcast(w, id, sizeof(id), err)) { std::cerr << "match: " << err << std::endl; return 2; }
+        unsigned sum = 0; for (int i = 0; i < 128; ++i) sum = sum * 31 + id[i];
+        std::cout << "rank " << w.rank << " of " << w.world << " id " << sum << std::endl;
+        return 0;
+    }
+    if (args.cmdOptionExists("-selftest-shards")) {                             // shard cut rule (no GPU): weights file (one int per line), world
+        std::ifstream f(args.getCmdOption("-selftest-shards"));
+        std::vector<int32_t> wts; int v;
+        while (f >> v) wts.push_back(v);
+        const int world = atoi(args.getCmdOption("-world").c_str());
+        for (const auto& b : shard_bounds((int64_t)wts.size(), wts, world)) std::cout << b.first << " " << b.second << std::endl;
+        std::vector<int32_t> none;
+        for (const auto& b : shard_bounds((int64_t)wts.size(), none, world)) std::cout << b.first << " " << b.second << std::endl;
+        return 0;
+    }
     if (args.cmdOptionExists("-h") || args.cmdOptionExists("--help")) {
         std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>] [-pack <gallery container to write>]\n       -g may name a packed gallery container instead of a directory\n";
         return 0;
@@ -168,7 +232,11 @@ int main(int argc, char** argv)
     std::error_code ec; fs::create_directory(fs::path(score_path), ec);
     if (args.cmdOptionExists("-g")) gallery_path = args.getCmdOption("-g");
     else { std::cout << "Missing argument for gallery directory. Using default from afis.config" << std::endl; if (!from_config("GalleryTemplateDirectory", gallery_path)) return 2; }
-    const int device = args.cmdOptionExists("-d") ? atoi(args.getCmdOption("-d").c_str()) : 0;
+    Job job;
+    world_from_env(job.w);
+    job.multi = job.w.world > 1 || getenv("AFIS_FORCE_EXCHANGE") != nullptr;   // the variable runs the RCCL path with a single rank (tests)
+    if (!job.root()) std::cout.rdbuf(nullptr);                                  // rank 0 speaks for the job; errors still go to stderr
+    const int device = args.cmdOptionExists("-d") ? atoi(args.getCmdOption("-d").c_str()) : (job.w.world > 1 ? job.w.local_rank : 0);
 
     std::vector<uint8_t> cb;
     if (!read_file(codebook_path, cb) || cb.empty()) { std::cout << "codebook is empty!" << std::endl; return 2; }
@@ -178,39 +246,75 @@ int main(int argc, char** argv)
         return 2;
     }
 
+    if (job.multi) {
+        std::string err;
+        if (!world_init(job.w, device, err)) { std::cerr << "match[rank " << job.w.rank << "]: " << err << std::endl; afis_destroy(ctx); return 2; }
+    }
+    auto finish = [&](int code) { if (job.multi) world_finalize(job.w); afis_destroy(ctx); return code; };
     using clk = std::chrono::high_resolution_clock;
     int ret = 0;
     const std::string pack_to = args.cmdOptionExists("-pack") ? args.getCmdOption("-pack") : "";
+    if (!pack_to.empty() && job.w.world > 1) { std::cerr << "match: -pack is a single-process operation" << std::endl; return finish(2); }
     if (!pack_to.empty() && !args.cmdOptionExists("-l") && !args.cmdOptionExists("-ldir")) {          // pack only
         std::vector<fs::path> rolled = list_gallery(gallery_path);
-        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; afis_destroy(ctx); return -1; }
+        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; return finish(-1); }
         ret = load_gallery(ctx, gallery_path, rolled, pack_to);
         if (ret == 0) std::cout << "Packed " << rolled.size() << " templates into " << pack_to << std::endl;
-        afis_destroy(ctx);
-        return ret;
+        return finish(ret);
     }
     if (args.cmdOptionExists("-l")) {
         // ---- One2List_matching, matcher.cpp:216-337 ----
         const fs::path latent_file(args.getCmdOption("-l"));
         const std::string score_file = score_path + latent_file.stem().string() + ".csv";
         std::vector<fs::path> rolled = list_gallery(gallery_path);
-        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; afis_destroy(ctx); return -1; }
+        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; return finish(-1); }
         const auto t0 = clk::now();
         std::cout << "Latent Query: " << latent_file << std::endl;
         std::cout << "Gallery size: " << rolled.size() << std::endl;
-        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to)) != 0) { afis_destroy(ctx); return ret; }
+        if ((ret = plan_shards(job, gallery_path, rolled)) != 0) return finish(ret);
+        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi)) != 0) return finish(ret);
         Latent L; L.load(latent_file);
-        if (L.view.n_minu <= 0 && L.view.n_tex <= 0) { std::ofstream out(score_file); out << 0 << std::endl; }       // :260-268
+        if (job.root() && L.view.n_minu <= 0 && L.view.n_tex <= 0) { std::ofstream out(score_file); out << 0 << std::endl; }       // :260-268
         const int k = (int)std::min<size_t>(24, rolled.size());
-        std::vector<int64_t> idx(k); std::vector<float> sc(k); int32_t status = 0;
-        CHECK(ctx, afis_search(ctx, &L.view, 1, nullptr, nullptr, &status, k, idx.data(), sc.data()));
-        if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; afis_destroy(ctx); return 1; }
+        constexpr int kk = 24;                                                   // fixed-size per-rank block of the exchange
+        std::vector<int64_t> idx(kk); std::vector<float> sc(kk); int32_t status = 0;
+        CHECK(ctx, afis_search(ctx, &L.view, 1, nullptr, nullptr, &status, kk, idx.data(), sc.data()));     // padded with -1 beyond the shard
+        if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; return finish(1); }
+        if (job.multi) {                                                         // the exchange step: per-shard top-24 -> merged top-24
+            std::vector<int64_t> all_i((size_t)job.w.world * kk); std::vector<float> all_s((size_t)job.w.world * kk);
+            JOBCHK(world_all_gather(job.w, idx.data(), all_i.data(), kk * sizeof(int64_t), e_));
+            JOBCHK(world_all_gather(job.w, sc.data(), all_s.data(), kk * sizeof(float), e_));
+            merge_topk(all_i, all_s, job.w.world, kk, kk, idx, sc);
+        }
+        // correspondence files for the top 24 (matcher.cpp:311-328): one "lx,ly,rx,ry" line per surviving correspondence;
+        // every rank exports the pairs of its own shard
+        constexpr size_t kXY = 3 * 120 * 4;
+        std::vector<int32_t> counts((size_t)kk * 3, -1); std::vector<int16_t> xy((size_t)kk * kXY, 0);
+        {
+            std::vector<int64_t> mine; std::vector<int> pos;
+            for (int j = 0; j < k; ++j) if (idx[j] >= job.lo && idx[j] < job.hi) { mine.push_back(idx[j]); pos.push_back(j); }
+            std::vector<int32_t> c((size_t)mine.size() * 3 + 1); std::vector<int16_t> v((size_t)mine.size() * kXY + 1);
+            CHECK(ctx, afis_correspondences(ctx, &L.view, mine.data(), (int)mine.size(), c.data(), v.data()));
+            for (size_t a = 0; a < mine.size(); ++a) {
+                memcpy(&counts[(size_t)pos[a] * 3], &c[a * 3], 3 * sizeof(int32_t));
+                memcpy(&xy[(size_t)pos[a] * kXY], &v[a * kXY], kXY * sizeof(int16_t));
+            }
+        }
+        if (job.multi) {
+            std::vector<int32_t> all_c((size_t)job.w.world * counts.size()); std::vector<int16_t> all_v((size_t)job.w.world * xy.size());
+            JOBCHK(world_all_gather(job.w, counts.data(), all_c.data(), counts.size() * sizeof(int32_t), e_));
+            JOBCHK(world_all_gather(job.w, xy.data(), all_v.data(), xy.size() * sizeof(int16_t), e_));
+            for (int j = 0; j < k; ++j) {
+                const int r = job.owner(idx[j]);
+                if (r < 0) continue;
+                memcpy(&counts[(size_t)j * 3], &all_c[(size_t)r * counts.size() + (size_t)j * 3], 3 * sizeof(int32_t));
+                memcpy(&xy[(size_t)j * kXY], &all_v[(size_t)r * xy.size() + (size_t)j * kXY], kXY * sizeof(int16_t));
+            }
+        }
+        if (!job.root()) return finish(0);
         std::ofstream out(score_file);
         out << "filename,score" << std::endl;
         std::cout << "Match Results" << std::endl << "----------------" << std::endl << "Rank     Filename      Score" << std::endl;
-        // correspondence files for the top 24 (matcher.cpp:311-328): one "lx,ly,rx,ry" line per surviving correspondence
-        std::vector<int32_t> counts((size_t)k * 3); std::vector<int16_t> xy((size_t)k * 3 * 120 * 4);
-        CHECK(ctx, afis_correspondences(ctx, &L.view, idx.data(), k, counts.data(), xy.data()));
         const std::string corr_prefix = args.cmdOptionExists("-corr") ? args.getCmdOption("-corr") : score_path + "corr";
         for (int j = 0; j < k; ++j) {
             out << std::to_string(j + 1) << rolled[idx[j]] << "," << sc[j] << std::endl;
@@ -230,25 +334,38 @@ int main(int argc, char** argv)
         if (args.cmdOptionExists("-ldir")) latent_dir = args.getCmdOption("-ldir");
         else {
             std::cout << "Missing argument for latent template or directory. Assuming batch matching, using default directory from afis.config" << std::endl;
-            if (!from_config("LatentTemplateDirectory", latent_dir)) { afis_destroy(ctx); return 2; }
+            if (!from_config("LatentTemplateDirectory", latent_dir)) return finish(2);
         }
         std::vector<fs::path> latents = list_dat(latent_dir);
         for (const fs::path& p : latents) std::cout << "latent template file" << p << std::endl;
-        if (latents.empty()) { std::cout << "No latent templates found in directory: " << latent_dir << std::endl; afis_destroy(ctx); return -1; }
+        if (latents.empty()) { std::cout << "No latent templates found in directory: " << latent_dir << std::endl; return finish(-1); }
         std::vector<fs::path> rolled = list_gallery(gallery_path);
         for (const fs::path& p : rolled) std::cout << "rolled template file" << p << std::endl;
-        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; afis_destroy(ctx); return -1; }
+        if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; return finish(-1); }
         std::cout << "Gallery size: " << rolled.size() << std::endl;
         const auto t0 = clk::now();
-        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to)) != 0) { afis_destroy(ctx); return ret; }
-        const size_t G = rolled.size();
+        if ((ret = plan_shards(job, gallery_path, rolled)) != 0) return finish(ret);
+        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi)) != 0) return finish(ret);
+        const size_t G = rolled.size(), Gl = (size_t)(job.hi - job.lo), Gm = (size_t)job.g_max;
         const size_t batch = 16;
         for (size_t i0 = 0; i0 < latents.size(); i0 += batch) {
             const size_t nb = std::min(batch, latents.size() - i0);
             std::vector<Latent> Ls(nb); std::vector<afis_template_view> views(nb);
             for (size_t i = 0; i < nb; ++i) { Ls[i].load(latents[i0 + i]); views[i] = Ls[i].view; }
             std::vector<float> scores(nb * G); std::vector<int32_t> status(nb);
-            CHECK(ctx, afis_search(ctx, views.data(), (int)nb, scores.data(), nullptr, status.data(), 0, nullptr, nullptr));
+            if (!job.multi) {
+                CHECK(ctx, afis_search(ctx, views.data(), (int)nb, scores.data(), nullptr, status.data(), 0, nullptr, nullptr));
+            } else {                                                             // the exchange step: score columns of every shard
+                std::vector<float> part(nb * std::max<size_t>(Gl, 1)), block(nb * std::max<size_t>(Gm, 1), -1.0f), all((size_t)job.w.world * block.size());
+                CHECK(ctx, afis_search(ctx, views.data(), (int)nb, part.data(), nullptr, status.data(), 0, nullptr, nullptr));
+                for (size_t i = 0; i < nb; ++i) memcpy(&block[i * Gm], &part[i * Gl], Gl * sizeof(float));
+                JOBCHK(world_all_gather(job.w, block.data(), all.data(), block.size() * sizeof(float), e_));
+                for (int r = 0; r < job.w.world; ++r) {
+                    const size_t lo = (size_t)job.bounds[(size_t)r].first, n = (size_t)(job.bounds[(size_t)r].second - job.bounds[(size_t)r].first);
+                    for (size_t i = 0; i < nb; ++i) memcpy(&scores[i * G + lo], &all[(size_t)r * block.size() + i * Gm], n * sizeof(float));
+                }
+                if (!job.root()) continue;
+            }
             for (size_t i = 0; i < nb; ++i) {
                 const fs::path& lf = latents[i0 + i];
                 std::cout << lf << std::endl;
@@ -267,6 +384,5 @@ int main(int argc, char** argv)
         }
         std::cout << "Total matching duration (ms): " << std::chrono::duration<double, std::milli>(clk::now() - t0).count() << std::endl;
     }
-    afis_destroy(ctx);
-    return ret;
+    return finish(ret);
 }

@@ -382,6 +382,35 @@ def test_candidate_selection_degenerate_keys(codebook_bytes, cb, oracle):
         m.close()
 
 
+def test_cli_exchange_path_single_rank(codebook_bytes, cb, small, tmp_path):
+    """`match` with the multi-rank code path switched on for one rank (RCCL communicator of size 1, the all-gathers, the merge, the
+    shard plan): same files as the plain single-process run, for -l (rank list + correspondence files) and -ldir."""
+    import os, subprocess
+    lats, gal = small
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    for d in ("gal", "lat", "o1", "o2", "work"):
+        (tmp_path / d).mkdir()
+    for j, g in enumerate(gal[:10]):
+        (tmp_path / "gal" / f"R{j:03d}.dat").write_bytes(T.write_rolled(g))
+    (tmp_path / "gal" / "R_empty.dat").write_bytes(b"")
+    for i, L in enumerate(lats[:2]):
+        (tmp_path / "lat" / f"L{i}.dat").write_bytes(T.write_latent(L))
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    env = dict(os.environ, AFIS_FORCE_EXCHANGE="1", RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    env.pop("NCCL_DEBUG", None)
+    for mode in (["-ldir", str(tmp_path / "lat")], ["-l", str(tmp_path / "lat" / "L0.dat")]):
+        common = ["-g", str(tmp_path / "gal"), "-c", str(cbp)]
+        o1 = subprocess.run([exe] + mode + common + ["-s", str(tmp_path / "o1") + "/"], capture_output=True, text=True, cwd=tmp_path / "work")
+        o2 = subprocess.run([exe] + mode + common + ["-s", str(tmp_path / "o2") + "/"], capture_output=True, text=True, cwd=tmp_path / "work", env=env)
+        assert o1.returncode == 0 and o2.returncode == 0, (o1.stderr, o2.stderr)
+        names = sorted(os.listdir(tmp_path / "o1"))
+        assert names == sorted(os.listdir(tmp_path / "o2")) and len(names) >= 2
+        for n in names:
+            assert (tmp_path / "o1" / n).read_bytes() == (tmp_path / "o2" / n).read_bytes(), n
+        strip = lambda t: [l for l in t.splitlines() if not l.startswith("Total matching duration")]
+        assert strip(o1.stdout) == strip(o2.stdout)
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)

@@ -78,3 +78,43 @@ def test_gather_topk_world2_gloo():
     res = [q.get(timeout=120) for _ in procs]
     for p in procs: p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---- the C++ host's multi-rank pieces (msu-latentafis_amd/csrc/rank_exchange.cpp), without a GPU ---------------------------------
+def _match_exe():
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "msu-latentafis_amd", "csrc")
+    exe = os.path.join(csrc, "match")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", csrc, "match"], check=True)
+    return exe
+
+
+def test_cpp_shard_bounds_equal_python(tmp_path):
+    import subprocess
+    exe = _match_exe()
+    rng = np.random.default_rng(9)
+    for G, world in ((1000, 8), (13, 4), (5, 8), (1, 2)):
+        w = rng.integers(0, 1000, G).astype(np.int32)
+        w[rng.integers(0, G, max(1, G // 10))] = 0                      # templates without texture
+        f = tmp_path / f"w_{G}_{world}.txt"; f.write_text("\n".join(str(int(x)) for x in w) + "\n")
+        out = subprocess.run([exe, "-selftest-shards", str(f), "-world", str(world)], capture_output=True, text=True, check=True).stdout.split()
+        got = [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(2 * world)]
+        assert got[:world] == SH.shard_bounds(w, world), (G, world)
+        assert got[world:] == SH.shard_bounds(np.ones(G), world), (G, world)
+
+
+def test_cpp_rendezvous_three_ranks():
+    """The ncclUniqueId hand-off of `match` (rank 0 -> every rank over TCP) with three local processes, rank 0 started last."""
+    import subprocess, socket, time
+    exe = _match_exe()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = lambda r: dict(os.environ, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port - 1))
+    procs = [subprocess.Popen([exe, "-selftest-exchange"], env=env(r), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (1, 2)]
+    time.sleep(0.5)                                                     # the peers retry until rank 0 listens
+    procs.append(subprocess.Popen([exe, "-selftest-exchange"], env=env(0), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    ids = {o[0].strip().split(" id ")[1] for o in outs}
+    assert len(ids) == 1 and sorted(o[0].split()[1] for o in outs) == ["0", "1", "2"]
