@@ -26,7 +26,8 @@ M = importlib.import_module("msu-latentafis_amd.host.matcher")
 SH = importlib.import_module("msu-latentafis_amd.host.sharding")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LDS_PEAK_LOOKUPS = 256 * 64 * 2.4e9   # 256 CUs x 256 B/clk (ds_read_b128) / 4 B x 2.4 GHz (MI355X_MICROARCH.md §LDS)
+LDS_PEAK_LOOKUPS = 256 * 64 * 2.4e9   # 256 CUs x 256 B/clk (ds_read_b128) / 4 B x 2.4 GHz (MI355X_MICROARCH.md §LDS); measured 3.87e13/s
+                                      # with tools/ubench/lds_rate.hip (profiles/r01_lds_peak.json)
 BYTES_PER_TEX_POINT = 2 + 2 + 4 + 16  # x, y, ori, 16 PQ code bytes per rolled texture point
 BYTES_PER_MINUTIA = 2 + 2 + 4 + 96 * 4
 
