@@ -292,12 +292,43 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     }
     WSYNC();
     GPH(PH + 0);
+    // Rows differ in their number of non-zeros, and a wave pays for the longest row of every pass.  So the rows are dealt to the
+    // lanes in descending order of their non-zero count (16 buckets of 4, counting sort with ballots): the rows of one pass
+    // then have nearly equal lengths.  Rows are independent, so the row -> lane assignment does not touch any result.
+    int myrow[U];
+    {
+        int cnt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = lane + 64 * u;
+            int c = -1;
+            if (t < num) { c = 0; for (int w = 0; w < (num + 31) / 32; ++w) c += __popc(sm.hb[t][w]); c = min(c >> 2, 15); }
+            cnt[u] = c;
+        }
+        int base = 0;
+        for (int bk = 15; bk >= 0; --bk) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = cnt[u] == bk;
+                const u64 m = __ballot(in);
+                if (in) sm.y.os.order[base + g_lane_prefix(m)] = (short)(lane + 64 * u);   // order[] aliases cc[0 .. num/2): dead until the iterations
+                base += __popcll(m);
+            }
+        }
+        WSYNC();
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int p = lane + 64 * u; myrow[u] = p < num ? (int)sm.y.os.order[p] : -1; }
+        WSYNC();
+    }
+    Pt mine[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mine[u] = unpack_xy(myrow[u] >= 0 ? sm.xy[myrow[u]] : make_int2(0, 0));
     // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle)
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = lane + 64 * u;
-            if (t < num) {
+            const int t = myrow[u];
+            if (t >= 0) {
                 float acc = 0.0f;
                 int n = 0;
                 for (int w = 0; w < (num + 31) / 32; ++w) {
@@ -308,7 +339,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
                         float h;
                         if (it == 0 || n >= CACHE) {
                             float dist;
-                            pair_dist<LOOKUP>(me[u], unpack_xy(sm.xy[k]), table, dist);
+                            pair_dist<LOOKUP>(mine[u], unpack_xy(sm.xy[k]), table, dist);
                             h = h_value(dist);
                             if (n < CACHE) sm.x.stash[n * NMAX + t] = h;
                         } else h = sm.x.stash[n * NMAX + t];
