@@ -242,6 +242,42 @@ __device__ __forceinline__ bool pair_compatible(const Pt& a, const Pt& o, const 
     pair_dist<LOOKUP>(a, o, table, exact);
     return ok && exact < 30.0f;
 }
+// ---- texture lists whose block coordinates all lie in [0, 8191] (always, for real templates): the same two functions on the
+// packed (x | y << 16) words as they sit in LDS.  One v_pk_sub_i16 gives (dx, dy), one v_dot2_i32_i16 gives n = dx^2 + dy^2
+// (<= 4802 for an in-range pair), and table_dist[dx*50+dy] = RN(sqrt(256 n)) = 16 * RN(sqrt(n)) because scaling by a power of
+// two commutes with every rounding involved: dist = |d1 - d2| = 16 * |RN(sqrt n1) - RN(sqrt n2)| exactly.
+typedef short v2s16 __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool tex_pair_n(int2 a, int2 o, float& s1, float& s2)
+{
+    const v2s16 dl = __builtin_bit_cast(v2s16, a.x) - __builtin_bit_cast(v2s16, o.x);
+    const v2s16 dr = __builtin_bit_cast(v2s16, a.y) - __builtin_bit_cast(v2s16, o.y);
+    s1 = (float)__builtin_amdgcn_sdot2(dl, dl, 0, false);
+    s2 = (float)__builtin_amdgcn_sdot2(dr, dr, 0, false);
+    // |d| < 50 for all four components (matcher.cpp:1257)  <=>  (d + 49) as u16 <= 98
+    const v2u16 bias = {49, 49};
+    const v2u16 tl = __builtin_bit_cast(v2u16, dl) + bias, tr = __builtin_bit_cast(v2u16, dr) + bias;
+    const v2u16 mx = __builtin_elementwise_max(tl, tr);
+    return max((unsigned)mx.x, (unsigned)mx.y) <= 98u;
+}
+__device__ __forceinline__ bool tex_pair_dist(int2 a, int2 o, float& dist)
+{
+    float s1, s2;
+    const bool ok = tex_pair_n(a, o, s1, s2);
+    dist = 16.0f * fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2));
+    return ok;
+}
+__device__ __forceinline__ bool tex_pair_compatible(int2 a, int2 o)
+{
+    float s1, s2;
+    const bool ok = tex_pair_n(a, o, s1, s2);
+    const float q1 = __builtin_amdgcn_sqrtf(s1), q2 = __builtin_amdgcn_sqrtf(s2);
+    const float diff = fabsf(q1 - q2);                                   // dist / 16
+    const float slack = fmaxf(q1, q2) * 4.76837158e-7f;                  // 2^-21, as in pair_compatible
+    if (fabsf(diff - 1.875f) > slack) return ok && diff < 1.875f;
+    return ok && 16.0f * fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2)) < 30.0f;
+}
+
 // H = clamp((30 - dist)/(25.0), 0, 1) for dist <= 30 (matcher.cpp:1268-1272 / :1389-1393): float numerator, double divide,
 // float store.  (float)((double)x/25.0) == x/25.0f (double rounding through 53 bits is innocuous for a quotient of two
 // 24-bit values), and for every float x in [0, 30] the fma sequence below equals x/25.0f — checked exhaustively over all
@@ -257,20 +293,21 @@ __device__ __forceinline__ float h_value(float dist)
 }
 
 // S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
-template <class SM, bool LOOKUP, int ITERS>
+template <class SM, bool LOOKUP, int ITERS, bool PACKED>
 __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
 {
+    constexpr bool fast = LOOKUP && PACKED;
     constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX, CACHE = SM::CACHE;
     constexpr int PH = LOOKUP ? 8 : 0;
     GPH_INIT();
     const int lane = threadIdx.x;
     for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
-    Pt me[U];
+    int2 me[U];                                                           // own points, packed as in LDS
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int t = lane + 64 * u;
         if (t < SM::N4) { sm.b[t] = t < num ? sm.sim[t] : 0.0f; sm.y.cc[t] = 0.0f; }
-        me[u] = unpack_xy(t < num ? sm.xy[t] : make_int2(0, 0));
+        me[u] = t < num ? sm.xy[t] : make_int2(0, 0);
     }
     WSYNC();
     // non-zero pattern of the compatibility matrix (matcher.cpp:1237-1275 / :1363-1397): row t visits the pairs
@@ -283,7 +320,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
             const int t = lane + 64 * u;
             if (t < num && !(d == half && even && t >= half)) {       // even num: the antipodal pairs belong to the lower half
                 int k = t + d; if (k >= num) k -= num;
-                if (pair_compatible<LOOKUP>(me[u], unpack_xy(sm.xy[k]), table)) {
+                if (fast ? tex_pair_compatible(me[u], sm.xy[k]) : pair_compatible<LOOKUP>(unpack_xy(me[u]), unpack_xy(sm.xy[k]), table)) {
                     atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
                     atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
                 }
@@ -320,9 +357,9 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
         for (int u = 0; u < U; ++u) { const int p = lane + 64 * u; myrow[u] = p < num ? (int)sm.y.os.order[p] : -1; }
         WSYNC();
     }
-    Pt mine[U];
+    int2 mine[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) mine[u] = unpack_xy(myrow[u] >= 0 ? sm.xy[myrow[u]] : make_int2(0, 0));
+    for (int u = 0; u < U; ++u) mine[u] = myrow[u] >= 0 ? sm.xy[myrow[u]] : make_int2(0, 0);
     // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle)
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -339,7 +376,8 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
                         float h;
                         if (it == 0 || n >= CACHE) {
                             float dist;
-                            pair_dist<LOOKUP>(mine[u], unpack_xy(sm.xy[k]), table, dist);
+                            if (fast) tex_pair_dist(mine[u], sm.xy[k], dist);
+                            else pair_dist<LOOKUP>(unpack_xy(mine[u]), unpack_xy(sm.xy[k]), table, dist);
                             h = h_value(dist);
                             if (n < CACHE) sm.x.stash[n * NMAX + t] = h;
                         } else h = sm.x.stash[n * NMAX + t];
@@ -364,7 +402,8 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     const int nsel = greedy(sm, num, 0.0001, [&sm, table](int a, int o) {
         if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
         float dist;
-        pair_dist<LOOKUP>(unpack_xy(sm.xy[a]), unpack_xy(sm.xy[o]), table, dist);
+        if (fast) tex_pair_dist(sm.xy[a], sm.xy[o], dist);
+        else pair_dist<LOOKUP>(unpack_xy(sm.xy[a]), unpack_xy(sm.xy[o]), table, dist);
         return !((double)h_value(dist) < 0.00001);
     });
     compact(sm, nsel);
@@ -466,11 +505,12 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
 template <class SM, bool LOOKUP, int ITERS>
 __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
-                                             const float* __restrict__ rori, int& n_survivors, int stop_after = 2)
+                                             const float* __restrict__ rori, int& n_survivors, int stop_after = 2, bool packed_ok = false)
 {
     n_survivors = num;                                                     // stop_after 0: the candidate list itself (S3 / S7)
     if (stop_after == 0) return 0.0f;
-    num = dist_filter<SM, LOOKUP, ITERS>(sm, num, table);
+    // two instantiations rather than a flag inside the loops: the register budget is that of the path taken
+    num = (LOOKUP && packed_ok) ? dist_filter<SM, LOOKUP, ITERS, true>(sm, num, table) : dist_filter<SM, LOOKUP, ITERS, false>(sm, num, table);
     n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
     if (stop_after == 1) return 0.0f;
     n_survivors = 0;
@@ -566,14 +606,17 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             for (int t = lane; t < num; t += 64) { sm.sim[t] = rm_val[o + t]; sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
         }
         WSYNC();
+        int out_of_range = 0;                                            // any block coordinate outside [0, 8191]: generic arithmetic for this list
         for (int t = lane; t < num; t += 64) {
             const int a = sm.li[t], b = sm.ri[t];
             const short2 lp = q.lt_xy[l0 + a], rp = g.tex_xy[r0 + b];
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
+            out_of_range |= (lp.x | lp.y | rp.x | rp.y) & ~8191;
         }
+        const bool packed_ok = __ballot(out_of_range != 0) == 0ull;
         WSYNC();
         int n_surv;
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv, tap.out ? tap.stage : 2);   // :759, :767
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv, tap.out ? tap.stage : 2, packed_ok);   // :759, :767
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, task, n_surv, kTopTex);
         WSYNC();

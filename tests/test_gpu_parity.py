@@ -411,6 +411,37 @@ def test_cli_exchange_path_single_rank(codebook_bytes, cb, small, tmp_path):
         assert strip(o1.stdout) == strip(o2.stdout)
 
 
+def test_texture_coordinates_off_the_beaten_path(codebook_bytes, cb, oracle):
+    """S8b range rule and arithmetic paths: block coordinates spread over 0..120 (many pairs with |dx| or |dy| >= 50, which the
+    table look-up treats as incompatible, matcher.cpp:1257), beyond 8191 (the kernel's packed 16-bit fast path must step aside) and
+    >= 32768 (negative as the reference reads them into int16-backed storage).  Stage lists and scores against the oracle."""
+    rng = np.random.default_rng(21)
+    base = S.make_latent(rng, n_tex_lo=260, n_tex_hi=300)
+    ocb = oracle.codebook(codebook_bytes)
+
+    def spread(t, scale, offset=0):
+        x = ((t.x.astype(np.int64) * scale) // 10 + offset).astype(np.int64)
+        y = ((t.y.astype(np.int64) * scale) // 10 + offset).astype(np.int64)
+        return x.astype(np.uint16).view(np.int16), y.astype(np.uint16).view(np.int16)
+
+    for ci, (scale, off_l, off_r) in enumerate(((25, 0, 0), (25, 9000, 9000), (10, 40000, 40000), (25, 0, 8180))):
+        L = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(*spread(base.tex[0], scale, off_l), base.tex[0].ori, des=base.tex[0].des)])
+        R0 = S.make_mate(rng, cb, base, frac=0.7, n_tex=500)
+        rx, ry = spread(R0.tex[0], scale, off_r)
+        R = T.FPTemplate(minu=list(R0.minu), tex=[T.TextureTemplate(rx, ry, R0.tex[0].ori, codes=R0.tex[0].codes)])
+        m = M.Matcher(codebook_bytes); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
+        hl, _ = oracle.latent(ocb, T.write_latent(L)); hr, _ = oracle.rolled(T.write_rolled(R))
+        for stage in (0, 1, 2):
+            want = oracle.trace(ocb, hl, hr, which=0, stage=stage, tie_mode=1)
+            got = m.debug_stage_list(L, 0, 0, stage)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (ci, stage)
+            assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (ci, stage)
+        rc, want_sc = oracle.pair(ocb, hl, hr, 1)
+        got_sc = m.search([L], k=0, want_parts=True)["parts"][0, 0]
+        assert np.array_equal(got_sc.view(np.uint32), want_sc[:4].view(np.uint32)), (ci, got_sc, want_sc)
+        m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
