@@ -360,7 +360,14 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     int2 mine[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) mine[u] = myrow[u] >= 0 ? sm.xy[myrow[u]] : make_int2(0, 0);
-    // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle)
+    // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle).  Iteration 0 computes every
+    // value and stashes the first CACHE of each row; later iterations read those back and recompute only the rest.
+    auto value = [&](int2 own, int k) -> float {
+        float dist;
+        if (fast) tex_pair_dist(own, sm.xy[k], dist);
+        else pair_dist<LOOKUP>(unpack_xy(own), unpack_xy(sm.xy[k]), table, dist);
+        return h_value(dist);
+    };
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -370,20 +377,30 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
                 int n = 0;
                 for (int w = 0; w < (num + 31) / 32; ++w) {
                     uint32_t bits = sm.hb[t][w];
-                    while (bits) {
-                        const int k = w * 32 + __ffs(bits) - 1;
-                        bits &= bits - 1;
-                        float h;
-                        if (it == 0 || n >= CACHE) {
-                            float dist;
-                            if (fast) tex_pair_dist(mine[u], sm.xy[k], dist);
-                            else pair_dist<LOOKUP>(unpack_xy(mine[u]), unpack_xy(sm.xy[k]), table, dist);
-                            h = h_value(dist);
+                    if (it == 0) {
+                        while (bits) {
+                            const int k = w * 32 + __ffs(bits) - 1;
+                            bits &= bits - 1;
+                            const float h = value(mine[u], k);
                             if (n < CACHE) sm.x.stash[n * NMAX + t] = h;
-                        } else h = sm.x.stash[n * NMAX + t];
-                        const float p = h * sm.b[k];
-                        acc += p;
-                        ++n;
+                            const float p = h * sm.b[k];
+                            acc += p;
+                            ++n;
+                        }
+                    } else {
+                        while (bits && n < CACHE) {                      // stashed values
+                            const int k = w * 32 + __ffs(bits) - 1;
+                            bits &= bits - 1;
+                            const float p = sm.x.stash[n * NMAX + t] * sm.b[k];
+                            acc += p;
+                            ++n;
+                        }
+                        while (bits) {                                   // beyond the stash: recomputed
+                            const int k = w * 32 + __ffs(bits) - 1;
+                            bits &= bits - 1;
+                            const float p = value(mine[u], k) * sm.b[k];
+                            acc += p;
+                        }
                     }
                 }
                 sm.y.cc[t] = acc;
