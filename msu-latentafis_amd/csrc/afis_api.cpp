@@ -8,6 +8,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "afis_device.h"
@@ -140,14 +141,27 @@ void views_of(const HostTemplate& t, std::vector<afis_minutiae_view>& mv, std::v
     out.n_minu = (int)mv.size(); out.minu = mv.data(); out.n_tex = (int)tv.size(); out.tex = tv.data();
 }
 
+// host-side re-layouts at commit touch every byte of the shard once: split [0, n) over a few threads
+template <class F>
+void parallel_for(int64_t n, F body)
+{
+    const int64_t nt = std::min<int64_t>(std::max<int64_t>(1, (int64_t)std::thread::hardware_concurrency()), std::min<int64_t>(16, std::max<int64_t>(1, n / 256)));
+    if (nt <= 1) { body((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int64_t i = 0; i < nt; ++i) th.emplace_back(body, n * i / nt, n * (i + 1) / nt);
+    for (std::thread& t : th) t.join();
+}
+
 // k-permuted descriptor copy for the MFMA fragments: out[row][g*24 + s] = in[row][4*s + g]
 std::vector<float> permute_k(const std::vector<float>& in)
 {
     std::vector<float> out(in.size());
-    const size_t rows = in.size() / kDes;
-    for (size_t r = 0; r < rows; ++r)
-        for (int g = 0; g < 4; ++g)
-            for (int s = 0; s < 24; ++s) out[r * kDes + g * 24 + s] = in[r * kDes + 4 * s + g];
+    const int64_t rows = (int64_t)(in.size() / kDes);
+    parallel_for(rows, [&](int64_t lo, int64_t hi) {
+        for (int64_t r = lo; r < hi; ++r)
+            for (int g = 0; g < 4; ++g)
+                for (int s = 0; s < 24; ++s) out[(size_t)r * kDes + g * 24 + s] = in[(size_t)r * kDes + 4 * s + g];
+    });
     return out;
 }
 
@@ -428,7 +442,8 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
         if (nblk > 0x7fffffff / 64) return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for the ADC code stream; split the gallery into more shards");
         std::vector<uint8_t> cf((size_t)nblk * 64 * kM, 0);
         static const int perm[4] = {0, 2, 1, 3};
-        for (int64_t t = 0; t < G; ++t) {
+        parallel_for(G, [&](int64_t t_lo, int64_t t_hi) {
+        for (int64_t t = t_lo; t < t_hi; ++t) {
             const int64_t n = hg.tex_off[t + 1] - hg.tex_off[t];
             if (n <= 0) continue;
             const int64_t blocks = (n + 63) / 64;
@@ -445,6 +460,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
                     }
                 }
         }
+        });
         HIPCHK(ctx, upload(ctx->g_tex_codes_cf, cf, ctx->stream));
         HIPCHK(ctx, upload(ctx->g_tex_cf_blk, cfb, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
