@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Wide parity sweep (not part of the test suite): Q latents x G synthetic gallery templates, every per-part score and the fused
+score of every pair against the oracle (all host threads), bit for bit.  usage: python tools/parity_sweep.py [seed] [Q] [G]"""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle_lib import Oracle
+T = importlib.import_module("msu-latentafis_amd.host.templates"); S = importlib.import_module("msu-latentafis_amd.host.synth"); M = importlib.import_module("msu-latentafis_amd.host.matcher")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+Q = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+G = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read(); cb = T.Codebook.from_bytes(cbb)
+lats = S.make_latents(seed, Q); gal = S.make_packed_gallery(seed, G, cb); S.plant_mates(seed, gal, cb, lats, G=G)
+m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0)
+r = m.search(lats, k=0, want_parts=True)
+orc = Oracle(); ocb = orc.codebook(cbb)
+hr = [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(G)]
+t0 = time.time(); bad = 0; nz = 0
+for qi, L in enumerate(lats):
+    hl, _ = orc.latent(ocb, T.write_latent(L))
+    rc, sc, parts = orc.search(ocb, hl, hr, tie_mode=1, threads=orc.lib.orc_num_threads(), want_parts=True)
+    got = np.concatenate([r["parts"][qi], r["scores"][qi][:, None]], axis=1)
+    diff = got.view(np.uint32) != parts.view(np.uint32)
+    bad += int(diff.any(axis=1).sum()); nz += int((parts[:, :4] > 0).sum())
+    if diff.any():
+        g = int(np.argwhere(diff.any(axis=1))[0, 0]); print("first mismatch: query", qi, "gallery", g, "got", got[g], "want", parts[g])
+print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
