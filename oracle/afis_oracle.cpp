@@ -9,6 +9,8 @@
 //     PINNED: tests compare this file against oracle/_ref/libafis_ref.so, which is compiled from
 //     the reference's own header /root/reference/matching/include.h (self-contained, no
 //     third-party dependency).
+//   * The PQ encoder (orc_pq_encode; SURVEY §8f-1, extraction/descriptor_PQ.py:19-27) is PINNED to scipy.cluster.vq.vq — the
+//     routine the reference calls — through tests/golden/golden_pq.npz (made by tests/golden/make_golden_pq.py).
 //   * Everything that lives in /root/reference/matching/matcher.cpp (S1-S3, S5-S11, F1, F2) is
 //     "PARITY UNPINNED": matcher.cpp needs Eigen and Boost.Filesystem, which are neither in the
 //     reference tree nor in this image, the reference ships no tests or golden vectors for this
