@@ -178,9 +178,9 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
                          int32_t* counts /*[n][3]*/, int16_t* xy /*[n][3][120][4]*/);
 
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
-/* Tunables: "adc_variant" (0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups,
- * 4 = conflict-free lane classes, 5 = 4 with 1024-thread workgroups, 6/7 = 4/5 with one-instruction addressing, VCC-based
- * first-maximum update and a transposed wave reduction [7 = default]; all bit-identical), "query_batch" (latents per
+/* Tunables: "adc_variant" (0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups —
+ * kept as references; 6 = conflict-free lane classes with 512-thread workgroups, 7 = the same with 1024 [default]; all
+ * bit-identical; 4 and 5 were earlier forms of 6/7 and are rejected), "query_batch" (latents per
  * launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel),
  * "rowmax_budget_mb".  Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);

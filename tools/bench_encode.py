@@ -3,9 +3,11 @@
 The kernel-only time comes from running this script under `rocprofv3 --kernel-trace --stats` (k_pq_encode)."""
 import importlib, json, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 M = importlib.import_module("msu-latentafis_amd.host.matcher")
-cbb = open("/root/repo/tests/golden/codebook_EmbeddingSize_96_stride_16_subdim_6.dat", "rb").read()
+cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 rng = np.random.default_rng(0)
 des = rng.standard_normal((n, 96), dtype=np.float32) * 0.1

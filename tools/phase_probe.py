@@ -5,12 +5,14 @@
    Caveat (graph kernels): the counters are global atomics; a global load that follows them waits for them, so the angle
    stage's share is inflated.  Use the shares inside the distance stage and inside the candidate kernel."""
 import sys, importlib
-sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 T = importlib.import_module("msu-latentafis_amd.host.templates"); S = importlib.import_module("msu-latentafis_amd.host.synth"); M = importlib.import_module("msu-latentafis_amd.host.matcher")
-cbb = open("/root/repo/tests/golden/codebook_EmbeddingSize_96_stride_16_subdim_6.dat", "rb").read(); cb = T.Codebook.from_bytes(cbb)
+cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read(); cb = T.Codebook.from_bytes(cbb)
 G, Q = 10000, 4
 lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb); S.plant_mates(1, gal, cb, lats)
-m = M.Matcher(cbb, lib_path=sys.argv[1] if len(sys.argv) > 1 else "/root/repo/tools/libafis_phase.so")
+m = M.Matcher(cbb, lib_path=sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "libafis_phase.so"))
 m.gallery_add_packed(gal); m.gallery_commit(0); qh = m.upload_queries(lats)
 m.search_resident(qh); m.phase_cycles(True)
 m.search_resident(qh); ph = m.phase_cycles(True); tm = m.timing()
