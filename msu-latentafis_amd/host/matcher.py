@@ -337,15 +337,28 @@ class Matcher:
     def One2List_matching(self, latent_template_file: str, score_path: str, top: int = 24) -> int:
         """matcher.cpp:216-337: rank list of the top 24 as `<rank>"<path>",<score>` under a `filename,score` header."""
         with open(latent_template_file, "rb") as f:
-            r = self.search_dat([f.read()], k=min(top, max(1, self.gallery_size)))
+            buf = f.read()
+        r = self.search_dat([buf], k=min(top, max(1, self.gallery_size)))
         if r["status"][0] == 1:
             return 1
         stem = os.path.splitext(os.path.basename(latent_template_file))[0]
+        k = min(top, self.gallery_size)
+        idx = [int(r["topk_idx"][0, j]) for j in range(k)]
         with open(score_path + stem + ".csv", "w") as out:
             out.write("filename,score\n")
-            for j in range(min(top, self.gallery_size)):
-                g = int(r["topk_idx"][0, j])
+            for j, g in enumerate(idx):
                 out.write(f'{j + 1}"{self.gallery_files[g]}",{_cxx_float(r["topk_score"][0, j])}\n')
+        # correspondence files of the ranked templates (matcher.cpp:311-328, :497-505); the reference's hard-coded
+        # /LatentAFIS/scores/ prefix becomes the score directory, as in the `match` CLI
+        _, latent = read_latent(buf)
+        for g, lists in zip(idx, self.correspondences(latent, idx)):
+            rstem = os.path.splitext(os.path.basename(self.gallery_files[g]))[0]
+            for i, xy in enumerate(lists):
+                if xy is None:
+                    continue
+                with open(f"{score_path}corr{stem}_{rstem}_{i}.csv", "w") as cf:
+                    for lx, ly, rx, ry in xy:
+                        cf.write(f"{lx},{ly},{rx},{ry}\n")
         return 0
 
     def List2List_matching(self, latent_path: str, score_path: str) -> int:

@@ -442,6 +442,44 @@ def test_texture_coordinates_off_the_beaten_path(codebook_bytes, cb, oracle):
         m.close()
 
 
+def test_python_drivers_equal_cli(codebook_bytes, cb, small, tmp_path):
+    """host/matcher.py's One2List_matching / List2List_matching (the reference's two drivers, matcher.h:44-51) write the files the
+    `match` binary writes, from a directory and from a packed container."""
+    import os, subprocess
+    lats, gal = small
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    for d in ("gal", "lat", "cli", "py", "py2", "work"):
+        (tmp_path / d).mkdir()
+    for j, g in enumerate(gal[:9]):
+        (tmp_path / "gal" / f"R{j:03d}.dat").write_bytes(T.write_rolled(g))
+    (tmp_path / "gal" / "R_empty.dat").write_bytes(b"")
+    for i, L in enumerate(lats[:2]):
+        (tmp_path / "lat" / f"L{i}.dat").write_bytes(T.write_latent(L))
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    box = str(tmp_path / "g.afisgal")
+    common = ["-g", str(tmp_path / "gal"), "-c", str(cbp), "-s", str(tmp_path / "cli") + "/"]
+    for mode in (["-ldir", str(tmp_path / "lat")], ["-l", str(tmp_path / "lat" / "L1.dat"), "-pack", box]):
+        o = subprocess.run([exe] + mode + common, capture_output=True, text=True, cwd=tmp_path / "work")
+        assert o.returncode == 0, o.stderr
+    cli = {n: (tmp_path / "cli" / n).read_text() for n in os.listdir(tmp_path / "cli")}
+    # the -l run came last, so L1.csv holds the rank list; L0.csv the List2List scores
+    for src, out in ((str(tmp_path / "gal"), "py"), (box, "py2")):
+        m = M.Matcher(str(cbp))
+        files = m.load_gallery_dir(src)
+        assert len(files) == 10
+        assert m.List2List_matching(str(tmp_path / "lat"), str(tmp_path / out) + "/") == 0
+        l0 = (tmp_path / out / "L0.csv").read_text()
+        assert sorted(l0.splitlines()) == sorted(cli["L0.csv"].splitlines())          # directory order may differ between the two listings
+        assert m.One2List_matching(str(tmp_path / "lat" / "L1.dat"), str(tmp_path / out) + "/") == 0
+        got = {n: (tmp_path / out / n).read_text() for n in os.listdir(tmp_path / out)}
+        assert got["L1.csv"] == cli["L1.csv"]
+        corr = [n for n in cli if n.startswith("corr")]
+        assert corr and sorted(n for n in got if n.startswith("corr")) == sorted(corr)
+        for n in corr:
+            assert got[n] == cli[n], n
+        m.close()
+
+
 def test_edge_fusion_rules(codebook_bytes, cb, oracle):
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
