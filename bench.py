@@ -187,7 +187,11 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             pps, cores, sample, pps8 = cpu_baseline(cb_bytes, lats, gal, lo)
-            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": cores, "kind": "port", "sample": sample,
+            try:
+                cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except Exception:
+                cpu_model = "unknown"
+            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": cores, "kind": "port", "sample": sample, "cpu_model": cpu_model,
                                    "pairs_per_s": round(pps, 1), "reference_setting_8_threads_static16_queries_per_s": round(pps8 / G, 6)}
             out["speedup_vs_cpu_baseline"] = round(value / (pps / G), 1)
     m.free_queries(qh)
