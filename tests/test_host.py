@@ -228,3 +228,45 @@ def test_gallery_container_cpp_and_python_agree(cb, tio, tmp_path):
     assert "error=" in out and "range" in out
     with pytest.raises(ValueError):
         CT.read_container(str(bad))
+
+
+def test_readers_survive_damaged_files(cb, tio, tmp_path):
+    """Truncated and bit-flipped templates / containers: the C++ readers return a code or an error, they never crash or hang
+    (the reference's ifstream-based reader likewise just stops filling its buffers at EOF, matcher.cpp:785-983)."""
+    rng = np.random.default_rng(17)
+    lat = T.write_latent(S.make_latent(rng, n_tex_lo=60, n_tex_hi=80, n_minu_lo=5, n_minu_hi=9))
+    rol = T.write_rolled(S.make_rolled(rng, cb, n_tex=70, n_minu=12))
+    cases_ = []
+    for kind, buf in (("latent", lat), ("rolled", rol)):
+        for cut in [0, 1, 5, 10, 11, 23, 24, 25, 33, 34, 35, 40, len(buf) // 3, len(buf) // 2, len(buf) - 1]:
+            cases_.append((kind, buf[:cut]))
+        for _ in range(40):
+            b = bytearray(buf)
+            for pos in rng.integers(0, min(len(b), 400), 3):          # headers and counts are where damage matters
+                b[pos] = int(rng.integers(0, 256))
+            cases_.append((kind, bytes(b)))
+    for i, (kind, data) in enumerate(cases_):
+        p = tmp_path / f"d{i}.dat"; p.write_bytes(data)
+        r = subprocess.run([tio, kind, str(p)], capture_output=True, text=True, timeout=20)
+        assert r.returncode in (0, 1) and r.stdout.startswith("rc="), (kind, i, r.returncode, r.stderr[:200])
+        # the Python mirror agrees on the return code and the template counts
+        rc, t = (T.read_latent if kind == "latent" else T.read_rolled)(data)
+        m = re.match(r"rc=(-?\d+) n_minu=(\d+) n_tex=(\d+)", r.stdout)
+        assert m and int(m.group(1)) == rc and (int(m.group(2)), int(m.group(3))) == (len(t.minu), len(t.tex)) or rc < 0, (kind, i, r.stdout[:80], rc)
+    CT = importlib.import_module("msu-latentafis_amd.host.container")
+    good = tmp_path / "g.afisgal"
+    files = []
+    for i in range(3):
+        f = tmp_path / f"R{i}.dat"; f.write_bytes(T.write_rolled(S.make_rolled(rng, cb, n_tex=30, n_minu=6))); files.append(str(f))
+    subprocess.run([tio, "gallery-pack", str(good)] + files, check=True, capture_output=True)
+    raw = good.read_bytes()
+    for i in range(60):
+        b = bytearray(raw)
+        if i % 3 == 0:
+            b = b[:int(rng.integers(0, len(b)))]
+        else:
+            for pos in rng.integers(8, 160, 2):
+                b[pos] = int(rng.integers(0, 256))
+        p = tmp_path / f"c{i}.afisgal"; p.write_bytes(bytes(b))
+        r = subprocess.run([tio, "gallery-dump", str(p)], capture_output=True, text=True, timeout=20)
+        assert r.returncode in (0, 1) and (r.stdout.startswith("G=") or r.stdout.startswith("error=")), (i, r.returncode, r.stdout[:100], r.stderr[:200])
