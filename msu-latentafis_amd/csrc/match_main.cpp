@@ -203,6 +203,11 @@ int main(int argc, char** argv)
         std::cout << "rank " << w.rank << " of " << w.world << " id " << sum << std::endl;
         return 0;
     }
+    if (argc >= 3 && !strcmp(argv[1], "-selftest-args")) {                      // token rules (no GPU): match -selftest-args <opt> <tokens...>
+        ArgParser rest(argc - 2, argv + 2);                                     // argv[2] plays the program name, as argv[0] would
+        std::cout << "exists=" << (rest.cmdOptionExists(argv[2]) ? 1 : 0) << " value=" << rest.getCmdOption(argv[2]) << std::endl;
+        return 0;
+    }
     if (args.cmdOptionExists("-selftest-shards")) {                             // shard cut rule (no GPU): weights file (one int per line), world
         std::ifstream f(args.getCmdOption("-selftest-shards"));
         std::vector<int32_t> wts; int v;

@@ -10,9 +10,14 @@
 //   * RolledTextureTemplatePQ(n,x,y,ori,des_len,des)  (include.h:401-406)   -> PQ code extraction from the
 //     float-typed read buffer, and the short->int point conversion (include.h:171-193)
 //   * MinutiaeTemplate(...) (include.h:215-237)                                -> descriptor/point copy
+//   * ArgParser (matching/argparser.h, also self-contained once <string> and <algorithm> are in scope, as main.cpp has them)
+//                                                                              -> the `match` command line's token rules
 #include "include.h"
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <string>
+#include "argparser.h"
 
 extern "C" {
 
@@ -48,5 +53,14 @@ void ref_minutiae_template(int n, const short* x, const short* y, const float* o
 }
 
 double ref_pi(void) { return PI; }
+
+// matching/argparser.h through the reference class: returns cmdOptionExists(opt); out = getCmdOption(opt)
+int ref_arg(int argc, char** argv, const char* opt, char* out, int cap)
+{
+    ArgParser a(argc, argv);
+    const std::string& v = a.getCmdOption(opt);
+    strncpy(out, v.c_str(), (size_t)cap - 1); out[cap - 1] = 0;
+    return a.cmdOptionExists(opt) ? 1 : 0;
+}
 
 }  // extern "C"

@@ -131,6 +131,13 @@ class RefHarness:
         self.lib = _load(so)
         self.lib.ref_pi.restype = C.c_double
 
+    def arg(self, argv, opt):
+        """(exists, value) of `opt` in the command line `argv` (argv[0] = program name), per matching/argparser.h."""
+        arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
+        out = C.create_string_buffer(4096)
+        ex = self.lib.ref_arg(len(argv), arr, opt.encode(), out, 4096)
+        return bool(ex), out.value.decode()
+
     def build_lut(self, des, words):
         des = np.ascontiguousarray(des, np.float32); words = np.ascontiguousarray(words, np.float32)
         n, dl = des.shape; M, K, dsub = words.shape

@@ -165,3 +165,22 @@ def test_pq_encoder_pinned_to_scipy_golden(oracle, codebook_bytes, templates_mod
     assert np.array_equal(dec, g["des"][:64])
     # the host-side numpy helper used by the synthetic generator agrees as well
     assert np.array_equal(cb.encode(g["des"]), g["codes"])
+
+
+def test_cli_token_rules_pinned_by_reference_argparser():
+    """`match`'s flag parsing against the reference's own matching/argparser.h (compiled into oracle/_ref): first occurrence wins,
+    a flag at the end of the line exists but has an empty value, a value may look like a flag."""
+    import os, subprocess
+    from oracle_lib import RefHarness
+    ref = RefHarness()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "match"], check=True)
+    lines = [["-l", "a.dat", "-g", "gal/", "-s", "out/", "-c", "cb.dat"], ["-g", "gal", "-l"], ["-l", "-g", "x"], ["-s", "1", "-s", "2"],
+             [], ["-ldir", "d", "-l", "f"], ["-c"], ["--c", "x", "-c", "y"]]
+    for toks in lines:
+        for opt in ("-l", "-ldir", "-g", "-s", "-c", "-d"):
+            want = ref.arg(["match"] + toks, opt)
+            out = subprocess.run([exe, "-selftest-args", opt] + toks, capture_output=True, text=True, check=True).stdout.rstrip("\n")
+            assert out == f"exists={int(want[0])} value={want[1]}", (toks, opt, out, want)
