@@ -172,7 +172,11 @@ def test_cli_token_rules_pinned_by_reference_argparser():
     a flag at the end of the line exists but has an empty value, a value may look like a flag."""
     import os, subprocess
     from oracle_lib import RefHarness
-    ref = RefHarness()
+    try:
+        ref = RefHarness()
+        ref.lib.ref_arg
+    except (FileNotFoundError, OSError, AttributeError):
+        pytest.skip("oracle/_ref/libafis_ref.so not built with argparser.h (needs /root/reference)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match")
     if not os.path.exists(exe):
