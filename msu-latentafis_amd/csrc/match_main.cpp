@@ -208,6 +208,12 @@ int main(int argc, char** argv)
         std::cout << "exists=" << (rest.cmdOptionExists(argv[2]) ? 1 : 0) << " value=" << rest.getCmdOption(argv[2]) << std::endl;
         return 0;
     }
+    if (args.cmdOptionExists("-selftest-config")) {                             // config reader (no GPU): match -selftest-config <file> -key <key>
+        const auto kv = read_flat_json(args.getCmdOption("-selftest-config"));
+        const auto it = kv.find(args.getCmdOption("-key"));
+        std::cout << "found=" << (it != kv.end() ? 1 : 0) << " value=" << (it != kv.end() ? it->second : std::string()) << std::endl;
+        return 0;
+    }
     if (args.cmdOptionExists("-selftest-shards")) {                             // shard cut rule (no GPU): weights file (one int per line), world
         std::ifstream f(args.getCmdOption("-selftest-shards"));
         std::vector<int32_t> wts; int v;

@@ -12,12 +12,16 @@
 //   * MinutiaeTemplate(...) (include.h:215-237)                                -> descriptor/point copy
 //   * ArgParser (matching/argparser.h, also self-contained once <string> and <algorithm> are in scope, as main.cpp has them)
 //                                                                              -> the `match` command line's token rules
+//   * json.hpp (the JSON library vendored in matching/, used by main.cpp:41-44 to read ../afis.config)
+//                                                                              -> the config-file fallback of the CLIs
 #include "include.h"
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
 #include "argparser.h"
+#include <fstream>
+#include "json.hpp"
 
 extern "C" {
 
@@ -53,6 +57,22 @@ void ref_minutiae_template(int n, const short* x, const short* y, const float* o
 }
 
 double ref_pi(void) { return PI; }
+
+// main.cpp:41-44 + :50/:60/:71: `ifstream i(path); json config; i >> config; string v = config[key];`
+// returns 1 and the value, 0 when the key is absent, -1 when the file does not parse or the value is not a string
+int ref_config_get(const char* path, const char* key, char* out, int cap)
+{
+    out[0] = 0;
+    try {
+        std::ifstream i(path);
+        nlohmann::json config;
+        i >> config;
+        if (!config.contains(key)) return 0;
+        const std::string v = config[key];
+        strncpy(out, v.c_str(), (size_t)cap - 1); out[cap - 1] = 0;
+        return 1;
+    } catch (...) { return -1; }
+}
 
 // matching/argparser.h through the reference class: returns cmdOptionExists(opt); out = getCmdOption(opt)
 int ref_arg(int argc, char** argv, const char* opt, char* out, int cap)

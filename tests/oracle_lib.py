@@ -138,6 +138,12 @@ class RefHarness:
         ex = self.lib.ref_arg(len(argv), arr, opt.encode(), out, 4096)
         return bool(ex), out.value.decode()
 
+    def config_get(self, path, key):
+        """(rc, value): main.cpp:41-44 with the JSON library vendored in the reference (1 found, 0 absent, -1 unreadable)."""
+        out = C.create_string_buffer(8192)
+        rc = self.lib.ref_config_get(path.encode(), key.encode(), out, 8192)
+        return rc, out.value.decode()
+
     def build_lut(self, des, words):
         des = np.ascontiguousarray(des, np.float32); words = np.ascontiguousarray(words, np.float32)
         n, dl = des.shape; M, K, dsub = words.shape

@@ -188,3 +188,35 @@ def test_cli_token_rules_pinned_by_reference_argparser():
             want = ref.arg(["match"] + toks, opt)
             out = subprocess.run([exe, "-selftest-args", opt] + toks, capture_output=True, text=True, check=True).stdout.rstrip("\n")
             assert out == f"exists={int(want[0])} value={want[1]}", (toks, opt, out, want)
+
+
+def test_config_fallback_pinned_by_reference_json_library(tmp_path):
+    """`../afis.config` as main.cpp:41-44 reads it — with the JSON library vendored in the reference tree — against the flat reader
+    of the `match` CLI: the reference's own key set, escapes in values, extra whitespace, non-string values next to the keys."""
+    import os, subprocess
+    from oracle_lib import RefHarness
+    try:
+        ref = RefHarness()
+        ref.lib.ref_config_get
+    except (FileNotFoundError, OSError, AttributeError):
+        pytest.skip("oracle/_ref/libafis_ref.so not built with json.hpp (needs /root/reference)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "match"], check=True)
+    keys = ["CodebookPath", "ScorePath", "GalleryTemplateDirectory", "LatentTemplateDirectory", "MinuPath", "Absent"]
+    texts = [
+        '{\n\t"CodebookPath": "/home/x/codebook.dat",\n\t"ScorePath": "/home/x/scores",\n\n\t"GalleryTemplateDirectory": "/g",\n'
+        '\t"LatentTemplateDirectory": "/l",\n\t"MinuPath": "None"\n\n}\n',
+        '{"ScorePath":"a b/c",   "CodebookPath" :\n "q\\\\r\\"s" , "Depth": 3, "Flag": true, "GalleryTemplateDirectory": "/g/"}',
+        '{ "LatentTemplateDirectory": "", "ScorePath": "/s/", "Nested": {"CodebookPath": "inner"}, "List": ["x", "y"] }',
+    ]
+    for n, text in enumerate(texts):
+        f = tmp_path / f"c{n}.config"; f.write_text(text)
+        for key in keys:
+            rc, want = ref.config_get(str(f), key)
+            out = subprocess.run([exe, "-selftest-config", str(f), "-key", key], capture_output=True, text=True, check=True).stdout.rstrip("\n")
+            if rc == 1:
+                assert out == f"found=1 value={want}", (n, key, out, want)
+            elif n < 2:                                  # flat files: absent in one reader = absent in the other
+                assert out == "found=0 value=", (n, key, out)
