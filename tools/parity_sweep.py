@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """Wide parity sweep (not part of the test suite): Q latents x G synthetic gallery templates, every per-part score and the fused
-score of every pair against the oracle (all host threads), bit for bit.  usage: python tools/parity_sweep.py [seed] [Q] [G]"""
+score of every pair against the oracle (all host threads), bit for bit in tie_mode=1 (equal keys by ascending index, what the HIP
+path implements) and, with a 4th argument, against tie_mode=0 (libstdc++ std::sort order, what the reference binary executes):
+positive pairs with any differing bit / beyond 1e-3, top-24 changes.  usage: python tools/parity_sweep.py [seed] [Q] [G] [tie0]
+(tools/tie_sweep.py does the tie_mode 0-vs-1 comparison on the CPU alone.)"""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +19,8 @@ m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0)
 r = m.search(lats, k=0, want_parts=True)
 orc = Oracle(); ocb = orc.codebook(cbb)
 hr = [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(G)]
-t0 = time.time(); bad = 0; nz = 0
+TIE0 = len(sys.argv) > 4
+t0 = time.time(); bad = 0; nz = 0; pos0 = bit0 = far0 = top0 = 0
 for qi, L in enumerate(lats):
     hl, _ = orc.latent(ocb, T.write_latent(L))
     rc, sc, parts = orc.search(ocb, hl, hr, tie_mode=1, threads=orc.lib.orc_num_threads(), want_parts=True)
@@ -25,4 +29,15 @@ for qi, L in enumerate(lats):
     bad += int(diff.any(axis=1).sum()); nz += int((parts[:, :4] > 0).sum())
     if diff.any():
         g = int(np.argwhere(diff.any(axis=1))[0, 0]); print("first mismatch: query", qi, "gallery", g, "got", got[g], "want", parts[g])
+    if TIE0:
+        rc, s0, p0 = orc.search(ocb, hl, hr, tie_mode=0, threads=orc.lib.orc_num_threads(), want_parts=True)
+        gs = r["scores"][qi]
+        pos = (s0 > 0) | (gs > 0)
+        pos0 += int(pos.sum()); bit0 += int((pos & (s0.view(np.uint32) != gs.view(np.uint32))).sum())
+        far0 += int((np.abs(s0 - gs) > 1e-3 * np.maximum(1.0, np.abs(s0))).sum())
+        a = np.lexsort((np.arange(G), -s0.astype(np.float64)))[:24]; b = np.lexsort((np.arange(G), -gs.astype(np.float64)))[:24]
+        npos = int(min((s0[a] > 0).sum(), (gs[b] > 0).sum()))
+        top0 += int(not np.array_equal(a[:npos], b[:npos]))
 print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
+if TIE0:
+    print(f"  vs tie_mode=0 (reference sort order): {pos0} positive pairs, {bit0} with a differing bit, {far0} beyond 1e-3, queries whose positive top-24 order changes: {top0}")
