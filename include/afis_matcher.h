@@ -199,6 +199,10 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
 int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_t g, int which, int stage,
                           float* sim, int32_t* li, int32_t* ri, int32_t* n);
 
+/* S9: the angle stage's atan2 (matching/matcher.cpp:1516, :1524) on every integer coordinate difference of the grid
+ * [-R, R]^2: out[(dy + R) * (2R + 1) + (dx + R)] = line angle atan2(dy, dx) as the device evaluates it.  R <= 4096. */
+int afis_debug_atan2_grid(afis_ctx* ctx, int R, float* out);
+
 /* In-kernel phase timers (only when the library is built with PHASE_TIMING=1; all zeros otherwise): 32 cycle counters
  * accumulated since the last reset.  Development aid. */
 int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset);

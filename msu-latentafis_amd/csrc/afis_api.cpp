@@ -833,6 +833,21 @@ int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset)
     return AFIS_OK;
 }
 
+int afis_debug_atan2_grid(afis_ctx* ctx, int R, float* out)
+{
+    if (!ctx || !out || R < 0 || R > 4096) return fail(ctx, AFIS_EINVAL, "afis_debug_atan2_grid: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)(2 * R + 1) * (2 * R + 1);
+    DevBuf d;
+    HIPCHK(ctx, d.ensure(n * 4));
+    hipError_t e = launch_debug_atan2_grid(R, d.as<float>(), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d.p, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e != hipSuccess) return fail(ctx, AFIS_EDEVICE, std::string("afis_debug_atan2_grid: ") + hipGetErrorString(e));
+    return AFIS_OK;
+}
+
 int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, int32_t* n_rows)
 {
     if (!ctx || !query || !out) return fail(ctx, AFIS_EINVAL, "afis_debug_lut: null argument");

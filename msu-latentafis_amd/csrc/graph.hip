@@ -23,6 +23,7 @@
 //   * H (200x200 fp32 = 160 KB)        -> never stored: LDS keeps the bitmask of its non-zero entries, values are recomputed on
 //                                        demand and cached per row; a zero entry would only add +0.0f, so skipping it is exact.
 #include "afis_device.h"
+#include "atan2f_libm.h"
 
 namespace afis {
 
@@ -439,9 +440,10 @@ __device__ __forceinline__ float fold_pi(float d)                      // "if(an
     if ((double)d > AFIS_PI) d = (float)(2 * AFIS_PI - (double)d);
     return d;
 }
-// atan2f of the reference (glibc) replaced by a double-precision atan2 rounded to float: equal to a correctly
-// rounded atan2f except for results within 1e-16 relative of a rounding boundary.  The value only feeds threshold tests.
-__device__ __forceinline__ float atan2_f32(float y, float x) { return (float)atan2((double)y, (double)x); }
+// atan2f of the reference's CPU build = the C library's (matcher.cpp:1516, :1524).  glibc's routine is not correctly rounded (a
+// correctly rounded atan2 differs from it by one ulp on 16 % of the integer coordinate differences), so the device evaluates
+// the same fp32 operation sequence instead (atan2f_libm.h); tests compare the two exhaustively over [-2047, 2047]^2.
+__device__ __forceinline__ float atan2_f32(float y, float x) { return afis_atan2f_libm(y, x); }
 
 // the three angle tests of matcher.cpp:1495-1549 for the ordered pair (1 = lower index, 2 = higher index)
 __device__ __forceinline__ bool angle_compatible(const Pt& p1, float lo1, float ro1, const Pt& p2, float lo2, float ro2)
@@ -705,6 +707,22 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
     if (n_tasks <= 0) return hipSuccess;
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
     hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, GraphTap{tap_out, tap_n, tap_stage});
+    return hipGetLastError();
+}
+
+// parity tap: the device's atan2 on the grid of integer coordinate differences, out[(dy + R) * (2R + 1) + (dx + R)]
+__global__ __launch_bounds__(256) void k_debug_atan2_grid(int R, float* __restrict__ out)
+{
+    const int W = 2 * R + 1;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)W * W) return;
+    const int dy = (int)(idx / W) - R, dx = (int)(idx % W) - R;
+    out[idx] = atan2_f32((float)dy, (float)dx);
+}
+hipError_t launch_debug_atan2_grid(int R, float* out, hipStream_t stream)
+{
+    const long long n = (long long)(2 * R + 1) * (2 * R + 1);
+    hipLaunchKernelGGL(k_debug_atan2_grid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, R, out);
     return hipGetLastError();
 }
 

@@ -711,6 +711,17 @@ int orc_trace(void* cbp, void* lat, void* rol, int tie_mode, int which, int stag
 // S11: one latent against a list of rolled handles (the body of the OpenMP loop, matcher.cpp:168-190).
 // scores[j] = final or -1 (rolled empty).  Returns 1 if the latent is empty (whole query skipped).
 // threads <= 0: the reference's own setting, 8 threads schedule(static,16).
+// The libm atan2f this oracle (and a CPU build of the reference, matcher.cpp:1516/:1524) evaluates, on the grid of integer
+// coordinate differences: out[(dy + R) * (2R + 1) + (dx + R)] = atan2f((float)dy, (float)dx).  The GPU tests compare the device's
+// atan2 against this table exhaustively over the coordinate range of real templates.
+void orc_atan2f_grid(int R, float* out)
+{
+    const int W = 2 * R + 1;
+#pragma omp parallel for
+    for (int dy = -R; dy <= R; ++dy)
+        for (int dx = -R; dx <= R; ++dx) out[(size_t)(dy + R) * W + (dx + R)] = atan2f((float)dy, (float)dx);
+}
+
 int orc_search(void* cb, void* lat, void** rolled, int n, int tie_mode, int threads, float* scores, float* parts /*[n][5] or NULL*/)
 {
     int result = 0;

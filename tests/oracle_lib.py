@@ -45,6 +45,7 @@ class Oracle:
         L.orc_search.restype = C.c_int
         L.orc_search.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, fp, fp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_atan2f_grid.restype = None; L.orc_atan2f_grid.argtypes = [C.c_int, fp]
 
     # -- handles
     def codebook(self, buf: bytes):
@@ -108,6 +109,11 @@ class Oracle:
         if n < 0:
             return None
         return sim[:n], li[:n], ri[:n]
+
+    def atan2f_grid(self, R):
+        out = np.empty((2 * R + 1, 2 * R + 1), np.float32)
+        self.lib.orc_atan2f_grid(R, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
 
     def search(self, cb, lat, rolled_handles, tie_mode=1, threads=0, want_parts=False):
         n = len(rolled_handles)

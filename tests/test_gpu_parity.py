@@ -707,3 +707,17 @@ def test_edge_shapes_against_oracle(codebook_bytes, cb, oracle):
         assert not diff.any(), (qi, np.argwhere(diff), got[diff], parts[diff])
     assert res["scores"][0, 0] > 100 and res["scores"][2, 4] > 50
     print("edge shapes: max rel err", worst)
+
+
+def test_angle_stage_atan2_equals_libm_on_every_coordinate_difference(codebook_bytes, oracle):
+    """The angle tests of matcher.cpp:1503-1549 compare line angles -atan2f(dy, dx) with pi/6 in double; the device evaluates
+    atan2 in double and rounds to float.  Its arguments are differences of integer point coordinates, so the claim "same bits
+    as the CPU's atan2f" is checked here EXHAUSTIVELY over every (dy, dx) with |dy|, |dx| <= 2047 — the whole range of
+    minutiae pixel coordinates (images up to 2048 px; the generator's are 768 x 800) and of texture block coordinates."""
+    R = 2047
+    m = M.Matcher(codebook_bytes)
+    got = m.debug_atan2_grid(R)
+    m.close()
+    want = oracle.atan2f_grid(R)
+    diff = got.view(np.uint32) != want.view(np.uint32)
+    assert not diff.any(), (int(diff.sum()), np.argwhere(diff)[:5] - R, got[diff][:5], want[diff][:5])

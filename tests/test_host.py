@@ -114,7 +114,7 @@ def test_header_only_template_when_no_minutiae(cb):
 
 def test_abi_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "afis_matcher.h")).read()
-    declared = sorted(set(re.findall(r"\b(afis_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(afis_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 18
     lib = M.load_library()                       # dlopen only: no device call
     for name in declared:
@@ -270,3 +270,13 @@ def test_readers_survive_damaged_files(cb, tio, tmp_path):
         p = tmp_path / f"c{i}.afisgal"; p.write_bytes(bytes(b))
         r = subprocess.run([tio, "gallery-dump", str(p)], capture_output=True, text=True, timeout=20)
         assert r.returncode in (0, 1) and (r.stdout.startswith("G=") or r.stdout.startswith("error=")), (i, r.returncode, r.stdout[:100], r.stderr[:200])
+
+
+def test_device_atan2f_restatement_equals_libm_on_the_host(tmp_path):
+    """csrc/atan2f_libm.h (the angle stage's atan2, compiled here for the host) against the C library's atan2f on every integer
+    coordinate difference |d| <= 700 and a non-integer sweep; the GPU test repeats it on the device over |d| <= 2047."""
+    exe = tmp_path / "atan2f_check"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-o", str(exe), os.path.join(ROOT, "tools", "atan2f_check.c"), "-lm"], check=True)
+    out = subprocess.run([str(exe), "700"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "1962801 points, 0 mismatches" in out.stdout and "16000000 points, 0 mismatches" in out.stdout
