@@ -40,10 +40,10 @@ struct DevBuf {
 // One group of latents resident on the device.
 struct QueryGroup {
     QueryDev dev;
-    DevBuf lm_off, lm_xy, lm_ori, lm_des, lm_desp, lt_off, lt_xy, lt_ori, lt_des, tile_off, tex_slot, status;
+    DevBuf lm_off, lm_xy, lm_ori, lm_des, lm_frag, lm_tile_off, lt_off, lt_xy, lt_ori, lt_des, tile_off, tex_slot, status;
     int nq = 0; int max_nL = 0; int64_t lut_rows_x_tiles = 0;
     std::vector<int32_t> h_lt_n;
-    void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lm_desp.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
+    void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lm_frag.release(); lm_tile_off.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
                      lt_des.release(); tile_off.release(); tex_slot.release(); status.release(); }
 };
 
@@ -63,10 +63,10 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_desp, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_empty;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_empty;
     int max_nR = 0;
     int64_t total_tex_points = 0;
-    DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n;
+    DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 7;
     int query_batch = 8;
@@ -152,22 +152,35 @@ void parallel_for(int64_t n, F body)
     for (std::thread& t : th) t.join();
 }
 
-// k-permuted descriptor copy for the MFMA fragments: out[row][g*24 + s] = in[row][4*s + g]
-std::vector<float> permute_k(const std::vector<float>& in)
+// Descriptors re-laid as operand fragments of v_mfma_f32_16x16x4_f32 (minu.hip): template t (rows off[t] .. off[t+1]) becomes
+// ceil(n/16) tiles of 6 x 64 float4; lane l of load v holds des[16*tile + (l&15)][4*(4v + c) + (l>>4)], c = 0..3.  Rows past the
+// template's end are zero.  tile_off[t] = first tile of template t.
+template <class Off>
+std::vector<float> fragment_tiles(const std::vector<float>& des, const std::vector<Off>& off, std::vector<int32_t>& tile_off)
 {
-    std::vector<float> out(in.size());
-    const int64_t rows = (int64_t)(in.size() / kDes);
-    parallel_for(rows, [&](int64_t lo, int64_t hi) {
-        for (int64_t r = lo; r < hi; ++r)
-            for (int g = 0; g < 4; ++g)
-                for (int s = 0; s < 24; ++s) out[(size_t)r * kDes + g * 24 + s] = in[(size_t)r * kDes + 4 * s + g];
+    const int64_t T = (int64_t)off.size() - 1;
+    tile_off.assign((size_t)T + 1, 0);
+    for (int64_t t = 0; t < T; ++t) tile_off[(size_t)t + 1] = tile_off[(size_t)t] + (int32_t)((off[(size_t)t + 1] - off[(size_t)t] + 15) / 16);
+    std::vector<float> out((size_t)tile_off[(size_t)T] * 6 * 64 * 4, 0.0f);
+    parallel_for(T, [&](int64_t lo, int64_t hi) {
+        for (int64_t t = lo; t < hi; ++t) {
+            const int64_t r0 = (int64_t)off[(size_t)t], n = (int64_t)off[(size_t)t + 1] - r0;
+            for (int64_t row = 0; row < n; ++row) {
+                const float* src = &des[(size_t)(r0 + row) * kDes];
+                float* tile = &out[(size_t)(tile_off[(size_t)t] + row / 16) * 6 * 64 * 4];
+                const int li = (int)(row & 15);
+                for (int v = 0; v < 6; ++v)
+                    for (int lg = 0; lg < 4; ++lg)
+                        for (int c = 0; c < 4; ++c) tile[((size_t)v * 64 + lg * 16 + li) * 4 + c] = src[4 * (4 * v + c) + lg];
+            }
+        }
     });
     return out;
 }
 
 void free_gallery_dev(afis_ctx* c)
 {
-    c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_desp.release();
+    c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
     c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_empty.release();
 }
 
@@ -222,7 +235,7 @@ void afis_destroy(afis_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
-    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release();
+    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release();
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -426,7 +439,12 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     HIPCHK(ctx, upload(ctx->g_minu_xy, mxy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_ori, hg.mori, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_des, hg.mdes, ctx->stream));
-    { const std::vector<float> p = permute_k(hg.mdes); HIPCHK(ctx, upload(ctx->g_minu_desp, p, ctx->stream)); HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); }
+    {
+        std::vector<int32_t> toff;
+        const std::vector<float> p = fragment_tiles(hg.mdes, hg.minu_off, toff);
+        HIPCHK(ctx, upload(ctx->g_minu_frag, p, ctx->stream)); HIPCHK(ctx, upload(ctx->g_minu_tile_off, toff, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     HIPCHK(ctx, upload(ctx->g_tex_off, to, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
@@ -470,7 +488,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     GalleryDev& g = ctx->gal;
     g.G = (int32_t)G;
     g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
-    g.minu_des = ctx->g_minu_des.as<float>(); g.minu_desp = ctx->g_minu_desp.as<float>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
+    g.minu_des = ctx->g_minu_des.as<float>(); g.minu_frag = ctx->g_minu_frag.as<float4>(); g.minu_tile_off = ctx->g_minu_tile_off.as<int32_t>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
     g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
     ctx->max_nR = max_nR;
     ctx->total_tex_points = (int64_t)hg.tx.size();
@@ -534,14 +552,15 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
     hipStream_t s = ctx->stream;
     HIPCHK(ctx, upload(grp.lm_off, lm_off, s)); HIPCHK(ctx, upload(grp.lm_xy, lm_xy, s)); HIPCHK(ctx, upload(grp.lm_ori, lm_ori, s));
     HIPCHK(ctx, upload(grp.lm_des, lm_des, s)); HIPCHK(ctx, upload(grp.lt_off, lt_off, s));
-    const std::vector<float> lm_desp = permute_k(lm_des);
-    HIPCHK(ctx, upload(grp.lm_desp, lm_desp, s)); HIPCHK(ctx, upload(grp.lt_xy, lt_xy, s));
+    std::vector<int32_t> lm_tile_off;
+    const std::vector<float> lm_frag = fragment_tiles(lm_des, lm_off, lm_tile_off);
+    HIPCHK(ctx, upload(grp.lm_frag, lm_frag, s)); HIPCHK(ctx, upload(grp.lm_tile_off, lm_tile_off, s)); HIPCHK(ctx, upload(grp.lt_xy, lt_xy, s));
     HIPCHK(ctx, upload(grp.lt_ori, lt_ori, s)); HIPCHK(ctx, upload(grp.lt_des, lt_des, s)); HIPCHK(ctx, upload(grp.tile_off, tile_off, s));
     HIPCHK(ctx, upload(grp.tex_slot, tex_slot, s)); HIPCHK(ctx, upload(grp.status, status, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     QueryDev& d = grp.dev;
     d.nq = nq;
-    d.lm_off = grp.lm_off.as<int32_t>(); d.lm_xy = grp.lm_xy.as<short2>(); d.lm_ori = grp.lm_ori.as<float>(); d.lm_des = grp.lm_des.as<float>(); d.lm_desp = grp.lm_desp.as<float>();
+    d.lm_off = grp.lm_off.as<int32_t>(); d.lm_xy = grp.lm_xy.as<short2>(); d.lm_ori = grp.lm_ori.as<float>(); d.lm_des = grp.lm_des.as<float>(); d.lm_frag = grp.lm_frag.as<float4>(); d.lm_tile_off = grp.lm_tile_off.as<int32_t>();
     d.lt_off = grp.lt_off.as<int32_t>(); d.lt_xy = grp.lt_xy.as<short2>(); d.lt_ori = grp.lt_ori.as<float>(); d.lt_des = grp.lt_des.as<float>();
     d.tile_off = grp.tile_off.as<int32_t>(); d.tex_slot = grp.tex_slot.as<int32_t>(); d.status = grp.status.as<int32_t>();
     d.n_tiles = tile_off.back();
@@ -609,6 +628,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
             HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
+            HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
             hipStream_t s = ctx->stream;
             HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
@@ -619,7 +639,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
-            HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
+            HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
@@ -686,6 +706,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
         HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
         HIPCHK(ctx, ctx->cands.ensure((size_t)n * 3 * kTopMinu * sizeof(MinuCand)));
         HIPCHK(ctx, ctx->cand_n.ensure((size_t)n * 3 * 4));
+        HIPCHK(ctx, ctx->minu_fb.ensure(4 * 4));
         HIPCHK(ctx, ctx->parts.ensure((size_t)n * 16));
         HIPCHK(ctx, d_xy.ensure((size_t)n * 3 * kTopMinu * sizeof(short4)));
         HIPCHK(ctx, d_n.ensure((size_t)n * 3 * 4));
@@ -694,10 +715,10 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
         for (int i = 0; i < n && err == AFIS_OK; ++i) {
             const int64_t gi = gallery_idx[i] - ctx->index_base;
             GalleryDev one = g;                                            // a one-template view: offsets are absolute, so only the CSR bases move
-            one.G = 1; one.minu_off += gi; one.tex_off += gi; one.tex_cf_blk += gi; one.empty += gi;
+            one.G = 1; one.minu_off += gi; one.minu_tile_off += gi; one.tex_off += gi; one.tex_cf_blk += gi; one.empty += gi;
             MinuCand* cands = ctx->cands.as<MinuCand>() + (size_t)i * 3 * kTopMinu;
             int32_t* cand_n = ctx->cand_n.as<int32_t>() + (size_t)i * 3;
-            if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, grp.max_nL, ctx->max_nR, ctx->minu_generic, cands, cand_n, s) != hipSuccess ||
+            if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, cands, cand_n, ctx->minu_fb.as<int32_t>(), s) != hipSuccess ||
                 launch_graph_minutiae(grp.dev, one, cands, cand_n, ctx->parts.as<float>() + (size_t)i * 4,
                                       d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, nullptr, nullptr, 2, s) != hipSuccess)
                 err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: kernel launch failed");
@@ -915,7 +936,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
         if (st[0] != AFIS_QUERY_OK) return AFIS_OK;
         const QueryDev& d = grp.dev;
         GalleryDev one = ctx->gal;
-        one.G = 1; one.minu_off += gidx; one.tex_off += gidx; one.tex_cf_blk += gidx; one.empty += gidx;
+        one.G = 1; one.minu_off += gidx; one.minu_tile_off += gidx; one.tex_off += gidx; one.tex_cf_blk += gidx; one.empty += gidx;
         hipStream_t s = ctx->stream;
         HIPCHK(ctx, d_out.ensure(3 * (size_t)kTopTex * sizeof(MinuCand)));
         HIPCHK(ctx, d_n.ensure(3 * 4));
@@ -934,8 +955,8 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             slot = which - 1; cap = kTopMinu;
             const size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * 64));
-            HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12));
-            HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, grp.max_nL, ctx->max_nR, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), s));
+            HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12)); HIPCHK(ctx, ctx->minu_fb.ensure(4 * 4));
+            HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_minutiae(d, one, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr,
                                               d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
         }

@@ -24,7 +24,10 @@ struct GalleryDev {
     const short2*  minu_xy = nullptr;    // [NM]   pixel coords
     const float*   minu_ori = nullptr;   // [NM]
     const float*   minu_des = nullptr;   // [NM][96]
-    const float*   minu_desp = nullptr;  // [NM][96] same values, k-permuted [g][s] = des[4s+g] (MFMA fragment order, minu.hip)
+    const float4*  minu_frag = nullptr;  // the same descriptors as MFMA operand fragments: per template ceil(n/16) tiles of 16 descriptors,
+                                         // tile = [v < 6][lane < 64] float4 with lane l, component c = des[16*tile + (l&15)][4*(4v + c) + (l>>4)]
+                                         // (zero rows pad the last tile): a wave fetches a fragment with six fully coalesced 1 KB loads
+    const int32_t* minu_tile_off = nullptr;  // [G+1] first tile of each template in minu_frag
     const int32_t* tex_off = nullptr;    // [G+1]  (counts already clamped to 1000)
     const short2*  tex_xy = nullptr;     // [NT]   block coords
     const float*   tex_ori = nullptr;    // [NT]
@@ -42,7 +45,8 @@ struct QueryDev {
     const short2*  lm_xy = nullptr;
     const float*   lm_ori = nullptr;
     const float*   lm_des = nullptr;     // [NLM][96]
-    const float*   lm_desp = nullptr;    // [NLM][96] k-permuted copy
+    const float4*  lm_frag = nullptr;    // latent descriptors as MFMA operand fragments (layout as GalleryDev::minu_frag)
+    const int32_t* lm_tile_off = nullptr;   // [nq*3+1]
     const int32_t* lt_off = nullptr;     // [nq+1] texture rows (clamped to 1000)
     const short2*  lt_xy = nullptr;
     const float*   lt_ori = nullptr;
@@ -83,10 +87,11 @@ struct MinuCand { float sim; short li, ri; };
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
                                 const float* rm_val, const int32_t* rm_arg, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
-// (task = (q*3+s)*G + g)
-// Pairs with <= 64 latent and <= 128 rolled minutiae go through an LDS/scalar-cache fast kernel, the rest through the tiled generic one.
+// (task = (q*3+s)*G + g).  Pairs with <= 64 latent and <= 128 rolled minutiae go through the rolled-template-stationary MFMA kernel;
+// what it cannot take (other shapes, degenerate key distributions) it appends to `fallback` ([1 + n_tasks] ints: count, task ids), which the
+// generic kernel then works off.  force_generic: the generic kernel does every task.
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                             int max_nL, int max_nR, int force_generic, MinuCand* cands, int32_t* cand_n, hipStream_t stream);
+                             int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback, hipStream_t stream);
 // S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
                                  float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);

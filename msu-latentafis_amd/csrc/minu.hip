@@ -5,7 +5,8 @@
 //   S10 fusion                 final = score[0] + score[1] + score[2] + score[28]*0.3   (matcher.cpp:376-417, :188)
 // The correspondence lists go to HBM (120 x 8 B per task) and are consumed by k_graph_minutiae (graph.hip).
 //
-// One 256-thread workgroup per (query, selected latent template, gallery template) task, persistent over a strided task list.
+// k_minu_cands_rt (fast path, MFMA): one 256-thread workgroup per rolled template, looping over the launch's latent lists.
+// k_minu_cands (any shape; the fast path's fallback): one workgroup per (query, selected latent template, gallery template) task.
 // Canonical arithmetic (see oracle/afis_oracle.cpp): descriptor dot products are k-ascending fmaf chains, row/column sums are
 // index-ascending, the normalisation is evaluated in double exactly as the reference's expression promotes it.
 #include "afis_device.h"
@@ -17,10 +18,17 @@ constexpr int kWaves = kThreads / 64;
 typedef unsigned long long u64;
 
 #ifdef AFIS_PHASE_TIMING
+// Development aid (make PHASE_TIMING=1): per-phase cycle shares as seen by thread 0 of every workgroup.  The stopwatch values are
+// accumulated in LDS and flushed with ONE global atomic per slot at the end of the kernel — a global atomic inside the loop
+// would stall the loads that follow it and distort the very phases it measures.
 __device__ u64 g_phase_cycles[32];
+#define PHASE_DECL() __shared__ u64 ph_acc[32]; if (threadIdx.x < 32) ph_acc[threadIdx.x] = 0; __syncthreads()
+#define PHASE_FLUSH() do { __syncthreads(); if (threadIdx.x < 32 && ph_acc[threadIdx.x]) atomicAdd(&g_phase_cycles[threadIdx.x], ph_acc[threadIdx.x]); } while (0)
 #define PHASE_INIT() u64 ph_t0 = __builtin_readcyclecounter()
-#define PHASE(i) do { if (threadIdx.x == 0) { const u64 ph_t1 = __builtin_readcyclecounter(); atomicAdd(&g_phase_cycles[i], ph_t1 - ph_t0); ph_t0 = ph_t1; } } while (0)
+#define PHASE(i) do { if (threadIdx.x == 0) { const u64 ph_t1 = __builtin_readcyclecounter(); ph_acc[i] += ph_t1 - ph_t0; ph_t0 = ph_t1; } } while (0)
 #else
+#define PHASE_DECL() do {} while (0)
+#define PHASE_FLUSH() do {} while (0)
 #define PHASE_INIT() do {} while (0)
 #define PHASE(i) do {} while (0)
 #endif
@@ -66,22 +74,25 @@ struct MinuSmem {
 
 // Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
 __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
-                                                         MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int skip_fast)
+                                                         MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n,
+                                                         const int32_t* __restrict__ fb /* NULL: every task; else fb[0] tasks listed in fb[1 ...] */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
     float* gscr = scratch + (size_t)blockIdx.x * scratch_per_wg;
     int parity = 0;
+    PHASE_DECL();
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     const int tid = threadIdx.x;
-    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const long long n_work = fb ? (long long)fb[0] : n_tasks;
+    for (long long work = blockIdx.x; work < n_work; work += gridDim.x) {
+        const long long task = fb ? (long long)fb[1 + work] : work;
         // task order: gallery template fastest, then selected template, then query
         const int gi = (int)(task % g.G);
         const int qs = (int)(task / g.G);                    // qi*3 + s
         const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
         const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
         if (nL <= 0 || nR <= 0) { if (tid == 0) cand_n[task] = 0; continue; }     // matcher.cpp:400-404
-        if (skip_fast && nL <= kFastL && nR <= kFastR) continue;                   // done by k_minu_cands_fast
         const int n = nL * nR;
         PHASE_INIT();
         const bool fast = nL <= kFastL && nR <= kFastR;
@@ -237,418 +248,319 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
         __syncthreads();
         PHASE(4);
     }
+    PHASE_FLUSH();
 }
 
+
 // ---------------------------------------------------------------------------------------------------------------------
-// Fast path: pairs with nL <= 64 latent and nR <= 128 rolled minutiae (every template the extraction normally produces).
-//   S1  the one dense contraction of the path (the reference's Eigen GEMM) runs on the matrix cores with the exact-fp32
-//       v_mfma_f32_16x16x4_f32: wave w owns the 16-column tiles w, w+4, ...; fragments come straight from HBM/L2 (k-permuted
-//       descriptor copies), results go to the LDS-resident similarity matrix.  No LDS staging, no barriers.
-//   S2  sums and S3 keys from the LDS-resident similarity matrix.
-//   S3  top-120 in two stages with ONE barrier: every wave finds the 120 largest of its own quarter of the keys (bit-by-bit
-//       threshold search on ballot/popcount counts, keys in registers), wave 0 then takes the 120 largest of those <= 480 and
-//       ranks them.  Keys are 45-bit composites (norm key << 13 | 8191 - element index): unique, so "larger = earlier" is
-//       exactly "norm descending, index ascending" and no tie handling is needed.
+// Fast path, rolled-template-stationary: pairs with nL <= 64 latent and nR <= 128 rolled minutiae (every template the
+// extraction normally produces).  One workgroup owns ONE rolled minutiae template at a time and runs every (latent, selected
+// template) list of the launch against it:
+//   * S1, the one dense contraction of the path (the reference's Eigen GEMM), runs on the matrix cores with the exact-fp32
+//     v_mfma_f32_16x16x4_f32.  Wave w keeps the B fragment (16 rolled descriptors, k-permuted) of column tile w in 24
+//     registers for all <= 24 tasks of the rolled template; only the latent A fragments are fetched per task (24 x 15 KB
+//     shared by every workgroup: L2/L1 resident).  Rolled descriptors therefore cross HBM -> CU once per launch instead of
+//     once per task.  Column tiles 4.. (rolled templates with > 64 minutiae) are dealt round-robin over the waves with the B
+//     fragment fetched per item (an L1/L2 hit: the same workgroup reads it for every task).
+//   * the similarity matrix sits in LDS with an ODD row stride, so the sequential row sums (one lane per row) and the column
+//     sums (one lane per column) are both bank-conflict free.
+//   * S3: a 256-bin LDS histogram (16 bins per octave from 2^-15 up; one bin per thread for the scan) of fp32 APPROXIMATIONS of
+//     the norm keys — v_rcp_f32 instead of the reference's double division, at most 6 ulp away (see below) — finds the bin B
+//     holding the 120th largest key.  Keys of zero similarities (half of all entries, all in one bin: they serialised the LDS
+//     atomics) are not counted.  Only the ~130-150 entries that can still be among the 120 largest get the exact double-precision
+//     key; they are ranked among themselves by counting on 45-bit composites (norm key, lowest element index first), which
+//     yields exactly the reference's top 120 in the reference's order.  The kernel is bound by VALU issue, so the passes are laid
+//     out for few instructions per element (thread = column x row phase; keys stay in registers between the passes).
+//   * anything else — shapes beyond 64 x 128, fewer than 512 entries, a threshold in the two lowest bins (fewer than 120
+//     similarities with a norm of at least 2^-15), more than 256 candidates — is appended to a fallback list that k_minu_cands (exact threshold
+//     search on exact keys, any shape) works off afterwards.
+// Approximation bound.  a = sv * rcp(f + 1e-6f) with f the reference's own float (rowsum + colsum) - sv: the float sum
+// f + 1e-6f (<= 2^-23 relative incl. the constant's rounding), v_rcp_f32 (1 ulp) and the product (2^-24) put a within
+// 2.5 * 2^-23 relative of the exact quotient, whose own rounding to float adds 2^-24: at most 6 ulp between approximate and
+// exact float key, |ka - ke| <= E = 8 as ordered integers.  With Ta = the 120th largest approximate key (in bin B): at least
+// 120 exact keys are >= Ta - E, so every entry of the exact top 120 has ke >= Ta - E, hence ka >= Ta - 2E >= edge(B) - 2E.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kFastU = kFastN / kThreads;            // 32 keys per lane at most
-constexpr int kStage1Cap = 160;                      // stage-1 survivors per wave: a superset of the wave's 120 largest keys
-constexpr int kHistBins = 2048;                      // histogram path: key bits 29..19 (7 exponent + 4 mantissa bits; norm < 1)
-constexpr int kBndCap = 128;                         // keys that may share the threshold bin before the two-stage path takes over
-constexpr int kHistMinN = 512;                       // below this the two-stage path is as cheap
-struct FastSmem {
-    float simi[kFastN];                               // 32 KB
+constexpr int kSelBins = 256;                        // histogram bins: 16 per octave (4 mantissa bits) from 2^-15 up, one per thread
+constexpr int kBinBase = (127 - 15) * 16 - 1;        // key bits 30..19 of 2^-15, minus one: bin 0 = everything below (never counted)
+constexpr int kHistMinN = 512;                       // smaller pairs go to the fallback kernel
+constexpr int kCandCap = 256;                        // entries that may still be in the top 120 (exact keys computed for these)
+constexpr uint32_t kKeySlack = 16;                   // 2E
+struct RtSmem {
+    float simi[kFastN];                              // 32 KB, row stride ld (odd unless nR == 128)
     float rowsum[kFastL];
     float colsum[kFastR];
-    union {
-        u64 list[kWaves * kStage1Cap];                // two-stage path: stage-1 survivors
-        struct { uint32_t hist[kHistBins / 2]; u64 bnd[kBndCap]; } h;   // histogram path: 2048 16-bit bins; keys of the threshold bin
-    } sel;
-    u64 top[128];                                     // the selected keys (unordered on the histogram path)
-    int counts[kWaves];
+    uint32_t hist[kSelBins];                         // bin b >= 1: approximate keys with bits 30..19 == kBinBase + b (top bin: and above)
+    u64 cand[kCandCap];                              // exact composite keys of the candidates
+    uint32_t cand_e[kCandCap];                       // their (row << 8 | column)
     int wave_tot[kWaves];
-    int thr_bin, c_above, n_top, n_bnd;
+    int thr_bin, n_cand;
 };
 
-// K-th largest of the wave's composite keys c[0..U) (0 = padding), K >= 1 and K <= number of non-zero keys
-template <int U>
-__device__ __forceinline__ u64 wave_kth_largest(const u64 (&c)[U], int K)
-{
-    u64 T = 0;
-    for (int bit = 44; bit >= 0; --bit) {
-        const u64 cand = T | (1ull << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) cnt += wave_popc(c[u] >= cand);
-        if (cnt >= K) T = cand;
-    }
-    return T;
-}
 __device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
-// Stage 1 of the top-120 selection for one wave: keys of the elements e = (u*4 + wave)*64 + lane, u < U, are computed into
-// registers; the wave's Kw largest (ties: lowest element index) are written to list[] as 45-bit composites.  Returns Kw.
-template <int U>
-__device__ __forceinline__ int wave_stage1(const FastSmem& sm, u64* list, int n, int nR, int wave, int lane)
+__device__ __forceinline__ uint32_t exact_norm_key(float sv, float rs, float cs)
 {
-    uint32_t rk[U];                                                      // 32-bit norm keys; the element index is implied by (u, lane)
-    int n_own = 0;
-    {
-        // (i, j) of the lane's first element and the step between consecutive elements (256), without per-element divisions
-        int e = wave * 64 + lane;
-        int i = e / nR, j = e - i * nR;
-        const int si = kThreads / nR, sj = kThreads - si * nR;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t key = 0;                                            // real keys have the top bit set
-            if (e < n) {
-                const float sv = sm.simi[e];
-                float f = sm.rowsum[i] + sm.colsum[j];
-                f = f - sv;
-                key = ord_f32((float)((double)sv / ((double)f + 0.000001)));                    // matcher.cpp:467
-            }
-            rk[u] = key;
-            n_own += wave_popc(e < n);
-            e += kThreads; i += si; j += sj; if (j >= nR) { j -= nR; ++i; }
-        }
-    }
-    const int Kw = n_own < kTopMinu ? n_own : kTopMinu;
-    int n_out = 0;
-    if (Kw > 0) {
-        // norm lies in [0, 1): every key is in [0x80000000, 0xBF800000), so bit 31 is set and bit 30 clear.
-        // Stage 2 only needs a SUPERSET of the wave's Kw largest keys, so the bit-by-bit threshold search stops as soon as the
-        // keys >= T fit the wave's list (kStage1Cap): typically after 10-14 of the 30 bits.
-        uint32_t T = 0x80000000u;
-        int c_ge = n_own;                                                // keys >= T (padding keys are 0 < T)
-        for (int bit = 29; bit >= 0 && c_ge > kStage1Cap; --bit) {
-            const uint32_t cand = T | (1u << bit);
-            int cnt = 0;
-#pragma unroll
-            for (int u = 0; u < U; ++u) cnt += wave_popc(rk[u] >= cand);
-            if (cnt >= Kw) { T = cand; c_ge = cnt; }
-        }
-        int need = kStage1Cap;                                           // of the keys equal to T (all of them if everything fits)
-        int n_gt = 0;
-        if (c_ge > kStage1Cap) {                                         // T is exact and too many keys equal it: keep the lowest indices
-#pragma unroll
-            for (int u = 0; u < U; ++u) n_gt += wave_popc(rk[u] > T);
-            need = Kw - n_gt;
-            n_out = Kw;
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) n_gt += wave_popc(rk[u] > T);
-            n_out = c_ge;
-        }
-        int base_gt = 0, base_eq = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {                                    // (u, lane) ascending = element index ascending
-            const int e = (u * kWaves + wave) * 64 + lane;
-            const bool gt = rk[u] > T, eq = rk[u] == T;
-            const u64 mg = __ballot(gt), me = __ballot(eq);
-            int pos = -1;
-            if (gt) pos = base_gt + lane_prefix(mg);
-            else if (eq) { const int r = base_eq + lane_prefix(me); if (r < need) pos = n_gt + r; }
-            if (pos >= 0) list[pos] = ((u64)rk[u] << 13) | (u64)(8191 - e);
-            base_gt += __popcll(mg); base_eq += __popcll(me);
-        }
-    }
-    return n_out;
+    float f = rs + cs;
+    f = f - sv;
+    return ord_f32((float)((double)sv / ((double)f + 0.000001)));                               // matcher.cpp:467
+}
+__device__ __forceinline__ uint32_t approx_norm_key(float sv, float rs, float cs)
+{
+    float f = rs + cs;
+    f = f - sv;
+    const float a = sv * __builtin_amdgcn_rcpf(f + 0.000001f);
+    return __float_as_uint(a) | 0x80000000u;                                                    // a >= 0: ord_f32's key
 }
 
-// Top-120 selection by histogram (all four waves, no serial stage): a 2048-bin histogram of the norm keys' bits 29..19 in LDS,
-// a suffix scan that finds the bin in which the 120th largest key lies, then every key in a higher bin is selected outright and
-// the (few) keys of the threshold bin are ranked among themselves as 45-bit composites (norm key, then lowest element index), so
-// the result is exactly the 120 largest in the reference's order.  Returns false — uniformly for the workgroup — when the
-// threshold bin is the zero bin or holds more than kBndCap keys; the caller then runs the two-stage path.
-template <int U>
-__device__ __forceinline__ bool select_hist(FastSmem& sm, int n, int nR, int wave, int lane, int tid)
+// fb[0] = number of fallback tasks, fb[1 ...] = their task indices
+__global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, GalleryDev g, const float4* __restrict__ lat_frag,
+                                                                const float4* __restrict__ rol_frag,  // descriptors as operand fragments
+                                                                MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb)
 {
-    uint32_t rk[U];
-    {
-        int e = wave * 64 + lane;
-        int i = e / nR, j = e - i * nR;
-        const int si = kThreads / nR, sj = kThreads - si * nR;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t key = 0;
-            if (e < n) {
-                const float sv = sm.simi[e];
-                float f = sm.rowsum[i] + sm.colsum[j];
-                f = f - sv;
-                key = ord_f32((float)((double)sv / ((double)f + 0.000001)));                    // matcher.cpp:467
-            }
-            rk[u] = key;
-            e += kThreads; i += si; j += sj; if (j >= nR) { j -= nR; ++i; }
-        }
-    }
-    for (int w = tid; w < kHistBins / 2; w += kThreads) sm.sel.h.hist[w] = 0u;
-    if (tid == 0) { sm.n_top = 0; sm.n_bnd = 0; sm.thr_bin = -1; sm.c_above = 0; }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int e = (u * kWaves + wave) * 64 + lane;
-        if (e < n) { const uint32_t bin = (rk[u] >> 19) & (kHistBins - 1); atomicAdd(&sm.sel.h.hist[bin >> 1], 1u << ((bin & 1) * 16)); }
-    }
-    __syncthreads();
-    // thread tid owns bins 8*tid .. 8*tid+7; higher thread = larger keys
-    int cnt[8], own = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const uint32_t x = sm.sel.h.hist[4 * tid + w];
-        cnt[2 * w] = (int)(x & 0xffffu); cnt[2 * w + 1] = (int)(x >> 16);
-        own += cnt[2 * w] + cnt[2 * w + 1];
-    }
-    int suf = own;                                                       // keys in the bins of lanes >= this one (within the wave)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_down(suf, off); if (lane + off < 64) suf += t; }
-    if (lane == 0) sm.wave_tot[wave] = suf;
-    __syncthreads();
-    int above = suf - own;                                               // keys in all higher bins
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) if (w > wave) above += sm.wave_tot[w];
-#pragma unroll
-    for (int b = 7; b >= 0; --b) {
-        if (above < kTopMinu && above + cnt[b] >= kTopMinu) { sm.thr_bin = 8 * tid + b; sm.c_above = above; }
-        above += cnt[b];
-    }
-    __syncthreads();
-    const int B = sm.thr_bin, c_above = sm.c_above;
-    if (B <= 0) return false;                                            // the 120th key is a zero norm: index order decides, two-stage path
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int e = (u * kWaves + wave) * 64 + lane;
-        if (e < n) {
-            const int bin = (int)((rk[u] >> 19) & (kHistBins - 1));
-            const u64 comp = ((u64)rk[u] << 13) | (u64)(8191 - e);
-            if (bin > B) sm.top[atomicAdd(&sm.n_top, 1)] = comp;
-            else if (bin == B) { const int p = atomicAdd(&sm.n_bnd, 1); if (p < kBndCap) sm.sel.h.bnd[p] = comp; }
-        }
-    }
-    __syncthreads();
-    const int n_bnd = sm.n_bnd;
-    if (n_bnd > kBndCap) return false;
-    const int need = kTopMinu - c_above;                                 // 1 <= need <= n_bnd
-    if (tid < n_bnd) {
-        const u64 mine = sm.sel.h.bnd[tid];
-        int r = 0;
-        for (int k = 0; k < n_bnd; ++k) r += sm.sel.h.bnd[k] > mine;
-        if (r < need) sm.top[c_above + r] = mine;
-    }
-    __syncthreads();
-    return true;
-}
-
-__global__ __launch_bounds__(kThreads, 4) void k_minu_cands_fast(QueryDev q, GalleryDev g, const float* __restrict__ lat_desp,
-                                                              const float* __restrict__ rol_desp,   // k-permuted descriptor copies
-                                                              MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n)
-{
-    __shared__ FastSmem sm;
-    const long long n_tasks = (long long)q.nq * 3 * g.G;
+    __shared__ RtSmem sm;
+    PHASE_DECL();
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-        const int gi = (int)(task % g.G);
-        const int qs = (int)(task / g.G);
-        const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
+    const int li = lane & 15, lg = lane >> 4;
+    const int nqs = q.nq * 3;
+    auto to_fallback = [&](long long task) { const int p = atomicAdd(&fb[0], 1); fb[1 + p] = (int32_t)task; };
+    for (int gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
         const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
-        if (nL <= 0 || nR <= 0) { if (tid == 0) cand_n[task] = 0; continue; }     // matcher.cpp:400-404
-        if (nL > kFastL || nR > kFastR) continue;                                  // left to k_minu_cands
-        const int n = nL * nR;
-        PHASE_INIT();
-        // ---- S1 (matcher.cpp:440-452): simi = max(0, A * B^T) on the matrix cores ----
-        // v_mfma_f32_16x16x4_f32 is exact fp32: D = fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, C)))), i.e. bit for bit the
-        // k-ascending fmaf chain of the oracle (CDNA4 guide §3 "FP32-input MFMA").  Operand layout: lane l supplies A[i = l&15][k = l>>4]
-        // and B[k = l>>4][j = l&15]; step s covers k = 4s .. 4s+3.  lat_desp / rol_desp hold every descriptor with its 96 values
-        // permuted as [g][s] = des[4s + g], so the 24 values lane group g needs are contiguous (six 16-byte loads).
-        {
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const int li = lane & 15, lg = lane >> 4;
-            const int n_it = (nL + 15) >> 4, n_jt = (nR + 15) >> 4;
-            // work item = (column tile jt, pair of row tiles): the two row tiles are independent accumulator chains (an MFMA needs
-            // 40 cycles before its result can be accumulated into again), and items are dealt round-robin to the four waves
-            const int n_ip = (n_it + 1) >> 1;
-            for (int item = wave; item < n_jt * n_ip; item += kWaves) {
-                const int jt = item / n_ip, it0 = (item - jt * n_ip) * 2;
-                const bool two = it0 + 1 < n_it;
-                const int jr = min(jt * 16 + li, nR - 1);
-                const int ir0 = min(it0 * 16 + li, nL - 1), ir1 = min(it0 * 16 + 16 + li, nL - 1);
-                const float4* bp = reinterpret_cast<const float4*>(rol_desp + (size_t)(r0 + jr) * kDes + lg * 24);
-                const float4* ap0 = reinterpret_cast<const float4*>(lat_desp + (size_t)(l0 + ir0) * kDes + lg * 24);
-                const float4* ap1 = reinterpret_cast<const float4*>(lat_desp + (size_t)(l0 + ir1) * kDes + lg * 24);
-                float bf[24], af0[24], af1[24];
+        if (nR <= 0 || nR > kFastR) {                                               // no rolled minutiae (matcher.cpp:400-404) / too many for this kernel
+            for (int qs = tid; qs < nqs; qs += kThreads) {
+                const long long task = (long long)qs * g.G + gi;
+                const int nL = q.lm_off[qs + 1] - q.lm_off[qs];
+                if (nR <= 0 || nL <= 0) cand_n[task] = 0; else to_fallback(task);
+            }
+            continue;
+        }
+        const int n_jt = (nR + 15) >> 4;
+        const int ld = ((nR & 1) || nR == kFastR) ? nR : nR + 1;
+        const int R = kThreads / nR;                                                // selection: row phases per column (>= 2)
+        const int cr = tid / nR, cj = tid - cr * nR;                                // this thread's row phase and column (idle if cr >= R)
+        // ---- the wave's resident B fragment: rolled descriptors 16*wave .. 16*wave+15 (lane l: descriptor l&15, k-group l>>4) ----
+        const float4* btiles = rol_frag + (size_t)g.minu_tile_off[gi] * (6 * 64) + lane;
+        float bres[24];
+        if (wave < n_jt) {
 #pragma unroll
-                for (int v = 0; v < 6; ++v) {
-                    const float4 x = bp[v], y = ap0[v], z = ap1[v];
-                    bf[4 * v] = x.x; bf[4 * v + 1] = x.y; bf[4 * v + 2] = x.z; bf[4 * v + 3] = x.w;
-                    af0[4 * v] = y.x; af0[4 * v + 1] = y.y; af0[4 * v + 2] = y.z; af0[4 * v + 3] = y.w;
-                    af1[4 * v] = z.x; af1[4 * v + 1] = z.y; af1[4 * v + 2] = z.z; af1[4 * v + 3] = z.w;
-                }
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < 6; ++v) { const float4 x = btiles[(wave * 6 + v) * 64]; bres[4 * v] = x.x; bres[4 * v + 1] = x.y; bres[4 * v + 2] = x.z; bres[4 * v + 3] = x.w; }
+        } else {
 #pragma unroll
-                for (int st = 0; st < 24; ++st) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[st], bf[st], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[st], bf[st], acc1, 0, 0, 0);
-                }
+            for (int v = 0; v < 24; ++v) bres[v] = 0.0f;
+        }
+        for (int qs = 0; qs < nqs; ++qs) {
+            const long long task = (long long)qs * g.G + gi;
+            const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
+            if (nL <= 0) { if (tid == 0) cand_n[task] = 0; continue; }               // matcher.cpp:400-404
+            const int n = nL * nR;
+            if (nL > kFastL || n < kHistMinN) { if (tid == 0) to_fallback(task); continue; }
+            PHASE_INIT();
+            // ---- S1 (matcher.cpp:440-452): simi = max(0, A * B^T); v_mfma_f32_16x16x4_f32 == the k-ascending fmaf chain ----
+            // Operand layout: lane l supplies A[i = l&15][k = 4s + (l>>4)] and B[k][j = l&15] at step s = 4v + c; the fragment arrays
+            // hold exactly that per (tile, v, lane), so a fragment is six fully coalesced 1 KB loads.
+            const int n_it = (nL + 15) >> 4;
+            const float4* atiles = lat_frag + (size_t)q.lm_tile_off[qs] * (6 * 64) + lane;
+            auto load_frag = [&](const float4* __restrict__ tiles, int t, float (&f)[24]) {
+#pragma unroll
+                for (int v = 0; v < 6; ++v) { const float4 x = tiles[(t * 6 + v) * 64]; f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w; }
+            };
+            auto store_tile = [&](int it, int jt, const f32x4& acc) {              // D: col = lane & 15, row = (lane >> 4) * 4 + r
                 const int j = jt * 16 + li;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                          // D: col = lane & 15, row = (lane >> 4) * 4 + r
-                    const int i0 = it0 * 16 + lg * 4 + r, i1 = i0 + 16;
-                    float v0 = acc0[r], v1 = acc1[r];
-                    if (v0 < 0) v0 = 0;
-                    if (v1 < 0) v1 = 0;
-                    if (i0 < nL && j < nR) sm.simi[i0 * nR + j] = v0;
-                    if (two && i1 < nL && j < nR) sm.simi[i1 * nR + j] = v1;
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + lg * 4 + r;
+                    float v = acc[r];
+                    if (v < 0) v = 0;
+                    if (i < nL && j < nR) sm.simi[i * ld + j] = v;
+                }
+            };
+            // The six loads of a fragment are issued together (sched_barrier pins that: left alone, the scheduler sinks every load next
+            // to its first use — one exposed memory latency per 4 MFMAs instead of one per tile).
+            auto mfma_tile = [&](const float (&af)[24], const float (&bf)[24]) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int st = 0; st < 24; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], bf[st], acc, 0, 0, 0);
+                return acc;
+            };
+            if (wave < n_jt) {                                                      // column tile `wave`, every row tile: B stays in registers
+                // row tiles in pairs: two independent accumulator chains keep the matrix pipe issuing every 32 cycles (one chain alone
+                // waits 40+ cycles for each result)
+                for (int it = 0; it < n_it; it += 2) {
+                    float a0[24], a1[24];
+                    load_frag(atiles, it, a0);
+                    if (it + 1 < n_it) {
+                        load_frag(atiles, it + 1, a1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int st = 0; st < 24; ++st) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[st], bres[st], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[st], bres[st], acc1, 0, 0, 0);
+                        }
+                        store_tile(it, wave, acc0);
+                        store_tile(it + 1, wave, acc1);
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_tile(it, wave, mfma_tile(a0, bres));
+                    }
                 }
             }
-        }
-        __syncthreads();
-        PHASE(16);
-        // ---- S2 (:455-456): index-ascending sums ----
-        if (tid < nR) {
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int i = 0; i < nL; ++i) sacc += sm.simi[i * nR + tid];
-            sm.colsum[tid] = sacc;
-        } else if (tid >= 128 && tid - 128 < nL) {
-            const int i = tid - 128;
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < nR; ++j) sacc += sm.simi[i * nR + j];
-            sm.rowsum[i] = sacc;
-        }
-        __syncthreads();
-        PHASE(17);
-        // ---- S3 (:461-488): the 120 largest norm values, ties by lowest element index; element e = (u*4 + wave)*64 + lane ----
-        const int topN = n < kTopMinu ? n : kTopMinu;
-        bool selected = false;
-        if (n >= kHistMinN) {                                                 // histogram path (all waves); falls through when it declines
-            if (n <= 8 * kThreads) selected = select_hist<8>(sm, n, nR, wave, lane, tid);
-            else if (n <= 16 * kThreads) selected = select_hist<16>(sm, n, nR, wave, lane, tid);
-            else selected = select_hist<kFastU>(sm, n, nR, wave, lane, tid);
-        }
-        if (selected) {
+            for (int item = wave; item < (n_jt - kWaves) * n_it; item += kWaves) {   // column tiles 4..: dealt round-robin
+                const int jt = kWaves + item / n_it, it = item - (jt - kWaves) * n_it;
+                float af[24], bf[24];
+                load_frag(btiles, jt, bf);
+                load_frag(atiles, it, af);
+                __builtin_amdgcn_sched_barrier(0);
+                store_tile(it, jt, mfma_tile(af, bf));
+            }
+            sm.hist[tid] = 0u;
+            if (tid == 0) { sm.n_cand = 0; sm.thr_bin = -1; }
+            __syncthreads();
+            PHASE(16);
+            // ---- S2 (:455-456): index-ascending sums; odd row stride: both walks are conflict free.  Eight reads are issued before
+            // the eight dependent adds (one LDS round trip per eight elements instead of one per element).
+            if (tid < nR) {
+                const float* p = &sm.simi[tid];
+                float sacc = 0.f;
+                int k = 0;
+                for (; k + 8 <= nL; k += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * ld];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc += v[u];
+                }
+                for (; k < nL; ++k) sacc += p[k * ld];
+                sm.colsum[tid] = sacc;
+            } else if (tid >= 128 && tid - 128 < nL) {
+                const float* p = &sm.simi[(tid - 128) * ld];
+                float sacc = 0.f;
+                int k = 0;
+                for (; k + 8 <= nR; k += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = p[k + u];                   // immediate offsets: no address arithmetic
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc += v[u];
+                }
+                for (; k < nR; ++k) sacc += p[k];
+                sm.rowsum[tid - 128] = sacc;
+            }
+            __syncthreads();
+            PHASE(17);
+            // ---- S3 (:461-488): the 120 largest norm values.  The kernel is bound by VALU issue (about 2000 wave-instructions per wave
+            // and task before this layout), so the selection is organised for few instructions per element: thread = (column cj, row
+            // phase cr) walks the rows cr, cr + R, ... of ITS column — the column sum stays in a register, the address advances by a
+            // constant — and keeps the approximate keys in registers for the second pass.
+            const int n_rows = (nL + R - 1) / R;                                     // <= 32 (nL <= 64, R >= 2)
+            const int my_rows = cr < R ? (nL - cr + R - 1) / R : 0;
+            uint32_t rk[32];
+            {
+                const float cs = sm.colsum[cj];
+                int a = cr * ld + cj, i = cr;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) {
+                    rk[t] = 0u;
+                    if (t < n_rows) {                                                // uniform
+                        if (t < my_rows) {
+                            const uint32_t key = approx_norm_key(sm.simi[a], sm.rowsum[i], cs);
+                            rk[t] = key;
+                            const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
+                            if (bin > 0) atomicAdd(&sm.hist[bin], 1u);               // zero similarities and norms < 2^-15 are not counted
+                        }
+                        a += R * ld; i += R;
+                    }
+                }
+            }
+            __syncthreads();
+            {   // thread tid owns bin tid: suffix sums over the higher bins find the bin holding the 120th largest approximate key
+                const int own = (int)sm.hist[tid];
+                int suf = own;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
+                if (lane == 0) sm.wave_tot[wave] = suf;
+                __syncthreads();
+                int above = suf - own;
+#pragma unroll
+                for (int w = 0; w < kWaves; ++w) if (w > wave) above += sm.wave_tot[w];
+                if (above < kTopMinu && above + own >= kTopMinu) sm.thr_bin = tid;
+            }
+            __syncthreads();
+            const int B = sm.thr_bin;
+            if (B < 2) { if (tid == 0) to_fallback(task); __syncthreads(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
+            // ---- the candidates: approximate key >= edge(B) - 2E ----
+            {
+                const uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
+                uint32_t hits = 0;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) hits |= (rk[t] + kKeySlack >= edge ? 1u : 0u) << t;   // unused slots hold 0
+                if (hits) {
+                    int p = atomicAdd(&sm.n_cand, __popc(hits));
+                    while (hits) {
+                        const int t = __ffs(hits) - 1;
+                        hits &= hits - 1;
+                        if (p < kCandCap) sm.cand_e[p] = (uint32_t)(((cr + R * t) << 8) | cj);
+                        ++p;
+                    }
+                }
+            }
+            __syncthreads();
+            const int n_c = sm.n_cand;                                               // >= 120
+            if (n_c > kCandCap) { if (tid == 0) to_fallback(task); __syncthreads(); continue; }
+            int ci = 0, cj2 = 0;
+            if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
+                const uint32_t pe = sm.cand_e[tid];
+                ci = (int)(pe >> 8); cj2 = (int)(pe & 255u);
+                sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 13) | (u64)(8191 - (ci * nR + cj2));
+            }
+            __syncthreads();
             PHASE(18);
-            // rank by counting, two threads per key: each counts the larger keys in one half of the list
-            const int ki = tid >> 1, half = tid & 1;
-            const u64 mine = ki < kTopMinu ? sm.top[ki] : 0ull;
-            int r = 0;
-            const int k0 = half * (kTopMinu / 2);
+            // ---- rank the candidates by counting (composites are unique); ranks < 120 are the list, in the reference's order ----
+            if (tid < n_c) {
+                const u64 mine = sm.cand[tid];
+                int r = 0;
+                const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(sm.cand);
+                const int n2 = n_c >> 1;
 #pragma unroll 4
-            for (int k = k0; k < k0 + kTopMinu / 2; ++k) r += sm.top[k] > mine;
-            r += __shfl_xor(r, 1);
-            if (half == 0 && ki < kTopMinu) {
-                const int e = 8191 - (int)(mine & 8191);
-                const int i1 = e / nR, i2 = e - i1 * nR;
-                MinuCand cd; cd.sim = sm.simi[e]; cd.li = (short)i1; cd.ri = (short)i2;
-                cands[(size_t)task * kTopMinu + r] = cd;
+                for (int k = 0; k < n2; ++k) { const ulonglong2 kk = c2[k]; r += kk.x > mine; r += kk.y > mine; }
+                if (n_c & 1) r += sm.cand[n_c - 1] > mine;
+                if (r < kTopMinu) {
+                    MinuCand cd; cd.sim = sm.simi[ci * ld + cj2]; cd.li = (short)ci; cd.ri = (short)cj2;
+                    cands[(size_t)task * kTopMinu + r] = cd;
+                }
             }
             if (tid == 0) cand_n[task] = kTopMinu;
             __syncthreads();
             PHASE(20);
-            continue;
         }
-        // two-stage path: number of key slots per lane actually needed: 8 (n <= 2048), 16 (n <= 4096) or 32
-        int Kw;
-        if (n <= 8 * kThreads) Kw = wave_stage1<8>(sm, sm.sel.list + wave * kStage1Cap, n, nR, wave, lane);
-        else if (n <= 16 * kThreads) Kw = wave_stage1<16>(sm, sm.sel.list + wave * kStage1Cap, n, nR, wave, lane);
-        else Kw = wave_stage1<kFastU>(sm, sm.sel.list + wave * kStage1Cap, n, nR, wave, lane);
-        PHASE(18);
-        if (lane == 0) sm.counts[wave] = Kw;
-        __syncthreads();
-        PHASE(19);
-        // ---- stage 2 (wave 0): the topN largest of the <= 640 survivors, then rank them ----
-        if (wave == 0) {
-            constexpr int V = kWaves * kStage1Cap / 64;                       // 10 keys per lane
-            u64 d[V];
-            int off[kWaves + 1]; off[0] = 0;
-#pragma unroll
-            for (int w = 0; w < kWaves; ++w) off[w + 1] = off[w] + sm.counts[w];
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const int p = v * 64 + lane;                                  // position in the concatenation of the four lists
-                u64 key = 0;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) if (p >= off[w] && p < off[w + 1]) key = sm.sel.list[w * kStage1Cap + p - off[w]];
-                d[v] = key;
-            }
-            // topN largest composites = norm key descending, element index ascending.  Threshold search on the 32-bit keys;
-            // among the keys equal to the threshold the lowest element indices win (second, 13-bit search, only when needed).
-            uint32_t hk[V], he[V];
-#pragma unroll
-            for (int v = 0; v < V; ++v) { hk[v] = (uint32_t)(d[v] >> 13); he[v] = 8191u - (uint32_t)(d[v] & 8191); }
-            uint32_t T = 0x80000000u;
-            for (int bit = 29; bit >= 0; --bit) {
-                const uint32_t cand = T | (1u << bit);
-                int cnt = 0;
-#pragma unroll
-                for (int v = 0; v < V; ++v) cnt += wave_popc(hk[v] >= cand);
-                if (cnt >= topN) T = cand;
-            }
-            int n_gt = 0, n_eq = 0;
-#pragma unroll
-            for (int v = 0; v < V; ++v) { n_gt += wave_popc(hk[v] > T); n_eq += wave_popc(hk[v] == T); }
-            const int need = topN - n_gt;
-            uint32_t Emax = 0xffffffffu;
-            if (n_eq != need) {
-                uint32_t X = 0;                                       // largest X with count(eq && e < X) < need
-                for (int bit = 12; bit >= 0; --bit) {
-                    const uint32_t cand = X | (1u << bit);
-                    int cnt = 0;
-#pragma unroll
-                    for (int v = 0; v < V; ++v) cnt += wave_popc(hk[v] == T && he[v] < cand);
-                    if (cnt < need) X = cand;
-                }
-                Emax = X;
-            }
-            int base = 0;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                const bool take = hk[v] > T || (hk[v] == T && he[v] <= Emax);
-                const u64 m = __ballot(take);
-                if (take) sm.top[base + lane_prefix(m)] = d[v];
-                base += __popcll(m);
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            // rank by counting; the list leaves in rank order
-            u64 mine[2]; int r[2] = {0, 0};
-            mine[0] = lane < topN ? sm.top[lane] : 0; mine[1] = lane + 64 < topN ? sm.top[lane + 64] : 0;
-#pragma unroll 4
-            for (int k = 0; k < topN; ++k) { const u64 kk = sm.top[k]; r[0] += kk > mine[0]; r[1] += kk > mine[1]; }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (lane + 64 * h < topN) {
-                    const int e = 8191 - (int)(mine[h] & 8191);
-                    const int i1 = e / nR, i2 = e - i1 * nR;
-                    MinuCand cd; cd.sim = sm.simi[e]; cd.li = (short)i1; cd.ri = (short)i2;
-                    cands[(size_t)task * kTopMinu + r[h]] = cd;
-                }
-            }
-            if (lane == 0) cand_n[task] = topN;
-        }
-        __syncthreads();
-        PHASE(20);
     }
+    PHASE_FLUSH();
 }
 
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                             int max_nL, int max_nR, int force_generic, MinuCand* cands, int32_t* cand_n, hipStream_t stream)
+                             int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MinuSmem));
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (n_tasks > 0x7ffffff0LL) return hipErrorInvalidValue;
+    hipError_t e;
     if (!force_generic) {
-        const int gridf = (int)(n_tasks < 8192 ? n_tasks : 8192);
-        hipLaunchKernelGGL(k_minu_cands_fast, dim3(gridf), dim3(kThreads), 0, stream, q, g, q.lm_desp, g.minu_desp, cands, cand_n);
-        if (max_nL <= kFastL && max_nR <= kFastR) return hipGetLastError();       // every pair took the fast path
+        e = hipMemsetAsync(fallback, 0, sizeof(int32_t), stream);
+        if (e != hipSuccess) return e;
+        const int grid = g.G < 1024 ? g.G : 1024;                                 // 4 workgroups per CU, persistent over rolled templates
+        hipLaunchKernelGGL(k_minu_cands_rt, dim3(grid), dim3(kThreads), 0, stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
     }
+    // opt-in to > 64 KB of dynamic LDS: a per-device function attribute, set on every launch (cheap) rather than cached per process
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MinuSmem));
+    if (e != hipSuccess) return e;
     const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
     hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n,
-                       force_generic ? 0 : 1);
+                       force_generic ? (const int32_t*)nullptr : fallback);
     return hipGetLastError();
 }
 
