@@ -73,7 +73,8 @@ typedef struct afis_timing {
     float   tex_tail_ms;   /* S7+S8b+S9 on the texture correspondences                  */
     float   minu_ms;       /* S1-S3+S8a+S9 for the three selected minutiae templates    */
     float   fuse_ms;       /* S10 fusion                                                */
-    float   total_ms;      /* first kernel start .. last kernel end                     */
+    float   topk_ms;       /* S11 per-query rank lists on the device (k <= 64)           */
+    float   total_ms;      /* sum of the stages above                                   */
     int32_t adc_launches;  /* number of ADC kernel launches in the call                 */
     int64_t adc_lookups;   /* LUT look-ups performed by those launches                  */
     int64_t pairs;         /* (query, gallery template) pairs scored                    */
@@ -125,7 +126,11 @@ int afis_search_dat(afis_ctx* ctx, const void* const* latent_bytes, const size_t
                     float* scores, float* parts, int32_t* status,
                     int k, int64_t* topk_idx, float* topk_score);
 
-/* Queries resident in HBM before the timed region (bench): upload once, search many times. */
+/* Queries resident in HBM before the timed region (bench): upload once, search many times.
+ * afis_search_resident (and afis_search on top of it) runs the query groups back to back on the context's stream and syncs once.
+ * For k <= 64 the rank lists are made on the device (per-query top-k kernel over the shard's scores, score descending / index
+ * ascending) and only n_q x k x 12 bytes return to the host; the [n_q][G] score matrix crosses PCIe only when `scores` is given
+ * (-ldir mode) and the per-part scores only when `parts` is.  k > 64 sorts on the host. */
 typedef struct afis_queries afis_queries;
 int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_q, afis_queries** out);
 int afis_search_resident(afis_ctx* ctx, afis_queries* q,

@@ -56,7 +56,7 @@ struct afis_queries {
 struct afis_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {};
+    std::vector<hipEvent_t> evpool;      // 6 per query group + 2: the groups of a search run back to back, timings are read at the end
     std::string err;
     DevBuf codewords, table;
     HostGallery hg;
@@ -66,7 +66,7 @@ struct afis_ctx {
     DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_empty;
     int max_nR = 0;
     int64_t total_tex_points = 0;
-    DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb;
+    DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 7;
     int query_batch = 8;
@@ -205,7 +205,6 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
 #define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); afis_destroy(c); return AFIS_EDEVICE; } } while (0)
     CRCHK(hipSetDevice(device_id));
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto& e : c->ev) CRCHK(hipEventCreate(&e));
     std::vector<float> cw(codewords, codewords + (size_t)M * K * dsub);
     CRCHK(upload(c->codewords, cw, c->stream));
     std::vector<float> table((size_t)kDistN * kDistN);                     // matcher.cpp:45-56
@@ -235,8 +234,8 @@ void afis_destroy(afis_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
-    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release();
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release();
+    for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -598,6 +597,9 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q)
     delete q;
 }
 
+// Rank lists are made on the device for k <= kDeviceTopK (k passes of a workgroup-wide maximum per query); larger k sorts on the host.
+static const int kDeviceTopK = 64;
+
 int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* parts, int32_t* status,
                          int k, int64_t* topk_idx, float* topk_score)
 {
@@ -607,21 +609,28 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const GalleryDev& g = ctx->gal;
     const int64_t G = g.G;
+    const int nq_all = q->n_q;
     afis_timing tm = {};
-    if (status) for (int i = 0; i < q->n_q; ++i) status[i] = q->status[i];
+    if (status) for (int i = 0; i < nq_all; ++i) status[i] = q->status[i];
+    hipStream_t s = ctx->stream;
+    // The groups run back to back on the stream: no host round trip between them.  Scores of ALL queries stay on the device
+    // ([n_q][G]) for the rank-list kernel; they cross PCIe only when the caller asks for them.
+    const size_t n_groups = q->groups.size();
+    while (ctx->evpool.size() < n_groups * 6 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
+    if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
     int q0 = 0;
+    size_t gi = 0;
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
+        hipEvent_t* ev = &ctx->evpool[gi * 6];
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
             HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));
             HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
             HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
             HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
-            HIPCHK(ctx, ctx->scores.ensure(n_pairs * 4));
-            // minutiae scratch: simi + keys per workgroup
-            // per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs too large for the LDS fast path use it)
+            // minutiae scratch per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs the fast kernel cannot take use it)
             size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
             int n_wg = 1024;
             while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
@@ -629,53 +638,74 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
-            hipStream_t s = ctx->stream;
-            HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+            float* grp_scores = ctx->scores.as<float>() + (size_t)q0 * G;
+            HIPCHK(ctx, hipEventRecord(ev[0], s));
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
-            HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+            HIPCHK(ctx, hipEventRecord(ev[1], s));
             // larger chunks amortise the 128 KB LUT tile load; smaller ones keep enough workgroups in flight on a small gallery
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 65536 ? 512 : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32)));
             HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
-            HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+            HIPCHK(ctx, hipEventRecord(ev[2], s));
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
-            HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+            HIPCHK(ctx, hipEventRecord(ev[3], s));
             HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
-            HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
-            HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), ctx->scores.as<float>(), s));
-            HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
-            ctx->h_scores.resize(n_pairs);
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_scores.data(), ctx->scores.p, n_pairs * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(ctx, hipEventRecord(ev[4], s));
+            HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), grp_scores, s));
+            HIPCHK(ctx, hipEventRecord(ev[5], s));
+            // per-part scores only on request (tests, the all-templates mode); stream order keeps the buffer intact until the copy is done
             if (parts) HIPCHK(ctx, hipMemcpyAsync(parts + (size_t)q0 * G * 4, ctx->parts.p, n_pairs * 16, hipMemcpyDeviceToHost, s));
-            HIPCHK(ctx, hipStreamSynchronize(s));
-            float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
-            for (int i = 0; i < 5; ++i) HIPCHK(ctx, hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
-            HIPCHK(ctx, hipEventElapsedTime(&tot, ctx->ev[0], ctx->ev[5]));
-            tm.lut_ms += ms[0]; tm.adc_ms += ms[1]; tm.tex_tail_ms += ms[2]; tm.minu_ms += ms[3]; tm.fuse_ms += ms[4]; tm.total_ms += tot;
             if (d.n_tiles > 0) {
                 tm.adc_launches += 1;
                 int64_t rows = 0; for (int n : grp.h_lt_n) rows += (n + kTileRows - 1) / kTileRows * kTileRows;
                 tm.adc_lookups += rows * ctx->total_tex_points * kM;
             }
             tm.pairs += (int64_t)n_pairs;
-            if (scores) memcpy(scores + (size_t)q0 * G, ctx->h_scores.data(), n_pairs * 4);
         }
-        // rank lists (matcher.cpp:306-309; ties by ascending index)
-        if (k > 0) {
-            std::vector<int32_t> ind((size_t)G);
-            for (int i = 0; i < nq; ++i) {
-                const float* sc = ctx->h_scores.data() + (size_t)i * G;
-                std::iota(ind.begin(), ind.end(), 0);
-                const int kk = (int)std::min<int64_t>(k, G);
-                std::partial_sort(ind.begin(), ind.begin() + kk, ind.end(), [sc](int a, int b) { return sc[a] > sc[b] || (sc[a] == sc[b] && a < b); });
-                for (int r = 0; r < k; ++r) {
-                    const size_t o = (size_t)(q0 + i) * k + r;
-                    if (r < kk) { topk_idx[o] = ctx->index_base + ind[r]; topk_score[o] = sc[ind[r]]; }
-                    else { topk_idx[o] = -1; topk_score[o] = -INFINITY; }
-                }
+        q0 += nq; ++gi;
+    }
+    // ---- rank lists (matcher.cpp:306-309; ties by ascending index) ----
+    const bool dev_topk = k > 0 && k <= kDeviceTopK && G > 0 && nq_all > 0;
+    hipEvent_t* evk = &ctx->evpool[n_groups * 6];
+    if (dev_topk) {
+        HIPCHK(ctx, ctx->topk_idx.ensure((size_t)nq_all * k * 8));
+        HIPCHK(ctx, ctx->topk_score.ensure((size_t)nq_all * k * 4));
+        HIPCHK(ctx, hipEventRecord(evk[0], s));
+        HIPCHK(ctx, launch_topk(ctx->scores.as<float>(), nq_all, (int)G, k, (long long)ctx->index_base, ctx->topk_idx.as<long long>(), ctx->topk_score.as<float>(), s));
+        HIPCHK(ctx, hipEventRecord(evk[1], s));
+        HIPCHK(ctx, hipMemcpyAsync(topk_idx, ctx->topk_idx.p, (size_t)nq_all * k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipMemcpyAsync(topk_score, ctx->topk_score.p, (size_t)nq_all * k * 4, hipMemcpyDeviceToHost, s));
+    }
+    const bool host_topk = k > 0 && !dev_topk;
+    float* h_sc = scores;
+    if (G > 0 && nq_all > 0 && (scores || host_topk)) {
+        if (!h_sc) { ctx->h_scores.resize((size_t)nq_all * G); h_sc = ctx->h_scores.data(); }
+        HIPCHK(ctx, hipMemcpyAsync(h_sc, ctx->scores.p, (size_t)nq_all * G * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (G > 0) {
+        for (size_t i = 0; i < n_groups; ++i) {
+            hipEvent_t* ev = &ctx->evpool[i * 6];
+            float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
+            for (int j = 0; j < 5; ++j) HIPCHK(ctx, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
+            HIPCHK(ctx, hipEventElapsedTime(&tot, ev[0], ev[5]));
+            tm.lut_ms += ms[0]; tm.adc_ms += ms[1]; tm.tex_tail_ms += ms[2]; tm.minu_ms += ms[3]; tm.fuse_ms += ms[4]; tm.total_ms += tot;
+        }
+        if (dev_topk) { float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, evk[0], evk[1])); tm.topk_ms = t; tm.total_ms += t; }
+    }
+    if (host_topk) {                                                       // k > kDeviceTopK (or an empty gallery)
+        std::vector<int32_t> ind((size_t)G);
+        for (int i = 0; i < nq_all; ++i) {
+            const float* sc = G > 0 ? h_sc + (size_t)i * G : nullptr;
+            std::iota(ind.begin(), ind.end(), 0);
+            const int kk = (int)std::min<int64_t>(k, G);
+            std::partial_sort(ind.begin(), ind.begin() + kk, ind.end(), [sc](int a, int b) { return sc[a] > sc[b] || (sc[a] == sc[b] && a < b); });
+            for (int r = 0; r < k; ++r) {
+                const size_t o = (size_t)i * k + r;
+                if (r < kk) { topk_idx[o] = ctx->index_base + ind[r]; topk_score[o] = sc[ind[r]]; }
+                else { topk_idx[o] = -1; topk_score[o] = -INFINITY; }
             }
         }
-        q0 += nq;
     }
     ctx->timing = tm;
     return AFIS_OK;

@@ -98,6 +98,10 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
 // S10: fusion -> scores[q*G+g]
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 
+// S11: per-query rank list over the shard's scores [n_q][G] on the device (score descending, index ascending); out_idx[n_q][k] carries
+// index_base + local index (-1 / -inf beyond G)
+hipError_t launch_topk(const float* scores, int n_q, int G, int k, long long index_base, long long* out_idx, float* out_score, hipStream_t stream);
+
 // optional in-kernel phase timers (build with PHASE_TIMING=1); zeros otherwise
 hipError_t launch_pq_encode(const float* des, long long n, const float* codewords, uint8_t* codes, hipStream_t stream);
 hipError_t read_phase_cycles(unsigned long long* out32, bool reset);

@@ -587,6 +587,56 @@ __global__ __launch_bounds__(256) void k_fuse(QueryDev q, GalleryDev g, const fl
     scores[idx] = (float)((double)f + (double)a28 * 0.3);
 }
 
+// =====================================================================================================================
+// S11 rank list (matcher.cpp:306-309: indices sorted by score, descending; equal scores by ascending index — the documented
+// tie rule).  One 1024-thread workgroup per query; k rounds of a workgroup-wide maximum over UNIQUE 64-bit composites
+// (ordered score bits << 32 | ~index): round r finds the largest composite below round r-1's, so nothing is marked or moved.
+// The shard's scores stay in HBM/L2 (k passes over G floats per query: 24 x 0.4 MB at G = 100k); only k x 12 bytes per query go
+// back to the host.
+// =====================================================================================================================
+constexpr int kTopkThreads = 1024;
+__global__ __launch_bounds__(kTopkThreads) void k_topk(const float* __restrict__ scores, int G, int k, long long index_base,
+                                                      long long* __restrict__ out_idx, float* __restrict__ out_score)
+{
+    __shared__ u64 s_part[kTopkThreads / 64];
+    __shared__ u64 s_best;
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* sc = scores + (size_t)qi * G;
+    u64 prev = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        u64 best = 0;                                                     // every real composite is > 0 (ord_f32 >= 0x007fffff)
+        for (int e = tid; e < G; e += kTopkThreads) {
+            const u64 c = ((u64)ord_f32(sc[e]) << 32) | (uint32_t)(~(uint32_t)e);
+            if (c < prev && c > best) best = c;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u64 o = ((u64)(uint32_t)__shfl_xor((int)(best >> 32), off) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)best, off);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) s_part[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            u64 b = 0;
+#pragma unroll
+            for (int w = 0; w < kTopkThreads / 64; ++w) b = s_part[w] > b ? s_part[w] : b;
+            s_best = b;
+            const size_t o = (size_t)qi * k + r;
+            if (b) { const uint32_t idx = ~(uint32_t)b; out_idx[o] = index_base + (long long)idx; out_score[o] = sc[idx]; }
+            else { out_idx[o] = -1; out_score[o] = -INFINITY; }              // k > G
+        }
+        __syncthreads();
+        prev = s_best;                                                     // 0 once the scores are exhausted: nothing is below it
+    }
+}
+
+hipError_t launch_topk(const float* scores, int n_q, int G, int k, long long index_base, long long* out_idx, float* out_score, hipStream_t stream)
+{
+    if (n_q <= 0 || k <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_topk, dim3(n_q), dim3(kTopkThreads), 0, stream, scores, G, k, index_base, out_idx, out_score);
+    return hipGetLastError();
+}
+
 hipError_t read_phase_cycles(unsigned long long* out32, bool reset)
 {
 #ifdef AFIS_PHASE_TIMING

@@ -721,3 +721,32 @@ def test_angle_stage_atan2_equals_libm_on_every_coordinate_difference(codebook_b
     want = oracle.atan2f_grid(R)
     diff = got.view(np.uint32) != want.view(np.uint32)
     assert not diff.any(), (int(diff.sum()), np.argwhere(diff)[:5] - R, got[diff][:5], want[diff][:5])
+
+
+def test_rank_lists_device_kernel_equals_host_sort(codebook_bytes, cb, medium, small):
+    """S11 (matcher.cpp:306-309 + the documented tie rule): k <= 64 is ranked by the device kernel, k > 64 by a host partial_sort of the
+    copied score matrix; both must give the lexsort (score descending, index ascending) — including the 99 % of pairs tied at 0 —
+    and the -1 / -inf padding when k exceeds the gallery."""
+    lats, gal, planted = medium
+    G = gal.G
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add_packed(gal); m.gallery_commit(1000)                      # index_base: rank lists carry global indices
+    qh = m.upload_queries(lats)
+    r64 = m.search_resident(qh, k=64, want_scores=True)
+    r100 = m.search_resident(qh, k=100)                                    # host path
+    r1 = m.search_resident(qh, k=1)
+    m.free_queries(qh)
+    assert (r64["scores"] == 0).mean() > 0.3                                # the tie at zero is massive
+    for q in range(len(lats)):
+        order = np.lexsort((np.arange(G), -r64["scores"][q].astype(np.float64)))
+        assert np.array_equal(r64["topk_idx"][q], order[:64] + 1000) and np.array_equal(r64["topk_score"][q], r64["scores"][q][order[:64]])
+        assert np.array_equal(r100["topk_idx"][q], order[:100] + 1000)
+        assert r1["topk_idx"][q, 0] == order[0] + 1000
+    m.close()
+    lats2, gal2 = small
+    m = _matcher(codebook_bytes, gal2[:12])
+    r = m.search(lats2, k=24)
+    assert (r["topk_idx"][:, 12:] == -1).all() and np.isneginf(r["topk_score"][:, 12:]).all() and (r["topk_idx"][:, :12] >= 0).all()
+    for q in range(len(lats2)):
+        assert sorted(r["topk_idx"][q, :12]) == list(range(12))
+    m.close()
