@@ -32,29 +32,66 @@ BYTES_PER_TEX_POINT = 2 + 2 + 4 + 16  # x, y, ori, 16 PQ code bytes
 BYTES_PER_MINUTIA = 2 + 2 + 4 + 96 * 4
 
 
-def cpu_baseline(cb_bytes, lats, gal, lo, budget_s=15.0):
-    """Oracle (CPU restatement, OpenMP) timed on a bounded sample of the same workload: a few latents x a slice of the gallery."""
+def physical_cores():
+    """(physical cores, logical CPUs) of this host from /proc/cpuinfo (threads != cores on an SMT host)."""
+    try:
+        ids, n = set(), 0
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"): n += 1
+            elif line.startswith("physical id"): phys = line.split(":")[1].strip()
+            elif line.startswith("core id"): core = line.split(":")[1].strip(); ids.add((phys, core))
+        return (len(ids) or n), n
+    except Exception:
+        return os.cpu_count() or 1, os.cpu_count() or 1
+
+
+def cpu_baseline(cb_bytes, lats, gal, lo, budget_s=12.0):
+    """The CPU restatement of the reference path (oracle/, OpenMP) timed on bounded samples of the same workload:
+       compute-only   gallery parsed once and resident in RAM, all host threads          -> the `value` of cpu_baseline
+       compute-only   8 threads, schedule(static,16): the reference's OpenMP setting (matcher.cpp:168, :273)
+       reference-faithful  8 threads, static 16, and every rolled .dat RE-READ AND RE-PARSED for every pair from page-cache-warm
+                      files, which is what the reference's loop does (matcher.cpp:173, :278)."""
+    import shutil
+    import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle
     orc = Oracle()
     ocb = orc.codebook(cb_bytes)
-    cores = orc.lib.orc_num_threads()
+    threads = orc.lib.orc_num_threads()
     n_lat = min(2, len(lats))
-    # size the sample from a probe of 2*cores pairs
     hl = [orc.latent(ocb, T.write_latent(L))[0] for L in lats[:n_lat]]
-    probe = [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(min(gal.G, 2 * cores))]
-    t0 = time.perf_counter(); orc.search(ocb, hl[0], probe, tie_mode=1, threads=cores); dt = time.perf_counter() - t0
+    dats = [T.write_rolled(gal.template(g)) for g in range(min(gal.G, 2 * threads))]
+    probe = [orc.rolled(d)[0] for d in dats]
+    t0 = time.perf_counter(); orc.search(ocb, hl[0], probe, tie_mode=1, threads=threads); dt = time.perf_counter() - t0
     per_pair_wall = dt / max(1, len(probe))
     n_gal = int(min(gal.G, max(len(probe), budget_s / n_lat / max(per_pair_wall, 1e-6))))
-    hr = probe + [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(len(probe), n_gal)]
+    dats += [T.write_rolled(gal.template(g)) for g in range(len(probe), n_gal)]
+    hr = probe + [orc.rolled(d)[0] for d in dats[len(probe):]]
     t0 = time.perf_counter()
     for h in hl:
-        orc.search(ocb, h, hr, tie_mode=1, threads=cores)
+        orc.search(ocb, h, hr, tie_mode=1, threads=threads)
     wall = time.perf_counter() - t0
-    t1 = time.perf_counter(); orc.search(ocb, hl[0], hr[:min(len(hr), 400)], tie_mode=1, threads=0); wall8 = time.perf_counter() - t1
-    pairs_per_s = n_lat * n_gal / wall
-    return pairs_per_s, cores, f"{n_lat} latents x {n_gal} gallery templates (templates {lo}..{lo + n_gal} of the bench gallery), all {cores} host threads", \
-        min(len(hr), 400) / wall8
+    n8 = min(len(hr), 480)
+    t1 = time.perf_counter(); orc.search(ocb, hl[0], hr[:n8], tie_mode=1, threads=0); wall8 = time.perf_counter() - t1
+    # reference-faithful leg: the same n8 templates as files in a tmpdir (written and read once: page-cache warm)
+    tmp = tempfile.mkdtemp(prefix="afis_cpu_baseline_")
+    try:
+        paths = []
+        for g in range(n8):
+            pth = os.path.join(tmp, "R%06d.dat" % g)
+            with open(pth, "wb") as f: f.write(dats[g])
+            with open(pth, "rb") as f: f.read()
+            paths.append(pth)
+        t2 = time.perf_counter(); _, sf = orc.search_files(ocb, hl[0], paths, tie_mode=1, threads=0); wallf = time.perf_counter() - t2
+        _, sr = orc.search(ocb, hl[0], hr[:n8], tie_mode=1, threads=0)
+        assert np.array_equal(sf, sr)                                    # same scores either way; only the time differs
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"pairs_per_s": n_lat * n_gal / wall, "threads": threads,
+            "sample": f"{n_lat} latents x {n_gal} gallery templates (templates {lo}..{lo + n_gal} of the bench gallery), all {threads} host threads",
+            "pairs_per_s_8_threads": n8 / wall8, "pairs_per_s_reference_faithful": n8 / wallf,
+            "sample_8_threads": f"1 latent x {n8} gallery templates, 8 threads schedule(static,16)"}
 
 
 def main():
@@ -72,6 +109,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test mode: every rank uses GPU 0 (validates the N>1 path on a 1-GPU box)")
+    ap.add_argument("--dump-ranks", default="", help="rank 0 writes the merged rank lists of the last step to this .npz (tests)")
     ap.add_argument("--force-dist", action="store_true", help="test mode: initialise torch.distributed and run the exchange step even when WORLD_SIZE is 1")
     a = ap.parse_args()
 
@@ -150,6 +188,8 @@ def main():
     hits = sum(1 for q in range(Q) if int(idx[q, 0]) == planted[q][0][0])
 
     out = None
+    if rank == 0 and a.dump_ranks:
+        np.savez(a.dump_ranks, idx=np.asarray(idx), score=np.asarray(sc))
     if rank == 0:
         # roofline of the dominant kernel (PQ-ADC row-max): algorithmic bytes per launch / average launch duration, where the
         # duration comes from HIP events on the stream the kernel runs on (afis_get_timing).
@@ -160,11 +200,13 @@ def main():
         alg_bytes_launch = q_per_launch * shard_tex_points * BYTES_PER_TEX_POINT
         achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
         lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
-        traffic = None
+        traffic = None; traffic_source = None
         tp = os.path.join(ROOT, "profiles", "adc_hbm_traffic.json")
         if os.path.exists(tp) and world == 1 and G == 100000 and Q == 100:      # measured for the default workload only
             try:
-                traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("traffic_bytes_per_launch")
+                traffic_source = "profiles/adc_hbm_traffic.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, %s; PMC counters cannot be read inside this run)" % tj.get("round", "round 1")
             except Exception:
                 traffic = None
         pipeline_bytes = Q * (int(nt_all.sum()) * BYTES_PER_TEX_POINT + int(nm_all.sum()) * BYTES_PER_MINUTIA)
@@ -177,7 +219,8 @@ def main():
                        "adc_variant": a.variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
             "roofline": {"bound": "hbm", "kernel": "k_adc_rowmax", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                         "achieved_is": "ALGORITHMIC bytes (24 B per rolled texture point per query of the launch) / kernel time; the kernel reads each code byte from HBM once per launch and is bound by LDS/VALU issue, see lds_frac",
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),
                          "lds_lookups_per_s": lookups_per_s, "lds_peak_lookups_per_s": LDS_PEAK_LOOKUPS,
                          "lds_frac": round(lookups_per_s / LDS_PEAK_LOOKUPS, 4),
@@ -186,13 +229,20 @@ def main():
             "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            pps, cores, sample, pps8 = cpu_baseline(cb_bytes, lats, gal, lo)
+            cpu = cpu_baseline(cb_bytes, lats, gal, lo)
             try:
                 cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
             except Exception:
                 cpu_model = "unknown"
-            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": cores, "kind": "port", "sample": sample, "cpu_model": cpu_model,
-                                   "pairs_per_s": round(pps, 1), "reference_setting_8_threads_static16_queries_per_s": round(pps8 / G, 6)}
+            phys, logical = physical_cores()
+            pps = cpu["pairs_per_s"]
+            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": phys, "threads": cpu["threads"], "logical_cpus": logical,
+                                   "kind": "port", "sample": cpu["sample"], "cpu_model": cpu_model, "pairs_per_s": round(pps, 1),
+                                   "compute_only_8_threads_static16_queries_per_s": round(cpu["pairs_per_s_8_threads"] / G, 6),
+                                   "reference_faithful_8_threads_static16_reparse_per_pair_queries_per_s": round(cpu["pairs_per_s_reference_faithful"] / G, 6),
+                                   "sample_8_threads": cpu["sample_8_threads"],
+                                   "note": "value = compute-only oracle on every host thread (gallery resident in RAM); reference-faithful = the reference's own loop: "
+                                           "8 threads, schedule(static,16), every rolled .dat re-parsed per pair from page-cache-warm files (matcher.cpp:168-173)"}
             out["speedup_vs_cpu_baseline"] = round(value / (pps / G), 1)
     m.free_queries(qh)
     m.close()

@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "../../include/afis_matcher.h"
+#include "cli_util.h"
 #include "rank_exchange.h"
 #include "template_io.h"
 
@@ -45,48 +46,6 @@ namespace fs = std::filesystem;
 using namespace afis;
 
 namespace {
-
-// argparser.h:5-24 — flat token search
-struct ArgParser {
-    std::vector<std::string> tokens;
-    ArgParser(int argc, char** argv) { for (int i = 1; i < argc; ++i) tokens.push_back(argv[i]); }
-    const std::string& getCmdOption(const std::string& option) const
-    {
-        static const std::string empty;
-        auto it = std::find(tokens.begin(), tokens.end(), option);
-        if (it != tokens.end() && ++it != tokens.end()) return *it;
-        return empty;
-    }
-    bool cmdOptionExists(const std::string& option) const { return std::find(tokens.begin(), tokens.end(), option) != tokens.end(); }
-};
-
-// afis.config is a flat JSON object of string values (afis.config:1-17); this reads exactly that.
-std::map<std::string, std::string> read_flat_json(const std::string& path)
-{
-    std::map<std::string, std::string> kv;
-    std::ifstream in(path);
-    if (!in) return kv;
-    std::stringstream ss; ss << in.rdbuf();
-    const std::string s = ss.str();
-    size_t i = 0;
-    auto read_string = [&](std::string& out) -> bool {
-        while (i < s.size() && s[i] != '"') ++i;
-        if (i >= s.size()) return false;
-        ++i; out.clear();
-        while (i < s.size() && s[i] != '"') { if (s[i] == '\\' && i + 1 < s.size()) ++i; out.push_back(s[i++]); }
-        ++i;
-        return true;
-    };
-    std::string k, v;
-    while (read_string(k)) {
-        while (i < s.size() && s[i] != ':' ) ++i;
-        if (i >= s.size()) break;
-        ++i;
-        while (i < s.size() && isspace((unsigned char)s[i])) ++i;
-        if (i < s.size() && s[i] == '"') { if (!read_string(v)) break; kv[k] = v; }
-    }
-    return kv;
-}
 
 std::vector<fs::path> list_dat(const std::string& dir)
 {
@@ -159,6 +118,17 @@ struct Job {
     std::vector<std::pair<int64_t, int64_t>> bounds{{0, 0}};
     int64_t lo = 0, hi = 0, g_max = 0;
     bool root() const { return w.rank == 0; }
+    // Agreement point: every rank reports its local status; all of them get the first failure (in rank order) and leave together.
+    // Without it a rank that fails (say, a corrupt rolled .dat in ITS shard) exits while the others wait in the next collective.
+    int agree(int code)
+    {
+        if (!multi) return code;
+        std::string e;
+        const int r = world_agree(w, code, e);
+        if (r == -1000) { std::cerr << "match[rank " << w.rank << "]: " << e << std::endl; return 2; }
+        if (r != 0 && code == 0) std::cerr << "match[rank " << w.rank << "]: stopping, another rank failed (" << r << ")" << std::endl;
+        return r;
+    }
     int owner(int64_t idx) const { for (int r = 0; r < (int)bounds.size(); ++r) if (idx >= bounds[(size_t)r].first && idx < bounds[(size_t)r].second) return r; return -1; }
 };
 
@@ -177,14 +147,19 @@ int plan_shards(Job& job, const std::string& gallery_path, const std::vector<fs:
     job.lo = job.bounds[(size_t)job.w.rank].first; job.hi = job.bounds[(size_t)job.w.rank].second;
     job.g_max = 0;
     for (const auto& b : job.bounds) job.g_max = std::max(job.g_max, b.second - b.first);
-    if (job.multi) {                                                          // every rank must see the same gallery in the same order
-        uint64_t h[2] = {(uint64_t)G, 1469598103934665603ull};
-        for (const fs::path& p : rolled) for (char c : p.string()) { h[1] ^= (unsigned char)c; h[1] *= 1099511628211ull; }
-        std::vector<uint64_t> all((size_t)job.w.world * 2);
-        JOBCHK(world_all_gather(job.w, h, all.data(), sizeof(h), e_));
-        for (int r = 0; r < job.w.world; ++r)
-            if (all[(size_t)r * 2] != h[0] || all[(size_t)r * 2 + 1] != h[1]) { std::cerr << "match[rank " << job.w.rank << "]: rank " << r << " lists a different gallery" << std::endl; return 2; }
-    }
+    return 0;
+}
+
+// every rank must see the same gallery in the same order
+int check_same_gallery(Job& job, const std::vector<fs::path>& rolled)
+{
+    if (!job.multi) return 0;
+    uint64_t h[2] = {(uint64_t)rolled.size(), 1469598103934665603ull};
+    for (const fs::path& p : rolled) for (char c : p.string()) { h[1] ^= (unsigned char)c; h[1] *= 1099511628211ull; }
+    std::vector<uint64_t> all((size_t)job.w.world * 2);
+    JOBCHK(world_all_gather(job.w, h, all.data(), sizeof(h), e_));
+    for (int r = 0; r < job.w.world; ++r)
+        if (all[(size_t)r * 2] != h[0] || all[(size_t)r * 2 + 1] != h[1]) { std::cerr << "match[rank " << job.w.rank << "]: rank " << r << " lists a different gallery" << std::endl; return 2; }
     return 0;
 }
 
@@ -193,37 +168,6 @@ int plan_shards(Job& job, const std::string& gallery_path, const std::vector<fs:
 int main(int argc, char** argv)
 {
     ArgParser args(argc, argv);
-    if (args.cmdOptionExists("-selftest-exchange")) {                           // rendezvous only (no GPU): rank 0's 128 bytes reach every rank
-        RankWorld w; world_from_env(w);
-        unsigned char id[128];
-        for (int i = 0; i < 128; ++i) id[i] = w.rank == 0 ? (unsigned char)(i * 7 + 3) : 0;
-        std::string err;
-        if (!tcp_broadcast(w, id, sizeof(id), err)) { std::cerr << "match: " << err << std::endl; return 2; }
-        unsigned sum = 0; for (int i = 0; i < 128; ++i) sum = sum * 31 + id[i];
-        std::cout << "rank " << w.rank << " of " << w.world << " id " << sum << std::endl;
-        return 0;
-    }
-    if (argc >= 3 && !strcmp(argv[1], "-selftest-args")) {                      // token rules (no GPU): match -selftest-args <opt> <tokens...>
-        ArgParser rest(argc - 2, argv + 2);                                     // argv[2] plays the program name, as argv[0] would
-        std::cout << "exists=" << (rest.cmdOptionExists(argv[2]) ? 1 : 0) << " value=" << rest.getCmdOption(argv[2]) << std::endl;
-        return 0;
-    }
-    if (args.cmdOptionExists("-selftest-config")) {                             // config reader (no GPU): match -selftest-config <file> -key <key>
-        const auto kv = read_flat_json(args.getCmdOption("-selftest-config"));
-        const auto it = kv.find(args.getCmdOption("-key"));
-        std::cout << "found=" << (it != kv.end() ? 1 : 0) << " value=" << (it != kv.end() ? it->second : std::string()) << std::endl;
-        return 0;
-    }
-    if (args.cmdOptionExists("-selftest-shards")) {                             // shard cut rule (no GPU): weights file (one int per line), world
-        std::ifstream f(args.getCmdOption("-selftest-shards"));
-        std::vector<int32_t> wts; int v;
-        while (f >> v) wts.push_back(v);
-        const int world = atoi(args.getCmdOption("-world").c_str());
-        for (const auto& b : shard_bounds((int64_t)wts.size(), wts, world)) std::cout << b.first << " " << b.second << std::endl;
-        std::vector<int32_t> none;
-        for (const auto& b : shard_bounds((int64_t)wts.size(), none, world)) std::cout << b.first << " " << b.second << std::endl;
-        return 0;
-    }
     if (args.cmdOptionExists("-h") || args.cmdOptionExists("--help")) {
         std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>] [-pack <gallery container to write>]\n       -g may name a packed gallery container instead of a directory\n";
         return 0;
@@ -245,7 +189,7 @@ int main(int argc, char** argv)
     else { std::cout << "Missing argument for gallery directory. Using default from afis.config" << std::endl; if (!from_config("GalleryTemplateDirectory", gallery_path)) return 2; }
     Job job;
     world_from_env(job.w);
-    job.multi = job.w.world > 1 || getenv("AFIS_FORCE_EXCHANGE") != nullptr;   // the variable runs the RCCL path with a single rank (tests)
+    job.multi = job.w.world > 1 || getenv("AFIS_FORCE_EXCHANGE") != nullptr;   // AFIS_FORCE_EXCHANGE: run the exchange path (RCCL communicator of one rank) in a single-process job
     if (!job.root()) std::cout.rdbuf(nullptr);                                  // rank 0 speaks for the job; errors still go to stderr
     const int device = args.cmdOptionExists("-d") ? atoi(args.getCmdOption("-d").c_str()) : (job.w.world > 1 ? job.w.local_rank : 0);
 
@@ -262,6 +206,17 @@ int main(int argc, char** argv)
         if (!world_init(job.w, device, err)) { std::cerr << "match[rank " << job.w.rank << "]: " << err << std::endl; afis_destroy(ctx); return 2; }
     }
     auto finish = [&](int code) { if (job.multi) world_finalize(job.w); afis_destroy(ctx); return code; };
+    auto api = [&](int rc, const char* what) -> int {                            // C-ABI return code -> process status (reported, not yet acted on)
+        if (rc == AFIS_OK) return 0;
+        std::cerr << "match[rank " << job.w.rank << "]: " << what << " failed (" << rc << "): " << afis_last_error(ctx) << std::endl;
+        return 2;
+    };
+    auto xchg = [&](const void* send, void* recv, size_t bytes) -> bool {        // the exchange step; a failure here ends the job on this rank
+        std::string e;
+        if (world_all_gather(job.w, send, recv, bytes, e)) return true;
+        std::cerr << "match[rank " << job.w.rank << "]: " << e << std::endl;
+        return false;
+    };
     using clk = std::chrono::high_resolution_clock;
     int ret = 0;
     const std::string pack_to = args.cmdOptionExists("-pack") ? args.getCmdOption("-pack") : "";
@@ -282,19 +237,19 @@ int main(int argc, char** argv)
         const auto t0 = clk::now();
         std::cout << "Latent Query: " << latent_file << std::endl;
         std::cout << "Gallery size: " << rolled.size() << std::endl;
-        if ((ret = plan_shards(job, gallery_path, rolled)) != 0) return finish(ret);
-        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi)) != 0) return finish(ret);
+        if ((ret = job.agree(plan_shards(job, gallery_path, rolled))) != 0) return finish(ret);
+        if ((ret = check_same_gallery(job, rolled)) != 0) return finish(ret);
+        if ((ret = job.agree(load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi))) != 0) return finish(ret);
         Latent L; L.load(latent_file);
         if (job.root() && L.view.n_minu <= 0 && L.view.n_tex <= 0) { std::ofstream out(score_file); out << 0 << std::endl; }       // :260-268
         const int k = (int)std::min<size_t>(24, rolled.size());
         constexpr int kk = 24;                                                   // fixed-size per-rank block of the exchange
         std::vector<int64_t> idx(kk); std::vector<float> sc(kk); int32_t status = 0;
-        CHECK(ctx, afis_search(ctx, &L.view, 1, nullptr, nullptr, &status, kk, idx.data(), sc.data()));     // padded with -1 beyond the shard
+        if ((ret = job.agree(api(afis_search(ctx, &L.view, 1, nullptr, nullptr, &status, kk, idx.data(), sc.data()), "afis_search"))) != 0) return finish(ret);   // padded with -1 beyond the shard
         if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; return finish(1); }
         if (job.multi) {                                                         // the exchange step: per-shard top-24 -> merged top-24
             std::vector<int64_t> all_i((size_t)job.w.world * kk); std::vector<float> all_s((size_t)job.w.world * kk);
-            JOBCHK(world_all_gather(job.w, idx.data(), all_i.data(), kk * sizeof(int64_t), e_));
-            JOBCHK(world_all_gather(job.w, sc.data(), all_s.data(), kk * sizeof(float), e_));
+            if (!xchg(idx.data(), all_i.data(), kk * sizeof(int64_t)) || !xchg(sc.data(), all_s.data(), kk * sizeof(float))) return finish(2);
             merge_topk(all_i, all_s, job.w.world, kk, kk, idx, sc);
         }
         // correspondence files for the top 24 (matcher.cpp:311-328): one "lx,ly,rx,ry" line per surviving correspondence;
@@ -305,7 +260,7 @@ int main(int argc, char** argv)
             std::vector<int64_t> mine; std::vector<int> pos;
             for (int j = 0; j < k; ++j) if (idx[j] >= job.lo && idx[j] < job.hi) { mine.push_back(idx[j]); pos.push_back(j); }
             std::vector<int32_t> c((size_t)mine.size() * 3 + 1); std::vector<int16_t> v((size_t)mine.size() * kXY + 1);
-            CHECK(ctx, afis_correspondences(ctx, &L.view, mine.data(), (int)mine.size(), c.data(), v.data()));
+            if ((ret = job.agree(api(afis_correspondences(ctx, &L.view, mine.data(), (int)mine.size(), c.data(), v.data()), "afis_correspondences"))) != 0) return finish(ret);
             for (size_t a = 0; a < mine.size(); ++a) {
                 memcpy(&counts[(size_t)pos[a] * 3], &c[a * 3], 3 * sizeof(int32_t));
                 memcpy(&xy[(size_t)pos[a] * kXY], &v[a * kXY], kXY * sizeof(int16_t));
@@ -313,8 +268,7 @@ int main(int argc, char** argv)
         }
         if (job.multi) {
             std::vector<int32_t> all_c((size_t)job.w.world * counts.size()); std::vector<int16_t> all_v((size_t)job.w.world * xy.size());
-            JOBCHK(world_all_gather(job.w, counts.data(), all_c.data(), counts.size() * sizeof(int32_t), e_));
-            JOBCHK(world_all_gather(job.w, xy.data(), all_v.data(), xy.size() * sizeof(int16_t), e_));
+            if (!xchg(counts.data(), all_c.data(), counts.size() * sizeof(int32_t)) || !xchg(xy.data(), all_v.data(), xy.size() * sizeof(int16_t))) return finish(2);
             for (int j = 0; j < k; ++j) {
                 const int r = job.owner(idx[j]);
                 if (r < 0) continue;
@@ -355,8 +309,9 @@ int main(int argc, char** argv)
         if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; return finish(-1); }
         std::cout << "Gallery size: " << rolled.size() << std::endl;
         const auto t0 = clk::now();
-        if ((ret = plan_shards(job, gallery_path, rolled)) != 0) return finish(ret);
-        if ((ret = load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi)) != 0) return finish(ret);
+        if ((ret = job.agree(plan_shards(job, gallery_path, rolled))) != 0) return finish(ret);
+        if ((ret = check_same_gallery(job, rolled)) != 0) return finish(ret);
+        if ((ret = job.agree(load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi))) != 0) return finish(ret);
         const size_t G = rolled.size(), Gl = (size_t)(job.hi - job.lo), Gm = (size_t)job.g_max;
         const size_t batch = 16;
         for (size_t i0 = 0; i0 < latents.size(); i0 += batch) {
@@ -365,12 +320,12 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < nb; ++i) { Ls[i].load(latents[i0 + i]); views[i] = Ls[i].view; }
             std::vector<float> scores(nb * G); std::vector<int32_t> status(nb);
             if (!job.multi) {
-                CHECK(ctx, afis_search(ctx, views.data(), (int)nb, scores.data(), nullptr, status.data(), 0, nullptr, nullptr));
+                if ((ret = api(afis_search(ctx, views.data(), (int)nb, scores.data(), nullptr, status.data(), 0, nullptr, nullptr), "afis_search")) != 0) return finish(ret);
             } else {                                                             // the exchange step: score columns of every shard
                 std::vector<float> part(nb * std::max<size_t>(Gl, 1)), block(nb * std::max<size_t>(Gm, 1), -1.0f), all((size_t)job.w.world * block.size());
-                CHECK(ctx, afis_search(ctx, views.data(), (int)nb, part.data(), nullptr, status.data(), 0, nullptr, nullptr));
+                if ((ret = job.agree(api(afis_search(ctx, views.data(), (int)nb, part.data(), nullptr, status.data(), 0, nullptr, nullptr), "afis_search"))) != 0) return finish(ret);
                 for (size_t i = 0; i < nb; ++i) memcpy(&block[i * Gm], &part[i * Gl], Gl * sizeof(float));
-                JOBCHK(world_all_gather(job.w, block.data(), all.data(), block.size() * sizeof(float), e_));
+                if (!xchg(block.data(), all.data(), block.size() * sizeof(float))) return finish(2);
                 for (int r = 0; r < job.w.world; ++r) {
                     const size_t lo = (size_t)job.bounds[(size_t)r].first, n = (size_t)(job.bounds[(size_t)r].second - job.bounds[(size_t)r].first);
                     for (size_t i = 0; i < nb; ++i) memcpy(&scores[i * G + lo], &all[(size_t)r * block.size() + i * Gm], n * sizeof(float));

@@ -6,7 +6,9 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <rccl/rccl.h>
+#include <poll.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -92,8 +94,73 @@ bool tcp_broadcast(const RankWorld& w, void* buf, size_t len, std::string& err)
 #define RX_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return false; } } while (0)
 #define RX_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { err = std::string(#call) + ": " + ncclGetErrorString(r_); return false; } } while (0)
 
+static void set_timeouts(int fd, double seconds)
+{
+    timeval tv; tv.tv_sec = (long)seconds; tv.tv_usec = 0;
+    setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+    setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+}
+
+// AFIS_EXCHANGE=tcp: every rank's block goes to rank 0, the concatenation comes back.  Header per peer: rank, call counter, size.
+static bool tcp_all_gather(RankWorld& w, const void* send, void* recv, size_t bytes, std::string& err)
+{
+    struct Hdr { int32_t rank; uint32_t seq; uint64_t bytes; };
+    const uint32_t seq = w.seq++;
+    if (w.rank == 0) {
+        if (w.listen_fd < 0) {
+            sockaddr_in sa; memset(&sa, 0, sizeof(sa));
+            sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)w.port); sa.sin_addr.s_addr = htonl(INADDR_ANY);
+            const int ls = ::socket(AF_INET, SOCK_STREAM, 0);
+            if (ls < 0) { err = "socket() failed"; return false; }
+            const int one = 1; setsockopt(ls, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+            if (::bind(ls, (sockaddr*)&sa, sizeof(sa)) != 0 || ::listen(ls, 64) != 0) { ::close(ls); err = "cannot listen on port " + std::to_string(w.port); return false; }
+            w.listen_fd = ls;
+        }
+        memcpy(recv, send, bytes);
+        std::vector<int> peers;
+        bool ok = true;
+        for (int i = 1; i < w.world && ok; ++i) {
+            pollfd pf{w.listen_fd, POLLIN, 0};
+            if (::poll(&pf, 1, (int)(w.timeout_s * 1000)) <= 0) { err = "rank 0: timed out waiting for a peer in exchange " + std::to_string(seq); ok = false; break; }
+            const int c = ::accept(w.listen_fd, nullptr, nullptr);
+            if (c < 0) { err = "accept() failed"; ok = false; break; }
+            set_timeouts(c, w.timeout_s);
+            peers.push_back(c);
+            Hdr h{};
+            ok = recv_all(c, &h, sizeof(h)) && h.rank > 0 && h.rank < w.world && h.seq == seq && h.bytes == bytes && recv_all(c, (char*)recv + (size_t)h.rank * bytes, bytes);
+            if (!ok) err = "rank 0: a peer sent a mismatching block in exchange " + std::to_string(seq);
+        }
+        for (int c : peers) { if (ok && !send_all(c, recv, bytes * w.world)) { ok = false; err = "rank 0: returning the gathered blocks failed"; } ::close(c); }
+        return ok;
+    }
+    sockaddr_in sa; memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET; sa.sin_port = htons((uint16_t)w.port);
+    if (inet_pton(AF_INET, w.addr.c_str(), &sa.sin_addr) != 1) { err = "MASTER_ADDR must be an IPv4 address, got " + w.addr; return false; }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(w.timeout_s);
+    while (std::chrono::steady_clock::now() < deadline) {
+        const int c = ::socket(AF_INET, SOCK_STREAM, 0);
+        if (c < 0) { err = "socket() failed"; return false; }
+        if (::connect(c, (sockaddr*)&sa, sizeof(sa)) == 0) {
+            set_timeouts(c, w.timeout_s);
+            const Hdr h{w.rank, seq, (uint64_t)bytes};
+            const bool ok = send_all(c, &h, sizeof(h)) && send_all(c, send, bytes) && recv_all(c, recv, bytes * w.world);
+            ::close(c);
+            if (!ok) err = "rank " + std::to_string(w.rank) + ": exchange " + std::to_string(seq) + " with rank 0 failed (peer gone or timed out)";
+            return ok;
+        }
+        ::close(c);
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    }
+    err = "rank " + std::to_string(w.rank) + ": cannot reach rank 0 at " + w.addr + ":" + std::to_string(w.port);
+    return false;
+}
+
 bool world_init(RankWorld& w, int device, std::string& err)
 {
+    if (const char* t = getenv("AFIS_EXCHANGE_TIMEOUT_S")) { const double v = atof(t); if (v > 0) w.timeout_s = v; }
+    const char* ex = getenv("AFIS_EXCHANGE");
+    w.tcp = ex && !strcmp(ex, "tcp");
+    if (w.tcp) return true;
     RX_HIP(hipSetDevice(device));
     ncclUniqueId id; memset(&id, 0, sizeof(id));
     if (w.rank == 0) RX_NCCL(ncclGetUniqueId(&id));
@@ -110,6 +177,7 @@ bool world_init(RankWorld& w, int device, std::string& err)
 bool world_all_gather(RankWorld& w, const void* send, void* recv, size_t bytes, std::string& err)
 {
     if (bytes == 0) return true;
+    if (w.tcp) return tcp_all_gather(w, send, recv, bytes, err);
     if (!w.comm) { err = "world_all_gather: communicator not initialised"; return false; }
     hipStream_t s = (hipStream_t)w.stream;
     if (w.cap_send < bytes) { if (w.d_send) RX_HIP(hipFree(w.d_send)); w.d_send = nullptr; RX_HIP(hipMalloc(&w.d_send, bytes)); w.cap_send = bytes; }
@@ -117,8 +185,29 @@ bool world_all_gather(RankWorld& w, const void* send, void* recv, size_t bytes, 
     RX_HIP(hipMemcpyAsync(w.d_send, send, bytes, hipMemcpyHostToDevice, s));
     RX_NCCL(ncclAllGather(w.d_send, w.d_recv, bytes, ncclChar, (ncclComm_t)w.comm, s));
     RX_HIP(hipMemcpyAsync(recv, w.d_recv, bytes * w.world, hipMemcpyDeviceToHost, s));
-    RX_HIP(hipStreamSynchronize(s));
-    return true;
+    // bounded wait: a peer that died before the collective would otherwise leave this rank in it for ever
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(w.timeout_s);
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return true;
+        if (q != hipErrorNotReady) { err = std::string("exchange failed: ") + hipGetErrorString(q); return false; }
+        if (std::chrono::steady_clock::now() > deadline) {
+            err = "exchange timed out after " + std::to_string((int)w.timeout_s) + " s (a peer rank is gone?)";
+            (void)ncclCommAbort((ncclComm_t)w.comm); w.comm = nullptr;
+            return false;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
+int world_agree(RankWorld& w, int my_code, std::string& err)
+{
+    if (w.world <= 1 && !w.tcp && !w.comm) return my_code;
+    std::vector<int32_t> all((size_t)w.world, 0);
+    const int32_t mine = my_code;
+    if (!world_all_gather(w, &mine, all.data(), sizeof(mine), err)) return -1000;
+    for (int32_t c : all) if (c != 0) return c;
+    return 0;
 }
 
 void world_finalize(RankWorld& w)
@@ -127,6 +216,8 @@ void world_finalize(RankWorld& w)
     if (w.d_recv) (void)hipFree(w.d_recv);
     if (w.comm) (void)ncclCommDestroy((ncclComm_t)w.comm);
     if (w.stream) (void)hipStreamDestroy((hipStream_t)w.stream);
+    if (w.listen_fd >= 0) ::close(w.listen_fd);
+    w.listen_fd = -1;
     w.d_send = w.d_recv = w.comm = w.stream = nullptr; w.cap_send = w.cap_recv = 0;
 }
 

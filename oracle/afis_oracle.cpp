@@ -708,9 +708,6 @@ int orc_trace(void* cbp, void* lat, void* rol, int tie_mode, int which, int stag
     return (int)c.size();
 }
 
-// S11: one latent against a list of rolled handles (the body of the OpenMP loop, matcher.cpp:168-190).
-// scores[j] = final or -1 (rolled empty).  Returns 1 if the latent is empty (whole query skipped).
-// threads <= 0: the reference's own setting, 8 threads schedule(static,16).
 // The libm atan2f this oracle (and a CPU build of the reference, matcher.cpp:1516/:1524) evaluates, on the grid of integer
 // coordinate differences: out[(dy + R) * (2R + 1) + (dx + R)] = atan2f((float)dy, (float)dx).  The GPU tests compare the device's
 // atan2 against this table exhaustively over the coordinate range of real templates.
@@ -722,6 +719,9 @@ void orc_atan2f_grid(int R, float* out)
         for (int dx = -R; dx <= R; ++dx) out[(size_t)(dy + R) * W + (dx + R)] = atan2f((float)dy, (float)dx);
 }
 
+// S11: one latent against a list of rolled handles (the body of the OpenMP loop, matcher.cpp:168-190).
+// scores[j] = final or -1 (rolled empty).  Returns 1 if the latent is empty (whole query skipped).
+// threads <= 0: the reference's own setting, 8 threads schedule(static,16).
 int orc_search(void* cb, void* lat, void** rolled, int n, int tie_mode, int threads, float* scores, float* parts /*[n][5] or NULL*/)
 {
     int result = 0;
@@ -733,6 +733,28 @@ int orc_search(void* cb, void* lat, void** rolled, int n, int tie_mode, int thre
         scores[j] = -1.f;
         int rc = pair_score(*(Latent*)lat, *(Rolled*)rolled[j], *(Codebook*)cb, tie_mode, out);
         if (parts) memcpy(parts + (size_t)j * 5, out, sizeof(out));
+        if (rc == 1) { result = 1; continue; }
+        if (rc == 2) continue;
+        scores[j] = out[4];
+    }
+    return result;
+}
+
+// S11 exactly as the reference runs it (matcher.cpp:168-190 / :273-295): the same loop, but every rolled template is re-read from
+// its file and re-parsed for every (latent, rolled) pair (load_FP_template inside the loop, :173 / :278).  threads <= 0: 8.
+int orc_search_files(void* cb, void* lat, const char* const* paths, int n, int tie_mode, int threads, float* scores)
+{
+    int result = 0;
+    int nt = threads <= 0 ? 8 : threads;
+    (void)nt;
+#pragma omp parallel for num_threads(nt) schedule(static, 16)
+    for (int j = 0; j < n; ++j) {
+        float out[5];
+        scores[j] = -1.f;
+        int lrc = 0;
+        Rolled* R = (Rolled*)orc_rolled_load(paths[j], &lrc);
+        int rc = pair_score(*(Latent*)lat, *R, *(Codebook*)cb, tie_mode, out);
+        delete R;
         if (rc == 1) { result = 1; continue; }
         if (rc == 2) continue;
         scores[j] = out[4];

@@ -45,6 +45,8 @@ class Oracle:
         L.orc_search.restype = C.c_int
         L.orc_search.argtypes = [vp, vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int, fp, fp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_search_files.restype = C.c_int
+        L.orc_search_files.argtypes = [vp, vp, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, fp]
         L.orc_atan2f_grid.restype = None; L.orc_atan2f_grid.argtypes = [C.c_int, fp]
 
     # -- handles
@@ -109,6 +111,14 @@ class Oracle:
         if n < 0:
             return None
         return sim[:n], li[:n], ri[:n]
+
+    def search_files(self, cb, lat, paths, tie_mode=1, threads=0):
+        """The reference's own loop: every rolled .dat re-read and re-parsed per pair (matcher.cpp:173, :278)."""
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+        scores = np.empty(n, np.float32)
+        rc = self.lib.orc_search_files(cb, lat, arr, n, tie_mode, threads, scores.ctypes.data_as(C.POINTER(C.c_float)))
+        return rc, scores
 
     def atan2f_grid(self, R):
         out = np.empty((2 * R + 1, 2 * R + 1), np.float32)

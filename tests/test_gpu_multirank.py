@@ -1,0 +1,135 @@
+"""N > 1 end to end on ONE GPU: two ranks share GPU 0, each owns one gallery shard, the exchange step and the merge run for real.
+
+* bench.py --gpus 2 --share-gpu --backend gloo: the Python host path (torch.distributed all_gather of the per-shard top-24 lists).
+* match with WORLD_SIZE=2 and AFIS_EXCHANGE=tcp: the C++ host path — shard planning, the padded score-column gather of -ldir, the
+  top-24 merge and the correspondence-file ownership of -l — with the TCP gather standing in for RCCL (two ranks cannot share a GPU
+  under RCCL).  RCCL stays the production exchange; on a 1-GPU box it is exercised with a communicator of one rank
+  (test_cli_exchange_path_single_rank).
+Rank lists / files must equal the single-process run bit for bit."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = importlib.import_module("msu-latentafis_amd.host.templates")
+S = importlib.import_module("msu-latentafis_amd.host.synth")
+M = importlib.import_module("msu-latentafis_amd.host.matcher")
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_bench_two_ranks_share_one_gpu(tmp_path):
+    common = ["--gallery", "3000", "--queries", "6", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-ranks", str(tmp_path / "one.npz")],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo",
+                          *common, "--dump-ranks", str(tmp_path / "two.npz")], capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    import json
+    j2 = json.loads(two.stdout.strip().splitlines()[-1])
+    assert j2["n_gpus"] == 2 and j2["rank1_hits"] == "6/6" and j2["config"]["parallelism"] == "gallery-shard x2"
+    a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "two.npz")
+    assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["score"], b["score"])
+
+
+def _run_match(exe, args, cwd, world=1, extra_env=None, timeout=300):
+    """Start `world` ranks of match on GPU 0; returns [(returncode, stdout, stderr)] in rank order."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        if world > 1:
+            env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       AFIS_EXCHANGE="tcp", AFIS_EXCHANGE_TIMEOUT_S="60")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([exe, *args, "-d", "0"], cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    out = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        out.append((p.returncode, o, e))
+    return out
+
+
+@pytest.fixture(scope="module")
+def match_case(tmp_path_factory, codebook_bytes):
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(M.LIB_PATH), "match"], check=True)
+    cb = T.Codebook.from_bytes(codebook_bytes)
+    lats, gal = cases.small_set(cb, seed=5, n_lat=3, n_gal=21)
+    d = tmp_path_factory.mktemp("mr")
+    (d / "work").mkdir(); (d / "gal").mkdir(); (d / "lat").mkdir()
+    (d / "cb.dat").write_bytes(codebook_bytes)
+    for j, g in enumerate(gal):
+        (d / "gal" / f"R{j:03d}.dat").write_bytes(T.write_rolled(g))
+    (d / "gal" / "R_empty.dat").write_bytes(b"")
+    for i, L in enumerate(lats):
+        (d / "lat" / f"L{i}.dat").write_bytes(T.write_latent(L))
+    return exe, d
+
+
+def _files(path):
+    return {f: open(os.path.join(path, f), "rb").read() for f in sorted(os.listdir(path))}
+
+
+def test_match_two_ranks_equal_one_rank(match_case):
+    exe, d = match_case
+    for mode, extra in (("ldir", ["-ldir", str(d / "lat")]), ("l", ["-l", str(d / "lat" / "L0.dat")])):
+        outs = {}
+        for world in (1, 2):
+            sd = d / f"out_{mode}_{world}"
+            sd.mkdir()
+            res = _run_match(exe, [*extra, "-g", str(d / "gal"), "-s", str(sd) + "/", "-c", str(d / "cb.dat")], d / "work", world)
+            for rc, o, e in res:
+                assert rc == 0, (mode, world, e[-1500:])
+            if world == 2:
+                assert res[1][1] == ""                                   # rank 1 is silent on stdout; rank 0 speaks for the job
+                assert "Gallery size: 22" in res[0][1]
+            outs[world] = _files(sd)
+        assert set(outs[1]) == set(outs[2]) and len(outs[1]) >= (3 if mode == "ldir" else 2), (mode, sorted(outs[1]), sorted(outs[2]))
+        for f in outs[1]:
+            assert outs[1][f] == outs[2][f], (mode, f)
+        if mode == "l":
+            assert any(f.startswith("corrL0_") and len(outs[1][f]) > 0 for f in outs[1])      # correspondence files came from both shards' owners
+
+
+def test_match_rank_failure_stops_the_whole_job(match_case, tmp_path):
+    """One rank's shard holds a rolled .dat the C ABI rejects (minutiae descriptor length 95): that rank fails in load_gallery,
+    the agreement point makes BOTH ranks leave with a non-zero status instead of one waiting in the collective for ever."""
+    exe, d = match_case
+    import shutil
+    g2 = tmp_path / "gal"
+    shutil.copytree(d / "gal", g2)
+    rng = np.random.default_rng(3)
+    bad = T.FPTemplate(minu=[T.MinutiaeTemplate(np.arange(5, dtype=np.int16), np.arange(5, dtype=np.int16), np.zeros(5, np.float32),
+                                                rng.standard_normal((5, 95)).astype(np.float32))], tex=[])
+    files = sorted(os.listdir(g2))
+    # directory order is what the ranks shard by: overwrite EVERY file of the second half so the bad shard is rank 1's whatever the order
+    listing = subprocess.run([exe, "-ldir", str(d / "lat"), "-g", str(g2), "-s", str(tmp_path / "o0") + "/", "-c", str(d / "cb.dat"), "-d", "0"],
+                             cwd=d / "work", capture_output=True, text=True, timeout=300)
+    assert listing.returncode == 0
+    order = [l.split('"')[1] for l in listing.stdout.splitlines() if l.startswith("rolled template file")]
+    assert len(order) == len(files)
+    open(order[-1], "wb").write(T.write_rolled(bad))                    # the last template of the listing: rank 1's shard
+    (tmp_path / "o2").mkdir()
+    res = _run_match(exe, ["-ldir", str(d / "lat"), "-g", str(g2), "-s", str(tmp_path / "o2") + "/", "-c", str(d / "cb.dat")], d / "work", 2, timeout=120)
+    assert res[0][0] != 0 and res[1][0] != 0, res
+    assert "des_len must be 96" in res[1][2] and "another rank failed" in res[0][2], (res[0][2][-500:], res[1][2][-500:])

@@ -178,9 +178,9 @@ def test_cli_token_rules_pinned_by_reference_argparser():
     except (FileNotFoundError, OSError, AttributeError):
         pytest.skip("oracle/_ref/libafis_ref.so not built with argparser.h (needs /root/reference)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match")
+    exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match_selftest")
     if not os.path.exists(exe):
-        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "match"], check=True)
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "match_selftest"], check=True)
     lines = [["-l", "a.dat", "-g", "gal/", "-s", "out/", "-c", "cb.dat"], ["-g", "gal", "-l"], ["-l", "-g", "x"], ["-s", "1", "-s", "2"],
              [], ["-ldir", "d", "-l", "f"], ["-c"], ["--c", "x", "-c", "y"]]
     for toks in lines:
@@ -201,9 +201,9 @@ def test_config_fallback_pinned_by_reference_json_library(tmp_path):
     except (FileNotFoundError, OSError, AttributeError):
         pytest.skip("oracle/_ref/libafis_ref.so not built with json.hpp (needs /root/reference)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match")
+    exe = os.path.join(root, "msu-latentafis_amd", "csrc", "match_selftest")
     if not os.path.exists(exe):
-        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "match"], check=True)
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe), "match_selftest"], check=True)
     keys = ["CodebookPath", "ScorePath", "GalleryTemplateDirectory", "LatentTemplateDirectory", "MinuPath", "Absent"]
     texts = [
         '{\n\t"CodebookPath": "/home/x/codebook.dat",\n\t"ScorePath": "/home/x/scores",\n\n\t"GalleryTemplateDirectory": "/g",\n'

@@ -84,9 +84,9 @@ def test_gather_topk_world2_gloo():
 def _match_exe():
     import subprocess
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "msu-latentafis_amd", "csrc")
-    exe = os.path.join(csrc, "match")
+    exe = os.path.join(csrc, "match_selftest")
     if not os.path.exists(exe):
-        subprocess.run(["make", "-s", "-C", csrc, "match"], check=True)
+        subprocess.run(["make", "-s", "-C", csrc, "match_selftest"], check=True)
     return exe
 
 
@@ -118,3 +118,20 @@ def test_cpp_rendezvous_three_ranks():
     assert all(p.returncode == 0 for p in procs), outs
     ids = {o[0].strip().split(" id ")[1] for o in outs}
     assert len(ids) == 1 and sorted(o[0].split()[1] for o in outs) == ["0", "1", "2"]
+
+
+def test_cpp_tcp_all_gather_and_agreement_three_ranks():
+    """AFIS_EXCHANGE=tcp: the gather-and-return through rank 0 that lets `match` run N > 1 ranks on one GPU, and the agreement point
+    that stops every rank when one reports a failure (three local processes, three exchanges + one agreement each)."""
+    import subprocess, socket
+    exe = _match_exe()
+    for fail_rank, want in ((0, "agree 0"), (2, "agree 7")):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        env = lambda r: dict(os.environ, RANK=str(r), WORLD_SIZE="3", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port - 1),
+                             AFIS_EXCHANGE_TIMEOUT_S="30")
+        procs = [subprocess.Popen([exe, "-selftest-allgather", "-fail-rank", str(fail_rank)], env=env(r), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in (2, 1, 0)]
+        outs = [p.communicate(timeout=90) for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        assert all(want in o[0] and "gathered ok" in o[0] for o in outs), outs
