@@ -18,7 +18,7 @@ using namespace afis;
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;   // last afis_create failure of THIS thread (there is no context to hang it on)
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;

@@ -14,6 +14,7 @@ namespace {
 
 constexpr int kMaxMinutiae = 2000;   // matcher.cpp:788
 constexpr int kMaxDesLength = 192;   // matcher.cpp:789
+constexpr int kBadDesLength = 8;     // parser return code with no reference counterpart: a descriptor length outside 1..192
 constexpr int kMaxBlkSize = 100;     // matcher.cpp:790
 
 // std::ifstream semantics: a read past the end delivers what is left and every later read delivers nothing.
@@ -50,7 +51,8 @@ int parse_common(Cursor& c, HostTemplate& out, bool rolled)
         m.x.resize(n); m.y.resize(n); m.ori.resize(n);
         c.read(m.x.data(), 2 * (size_t)n); c.read(m.y.data(), 2 * (size_t)n); c.read(m.ori.data(), 4 * (size_t)n);
         const int dl = c.get<int16_t>();
-        if (c.fail || dl <= 0 || dl > kMaxDesLength) break;
+        if (c.fail) break;
+        if (dl <= 0 || dl > kMaxDesLength) return kBadDesLength;   // the reference has no check here (it overruns a stack buffer): stop, keep what was parsed
         m.des_len = dl; m.des.assign((size_t)n * dl, 0.f);
         c.read(m.des.data(), 4 * (size_t)n * dl);
         out.minu.push_back(std::move(m));
@@ -66,7 +68,8 @@ int parse_common(Cursor& c, HostTemplate& out, bool rolled)
         t.x.resize(n); t.y.resize(n); t.ori.resize(n);
         c.read(t.x.data(), 2 * (size_t)n); c.read(t.y.data(), 2 * (size_t)n); c.read(t.ori.data(), 4 * (size_t)n);
         const int dl = c.get<int16_t>();
-        if (c.fail || dl <= 0 || dl > kMaxDesLength) break;
+        if (c.fail) break;
+        if (dl <= 0 || dl > kMaxDesLength) return kBadDesLength;   // as above: never parse texture templates from a misaligned cursor
         t.des_len = dl;
         if (rolled) {
             // the reference reads n*des_len floats here (a 4x over-read that runs into EOF, :975) and keeps the
@@ -224,8 +227,11 @@ bool check_header(const Mapped& m, const std::string& path, GalHeader& h, size_t
 }
 }  // namespace
 
-void gallery_append_template(HostGallery& g, const HostTemplate& t)
+bool gallery_append_template(HostGallery& g, const HostTemplate& t)
 {
+    // the staged arrays are fixed-width (96 floats / 16 code bytes per point): refuse anything else instead of reading past a vector
+    if (!t.minu.empty() && (t.minu[0].des_len != 96 || t.minu[0].des.size() != (size_t)t.minu[0].n() * 96)) return false;
+    if (!t.tex.empty() && (t.tex[0].des_len != 16 || t.tex[0].codes.size() < (size_t)t.tex[0].n() * 16)) return false;
     if (!t.minu.empty()) {
         const HostMinutiae& m = t.minu[0];
         g.mx.insert(g.mx.end(), m.x.begin(), m.x.end()); g.my.insert(g.my.end(), m.y.begin(), m.y.end());
@@ -240,6 +246,7 @@ void gallery_append_template(HostGallery& g, const HostTemplate& t)
     }
     g.tex_off.push_back((int64_t)g.tx.size());
     g.empty.push_back(t.minu.empty() && t.tex.empty() ? 1 : 0);
+    return true;
 }
 
 bool write_gallery_container(const std::string& path, const HostGallery& g, const std::vector<std::string>& names, std::string& err)

@@ -56,7 +56,7 @@ struct HostGallery {
 //       minu_des f32[][96] | tex_x i16[] | tex_y i16[] | tex_ori f32[] | tex_codes u8[][16] | name_off i64[G+1] | names char[]
 // names[i] = the path of the .dat file template i came from (what the score files print).
 // appends one parsed rolled template the way afis_gallery_add_dat does: minutiae template 0, texture template 0 clamped to 1000
-void gallery_append_template(HostGallery& g, const HostTemplate& t);
+bool gallery_append_template(HostGallery& g, const HostTemplate& t);   // false: descriptor / code width is not 96 / 16
 struct GalleryFileInfo { int64_t G = 0, n_minu = 0, n_tex = 0; };
 bool write_gallery_container(const std::string& path, const HostGallery& g, const std::vector<std::string>& names, std::string& err);
 bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std::string& err);

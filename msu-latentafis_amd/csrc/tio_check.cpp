@@ -31,7 +31,8 @@ int main(int argc, char** argv)
             HostTemplate t;
             if (!read_file(argv[i], fb)) { printf("rc=io\n"); return 1; }
             if (parse_rolled_dat(fb.data(), fb.size(), t) < 0) { t.minu.clear(); t.tex.clear(); }
-            gallery_append_template(g, t); names.push_back(argv[i]);
+            if (!gallery_append_template(g, t)) { fprintf(stderr, "%s: descriptor width is not 96 / 16\n", argv[i]); return 3; }
+            names.push_back(argv[i]);
         }
         std::string err;
         if (!write_gallery_container(argv[2], g, names, err)) { printf("error=%s\n", err.c_str()); return 1; }

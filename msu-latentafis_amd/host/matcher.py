@@ -344,10 +344,14 @@ class Matcher:
         """matcher.cpp:216-337: rank list of the top 24 as `<rank>"<path>",<score>` under a `filename,score` header."""
         with open(latent_template_file, "rb") as f:
             buf = f.read()
+        stem = os.path.splitext(os.path.basename(latent_template_file))[0]
+        _, parsed = read_latent(buf)
+        if not parsed.minu and not parsed.tex:                # matcher.cpp:260-268: a latent without any template gets a score file holding `0`
+            with open(score_path + stem + ".csv", "w") as out:
+                out.write("0\n")
         r = self.search_dat([buf], k=min(top, max(1, self.gallery_size)))
         if r["status"][0] == 1:
             return 1
-        stem = os.path.splitext(os.path.basename(latent_template_file))[0]
         k = min(top, self.gallery_size)
         idx = [int(r["topk_idx"][0, j]) for j in range(k)]
         with open(score_path + stem + ".csv", "w") as out:
@@ -375,9 +379,14 @@ class Matcher:
         bufs = [open(f, "rb").read() for f in files]
         r = self.search_dat(bufs, k=0)
         for i, f in enumerate(files):
+            stem = os.path.splitext(os.path.basename(f))[0]
+            _, parsed = read_latent(bufs[i])
+            if not parsed.minu and not parsed.tex:            # matcher.cpp:153-163: `0` and on to the next latent
+                with open(score_path + stem + ".csv", "w") as out:
+                    out.write("0\n")
+                continue
             if r["status"][i] == 1:
                 continue
-            stem = os.path.splitext(os.path.basename(f))[0]
             with open(score_path + stem + ".csv", "w") as out:
                 for j, gf in enumerate(self.gallery_files):
                     out.write(f'"{gf}",{r["scores"][i, j]:.3f}\n')

@@ -26,6 +26,7 @@ import numpy as np
 
 MAX_NROF_MINUTIAE = 2000   # matcher.cpp:788 / descriptor_PQ.py:84
 MAX_DES_LENGTH = 192       # matcher.cpp:789
+BAD_DES_LENGTH = 8         # parser return code without a reference counterpart
 DESCRIPTOR_NORM = 1.73     # extraction/descriptor_DR.py:150-152 rescales every descriptor to this L2 norm
 
 
@@ -199,7 +200,8 @@ class _Reader:
 
 def _read(buf: bytes, rolled: bool) -> (int, FPTemplate):
     """Mirror of Matcher::load_FP_template (matcher.cpp:785-884 latent, :886-983 rolled).
-    Returns (rc, template); rc as the reference: 0 ok, 1 empty, 2 too many minutiae, -1 texture too large."""
+    Returns (rc, template); rc as the reference: 0 ok, 1 empty, 2 too many minutiae, -1 texture too large; 8 (no reference
+    counterpart) = a descriptor length outside 1..192, parsing stopped there."""
     t = FPTemplate()
     if (rolled and len(buf) <= 10) or (not rolled and len(buf) <= 0):
         return 1, t
@@ -217,8 +219,10 @@ def _read(buf: bytes, rolled: bool) -> (int, FPTemplate):
             return 2, t
         x = r.array("<i2", n); y = r.array("<i2", n); ori = r.array("<f4", n)
         dl = r.scalar("<h")
-        if r.fail or dl <= 0 or dl > MAX_DES_LENGTH:
+        if r.fail:
             break
+        if dl <= 0 or dl > MAX_DES_LENGTH:
+            return BAD_DES_LENGTH, t      # no reference counterpart (it overruns a stack buffer): stop, keep what was parsed
         des = r.array("<f4", n * dl).reshape(n, dl)
         t.minu.append(MinutiaeTemplate(x, y, ori, des))
     ntt = r.scalar("<B")
@@ -232,8 +236,10 @@ def _read(buf: bytes, rolled: bool) -> (int, FPTemplate):
             return -1, t
         x = r.array("<i2", n); y = r.array("<i2", n); ori = r.array("<f4", n)
         dl = r.scalar("<h")
-        if r.fail or dl <= 0 or dl > MAX_DES_LENGTH:
+        if r.fail:
             break
+        if dl <= 0 or dl > MAX_DES_LENGTH:
+            return BAD_DES_LENGTH, t
         if rolled:
             # the reference reads n*dl floats (4x over-read to EOF, matcher.cpp:975) and keeps n*dl bytes
             raw = r.array("u1", n * dl * 4)

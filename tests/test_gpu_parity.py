@@ -453,6 +453,7 @@ def test_python_drivers_equal_cli(codebook_bytes, cb, small, tmp_path):
     (tmp_path / "gal" / "R_empty.dat").write_bytes(b"")
     for i, L in enumerate(lats[:2]):
         (tmp_path / "lat" / f"L{i}.dat").write_bytes(T.write_latent(L))
+    (tmp_path / "lat" / "Lnone.dat").write_bytes(T.write_latent(T.FPTemplate()))       # a latent without any template: score file `0` (matcher.cpp:153-163)
     cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
     box = str(tmp_path / "g.afisgal")
     common = ["-g", str(tmp_path / "gal"), "-c", str(cbp), "-s", str(tmp_path / "cli") + "/"]
@@ -466,6 +467,10 @@ def test_python_drivers_equal_cli(codebook_bytes, cb, small, tmp_path):
         files = m.load_gallery_dir(src)
         assert len(files) == 10
         assert m.List2List_matching(str(tmp_path / "lat"), str(tmp_path / out) + "/") == 0
+        assert (tmp_path / out / "Lnone.csv").read_text() == "0\n" == cli["Lnone.csv"]
+        os.remove(tmp_path / out / "Lnone.csv")
+        assert m.One2List_matching(str(tmp_path / "lat" / "Lnone.dat"), str(tmp_path / out) + "/") == 1        # :260-268 then :296-300
+        assert (tmp_path / out / "Lnone.csv").read_text() == "0\n"
         l0 = (tmp_path / out / "L0.csv").read_text()
         assert sorted(l0.splitlines()) == sorted(cli["L0.csv"].splitlines())          # directory order may differ between the two listings
         assert m.One2List_matching(str(tmp_path / "lat" / "L1.dat"), str(tmp_path / out) + "/") == 0

@@ -102,6 +102,27 @@ def test_reader_edge_cases(cb, tio, tmp_path):
     assert rc == 0 and len(t.tex) == 1 and np.array_equal(t.tex[0].codes[:-7], gal[1].tex[0].codes[:-7]) and not t.tex[0].codes[-1].any()
     # texture counts above 1000 are legal on disk (clamped at match time, matcher.cpp:544-547)
     assert T.MAX_NROF_MINUTIAE == 2000
+    # a descriptor length outside 1..192 (the reference overruns a stack buffer there): both parsers stop with code 8 and parse NOTHING
+    # from the misaligned bytes that follow; what came before is kept
+    ok = bytearray(T.write_rolled(gal[0]))
+    dl_off = 33 + 2 + gal[0].minu[0].n * (2 + 2 + 4)
+    assert int.from_bytes(ok[dl_off:dl_off + 2], "little") == 96
+    bad = bytearray(ok); bad[dl_off:dl_off + 2] = (300).to_bytes(2, "little")
+    rc, t = T.read_rolled(bytes(bad))
+    assert rc == T.BAD_DES_LENGTH == 8 and t.minu == [] and t.tex == []
+    p = tmp_path / "baddl.dat"; p.write_bytes(bytes(bad))
+    out = subprocess.run([tio, "rolled", str(p)], capture_output=True, text=True).stdout
+    assert out.startswith("rc=8") and "n_minu=0 n_tex=0" in out.splitlines()[0], out
+    tex_dl = off + 2 + gal[0].tex[0].n * (2 + 2 + 4)
+    assert int.from_bytes(ok[tex_dl:tex_dl + 2], "little") == 16
+    bad = bytearray(ok); bad[tex_dl:tex_dl + 2] = (0).to_bytes(2, "little")
+    rc, t = T.read_rolled(bytes(bad))
+    assert rc == 8 and len(t.minu) == 1 and t.tex == []
+    # a gallery container only takes 96-float descriptors / 16-byte codes: a legal-but-different width is refused, not over-read
+    narrow = T.FPTemplate(minu=[T.MinutiaeTemplate(gal[0].minu[0].x, gal[0].minu[0].y, gal[0].minu[0].ori, gal[0].minu[0].des[:, :12].copy())], tex=[])
+    p = tmp_path / "narrow.dat"; p.write_bytes(T.write_rolled(narrow))
+    r = subprocess.run([tio, "gallery-pack", str(tmp_path / "x.afisgal"), str(p)], capture_output=True, text=True)
+    assert r.returncode == 3 and "descriptor width" in r.stderr
 
 
 def test_header_only_template_when_no_minutiae(cb):
