@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--query-batch", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--lut-dtype", type=int, default=32, help="32 = exact fp32 LUT (the headline path); 16 = opt-in 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="test mode: every rank uses GPU 0 (validates the N>1 path on a 1-GPU box)")
@@ -149,6 +150,7 @@ def main():
     if a.variant >= 0: m.set_option("adc_variant", a.variant)
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)
+    if a.lut_dtype != 32: m.set_option("lut_dtype", a.lut_dtype)
     t_up = time.perf_counter()
     m.gallery_add_packed(gal)
     m.gallery_commit(lo)
@@ -213,12 +215,12 @@ def main():
         out = {
             "metric": "latent queries/sec vs 100k rolled gallery", "value": round(value, 4), "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if a.lut_dtype == 32 else "u16 fixed-point LUT + f32 (tolerance path, NOT the bit-exact headline configuration)", "data": "synthetic",
             "config": {"workload": f"batch {Q} latents vs {G}-template synthetic rolled gallery "
-                                   f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists", "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
+                                   f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists" + ("" if a.lut_dtype == 32 else "; 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4] kernel on one GPU)"), "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
                        "adc_variant": a.variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
-            "roofline": {"bound": "hbm", "kernel": "k_adc_rowmax", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_adc_rowmax" if a.lut_dtype == 32 else "k_adc_rowmin_q (lut build included in its time)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "achieved_is": "ALGORITHMIC bytes (24 B per rolled texture point per query of the launch) / kernel time; the kernel reads each code byte from HBM once per launch and is bound by LDS/VALU issue, see lds_frac",
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),

@@ -187,7 +187,11 @@ int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
  * kept as references; 6 = conflict-free lane classes with 512-thread workgroups, 7 = the same with 1024 [default]; all
  * bit-identical; 4 and 5 were earlier forms of 6/7 and are rejected), "query_batch" (latents per
  * launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel),
- * "rowmax_budget_mb".  Returns AFIS_EINVAL for unknown names. */
+ * "rowmax_budget_mb", and "lut_dtype": 32 (default) = the exact fp32 look-up table, every result bit-identical to the reference
+ * arithmetic; 16 = opt-in TOLERANCE path: the per-query table quantised to 16-bit fixed point (16 latent rows per 128 KB LDS tile,
+ * integer sums; BASELINE.json configs[4]).  Its only error is the quantisation (|d sim| <= 16 steps / 2, about 4e-3), so row maxima
+ * and arg-maxima can differ from the exact path where two candidates are closer than that; scores are NOT bit-exact.
+ * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
 
 /* Parity-test taps (stage intermediates; not needed by a production caller). */

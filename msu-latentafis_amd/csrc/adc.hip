@@ -485,4 +485,296 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
     return hipGetLastError();
 }
 
+// ===============================================================================================================
+// Opt-in tolerance path (BASELINE.json configs[4], "fp16 LUT path"): the LUT quantised to 16-bit fixed point.
+//   lut'[i][m][c] = lut[i][m][c] - min_c lut[i][m][.]  >= 0,   Q = round(lut' / q_i) in [0, 2047],   q_i = max_m range(i, m) / 2047
+//   sim(i, j) ~= (6 - sum_m min_m) - q_i * sum_m Q[i][m][code_jm]
+// Sixteen rows fit a 128 KB tile (two 16-byte reads return one (m, code) entry of all 16 rows), the 16 sub-quantizer terms are
+// added EXACTLY as packed 15-bit integers (16 x 2047 < 2^15: v_pk_add_u16, no rounding, any order), and the per-row minimum of
+// the integer sum — i.e. the maximum similarity — and its first point are tracked with packed 16-bit min / sign-mask / bfi.  Per
+// look-up this halves the LDS bytes and takes 0.7 x the VALU work of the fp32 kernel.  The ONLY error is the quantisation:
+// |sim_q - sim| <= 16 * q_i / 2 (about 4e-3; 6e-4 rms), so (max, argmax) can differ from the exact kernel's where the two best
+// points of a row are closer than that.  NOT bit-exact: afis_set_option("lut_dtype", 16) selects it, the default stays fp32.
+// Fixed-point rather than fp16 because an fp16 accumulation would add its own rounding at every one of the 16 steps.
+//   Tile layout (bytes): (m >> 3) << 16 | code << 8 | (m & 7) << 5 | half << 4, 16 bytes = rows 8*half .. 8*half+7 as u16.
+//   Conflict-free by construction, as k_adc_rowmax_cf: the 16 lanes a ds_read_b128 services together are 16 classes
+//   a = lane & 15 -> (pc = a >> 1, pr = a & 1); at step s a lane reads m = 8*mhi + ((s + pc) & 7), half pr first then pr ^ 1, so
+//   the 16 lanes always touch the 16 different 16-byte slots of their 256-byte code rows.  Integer sums are order-independent,
+//   so no half-period shift is needed; the per-lane code bytes come pre-rotated (k_codes_q) so that step s uses byte s.
+// ===============================================================================================================
+constexpr int kQRows = 16;
+constexpr int kQTileVec = 131072 / 16;            // uint4 per tile
+constexpr int kQMax = 2047;
+
+// per (latent texture row, m): min and range over the 256 codewords.  grid = rows, block = 256 (one thread per codeword)
+__global__ __launch_bounds__(256) void k_lutq_stats(QueryDev q, const float* __restrict__ codewords, float* __restrict__ row_min, float* __restrict__ row_rng)
+{
+    __shared__ float s_lo[4], s_hi[4];
+    const int row = blockIdx.x, k = threadIdx.x, lane = k & 63, wave = k >> 6;
+    for (int m = 0; m < kM; ++m) {
+        float des6[kDsub], cw6[kDsub];
+#pragma unroll
+        for (int d = 0; d < kDsub; ++d) { des6[d] = q.lt_des[(size_t)row * kDes + m * kDsub + d]; cw6[d] = codewords[(m * kK + k) * kDsub + d]; }
+        const float v = lut_entry(des6, cw6);
+        float lo = v, hi = v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+        __syncthreads();
+        if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+        __syncthreads();
+        if (k == 0) {
+            const float l = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])), h = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+            row_min[(size_t)row * kM + m] = l; row_rng[(size_t)row * kM + m] = h - l;
+        }
+    }
+}
+
+// tiles of 16 rows; grid = n_tiles16 * 16 (one block per (tile, m)), block = 256 (codeword).  rowc[row] = (6 - sum_m min_m, q_row)
+__global__ __launch_bounds__(256) void k_lutq_build(QueryDev q, const float* __restrict__ codewords, const float* __restrict__ row_min,
+                                                    const float* __restrict__ row_rng, uint4* __restrict__ tiles, float2* __restrict__ rowc)
+{
+    const int tile = blockIdx.x >> 4, m = blockIdx.x & 15, k = threadIdx.x;
+    int qi = 0;
+    while (qi + 1 < q.nq && tile >= q.tile16_off[qi + 1]) ++qi;
+    const int row0 = (tile - q.tile16_off[qi]) * kQRows;
+    const int base = q.lt_off[qi], n = q.lt_off[qi + 1] - base;
+    float cw6[kDsub];
+#pragma unroll
+    for (int d = 0; d < kDsub; ++d) cw6[d] = codewords[(m * kK + k) * kDsub + d];
+    unsigned short qv[kQRows];
+#pragma unroll
+    for (int r = 0; r < kQRows; ++r) {
+        int row = row0 + r; if (row >= n) row = n - 1;       // padding rows duplicate the last row; never read back
+        const size_t gr = (size_t)(base + row);
+        float des6[kDsub];
+#pragma unroll
+        for (int d = 0; d < kDsub; ++d) des6[d] = q.lt_des[gr * kDes + m * kDsub + d];
+        float rng = 0.f, msum = 0.f;
+        for (int mm = 0; mm < kM; ++mm) { rng = fmaxf(rng, row_rng[gr * kM + mm]); msum += row_min[gr * kM + mm]; }
+        const float qstep = fmaxf(rng, 1e-30f) / (float)kQMax;
+        const float v = lut_entry(des6, cw6) - row_min[gr * kM + m];
+        int iq = (int)floorf(v / qstep + 0.5f);
+        iq = iq < 0 ? 0 : (iq > kQMax ? kQMax : iq);
+        qv[r] = (unsigned short)iq;
+        if (m == 0 && k == 0 && row0 + r < n) rowc[gr] = make_float2(6.0f - msum, qstep);
+    }
+    uint4* t = tiles + (size_t)tile * kQTileVec + (((m >> 3) << 16 | k << 8 | (m & 7) << 5) >> 4);
+    auto pack = [&](int r) { return (uint32_t)qv[r] | ((uint32_t)qv[r + 1] << 16); };
+    t[0] = make_uint4(pack(0), pack(2), pack(4), pack(6));
+    t[1] = make_uint4(pack(8), pack(10), pack(12), pack(14));
+}
+
+// Lane-ordered code stream of the quantised kernel: template t owns ceil(n/64) blocks of 64 entries starting at block q_blk[t];
+// entry (block k, lane l) = the 16 code bytes of point 64k + l with each 8-byte half rotated by pc = (l & 15) >> 1:
+// byte 8*mhi + s = code[8*mhi + ((s + pc) & 7)].  Entries without a point are zero.  grid = G, block = 64.
+__global__ __launch_bounds__(64) void k_codes_q(GalleryDev g, const int32_t* __restrict__ q_blk, uint4* __restrict__ out)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int p0 = g.tex_off[t], n = g.tex_off[t + 1] - p0;
+    const int pc = (lane & 15) >> 1;
+    for (int k = 0; k * 64 < n; ++k) {
+        const int p = k * 64 + lane;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (p < n) {
+            const uint4 c = g.tex_codes[p0 + p];
+            const unsigned long long lo = (unsigned long long)c.x | ((unsigned long long)c.y << 32), hi = (unsigned long long)c.z | ((unsigned long long)c.w << 32);
+            const int sh = 8 * pc;
+            const unsigned long long rl = sh ? (lo >> sh) | (lo << (64 - sh)) : lo, rh = sh ? (hi >> sh) | (hi << (64 - sh)) : hi;
+            o = make_uint4((uint32_t)rl, (uint32_t)(rl >> 32), (uint32_t)rh, (uint32_t)(rh >> 32));
+        }
+        out[((size_t)q_blk[t] + k) * 64 + lane] = o;
+    }
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+
+template <int kAdcThreads>
+__global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, GalleryDev g, const uint4* __restrict__ codes_q, const int32_t* __restrict__ q_blk,
+                                                               const uint4* __restrict__ lutq_tiles, const float2* __restrict__ rowc,
+                                                               int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
+{
+    __shared__ uint4 s_lut[kQTileVec];                        // 128 KB
+    __shared__ int s_next;
+    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;      // XCD-aware: the tiles of one gallery chunk run back to back on one XCD
+    const int tile = seq % q.n_tiles16;
+    const int chunk_id = (seq / q.n_tiles16) * 8 + xcd;
+    if (chunk_id >= n_chunks) return;
+    int qi = 0;
+    while (qi + 1 < q.nq && tile >= q.tile16_off[qi + 1]) ++qi;
+    const int row0 = (tile - q.tile16_off[qi]) * kQRows;
+    const int lt0 = q.lt_off[qi], n_lt = q.lt_off[qi + 1] - lt0;
+    {
+        const uint4* src = lutq_tiles + (size_t)tile * kQTileVec;
+        for (int i = threadIdx.x; i < kQTileVec; i += kAdcThreads) s_lut[i] = src[i];
+        if (threadIdx.x == 0) s_next = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int g_lo = chunk_id * chunk, g_hi = min(g.G, g_lo + chunk);
+    const int a = lane & 15, pr = a & 1, pc = a >> 1;
+    uint32_t so[8];                                           // byte 0: slot << 4 of step s (first read), byte 3: 1
+#pragma unroll
+    for (int s = 0; s < 8; ++s) so[s] = 0x01000000u | (uint32_t)(((((s + pc) & 7) << 1) | pr) << 4);
+    const char* lut_b = reinterpret_cast<const char*>(s_lut);
+    auto claim = [&]() -> int {
+        int c = 0;
+        if (lane == 0) c = atomicAdd(&s_next, 1);
+        return g_lo + __builtin_amdgcn_readfirstlane(c);
+    };
+    auto stream_of = [&](int gidx, int& n, int& blk0) {
+        n = 0; blk0 = 0;
+        if (gidx < g_hi) { n = g.tex_off[gidx + 1] - g.tex_off[gidx]; blk0 = q_blk[gidx]; }
+    };
+    int gi = claim(), n_pts, blk0;
+    stream_of(gi, n_pts, blk0);
+    uint4 cw_next = make_uint4(0, 0, 0, 0);
+    if (n_pts > 0) cw_next = codes_q[(size_t)blk0 * 64 + lane];
+    while (gi < g_hi) {
+        const int gi_cur = gi, n_cur = n_pts, n_blocks = (n_pts + 63) >> 6;
+        const uint4* cfp = codes_q + ((size_t)blk0 * 64 + lane);
+        gi = claim();
+        stream_of(gi, n_pts, blk0);                           // the next template: its offsets and first entry are fetched early
+        const uint4* cfp_next = codes_q + ((size_t)blk0 * 64 + lane);
+        if (n_cur <= 0) { if (n_pts > 0) cw_next = cfp_next[0]; continue; }
+        u16x2 best[8]; uint32_t bidx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { best[k] = as_u16x2(0x7fff7fffu); bidx[k] = 0u; }
+        // one block = 64 points x 16 rows.  Only the LAST block of a template can hold lanes without a point: their sums are forced to
+        // 0x7fff (never a minimum) there; every other block runs without any validity test, and nothing in a block is conditional, so
+        // the compiler keeps reads and adds interleaved as written.
+        auto block = [&](int blk, auto last_tag) {
+            constexpr bool kLast = decltype(last_tag)::value;
+            const uint4 cw = cw_next;
+            if (!kLast) cw_next = cfp[(size_t)(blk + 1) * 64];
+            else if (n_pts > 0) cw_next = cfp_next[0];
+            const uint32_t w[4] = {cw.x, cw.y, cw.z, cw.w};
+            u16x2 acc[8];
+            // Two steps = four 16-byte reads per group; the NEXT group's reads are issued before the current group's sixteen packed
+            // adds, so eight reads are in flight while the adds run.  Each group ends with an empty asm that "modifies" the sums under
+            // a memory clobber: the adds cannot sink below it and later reads cannot rise above it (left alone the compiler puts all
+            // 32 reads first — 128 result registers — and every add behind them).
+            auto reads = [&](int sg, uint4 (&v)[2][2]) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int st = 2 * sg + u, mhi = st >> 3, s2 = st & 7;
+                    // address bytes: [slot << 4 (so byte 0)] [code (w byte s & 3)] [mhi (so byte 3, or 0)] [0]
+                    const uint32_t sel = 0x0c000004u | (uint32_t)((s2 & 3) << 8) | (mhi ? 0x00070000u : 0x000c0000u);
+                    const uint32_t a0 = __builtin_amdgcn_perm(so[s2], w[2 * mhi + (s2 >> 2)], sel);
+                    const uint32_t a1 = a0 ^ 16u;                                  // the other row half
+                    v[u][0] = *reinterpret_cast<const uint4*>(lut_b + a0);
+                    v[u][1] = *reinterpret_cast<const uint4*>(lut_b + a1);
+                }
+            };
+            auto adds = [&](bool first, const uint4 (&v)[2][2]) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint4 v0 = v[u][0], v1 = v[u][1];
+                    if (first && u == 0) {
+                        acc[0] = as_u16x2(v0.x); acc[1] = as_u16x2(v0.y); acc[2] = as_u16x2(v0.z); acc[3] = as_u16x2(v0.w);
+                        acc[4] = as_u16x2(v1.x); acc[5] = as_u16x2(v1.y); acc[6] = as_u16x2(v1.z); acc[7] = as_u16x2(v1.w);
+                    } else {
+                        acc[0] += as_u16x2(v0.x); acc[1] += as_u16x2(v0.y); acc[2] += as_u16x2(v0.z); acc[3] += as_u16x2(v0.w);
+                        acc[4] += as_u16x2(v1.x); acc[5] += as_u16x2(v1.y); acc[6] += as_u16x2(v1.z); acc[7] += as_u16x2(v1.w);
+                    }
+                }
+                uint32_t r0 = as_u32(acc[0]), r1 = as_u32(acc[1]), r2 = as_u32(acc[2]), r3 = as_u32(acc[3]), r4 = as_u32(acc[4]), r5 = as_u32(acc[5]), r6 = as_u32(acc[6]), r7 = as_u32(acc[7]);
+                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) :: "memory");
+                acc[0] = as_u16x2(r0); acc[1] = as_u16x2(r1); acc[2] = as_u16x2(r2); acc[3] = as_u16x2(r3); acc[4] = as_u16x2(r4); acc[5] = as_u16x2(r5); acc[6] = as_u16x2(r6); acc[7] = as_u16x2(r7);
+            };
+            {
+                uint4 va[2][2], vb[2][2];
+                reads(0, va);
+#pragma unroll
+                for (int sg = 0; sg < 8; sg += 2) {
+                    reads(sg + 1, vb);
+                    adds(sg == 0, va);
+                    if (sg + 2 < 8) reads(sg + 2, va);
+                    adds(false, vb);
+                }
+            }
+            {                                                  // first minimum per row: strict improvement only, blocks in ascending order
+                const uint32_t blkpk = (uint32_t)blk * 0x00010001u;
+                const uint32_t inv = (kLast && blk * 64 + lane >= n_cur) ? 0x7fff7fffu : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const u16x2 sum = kLast ? as_u16x2(as_u32(acc[k]) | inv) : acc[k];
+                    const s16x2 d = __builtin_bit_cast(s16x2, sum) - __builtin_bit_cast(s16x2, best[k]);       // both < 2^15: no overflow
+                    const uint32_t m = __builtin_bit_cast(uint32_t, d >> 15);                                   // 0xffff where sum < best
+                    best[k] = __builtin_elementwise_min(best[k], sum);
+                    bidx[k] = (blkpk & m) | (bidx[k] & ~m);
+                }
+            }
+        };
+        for (int blk = 0; blk + 1 < n_blocks; ++blk) block(blk, std::false_type{});
+        block(n_blocks - 1, std::true_type{});
+        // ---- minimum over the 64 lanes: 32-bit keys (sum << 16 | point index) make "smallest sum, then first point" one v_min_u32 ----
+        // physical slots: A[j] (j < 8) = rows 8*pr + j, B[j] = rows 8*(pr^1) + j
+        uint32_t A[8], B[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t ba = as_u32(best[k]), bb = as_u32(best[k + 4]);
+            A[2 * k] = (ba << 16) | ((bidx[k] & 0xffffu) * 64u + (uint32_t)lane);
+            A[2 * k + 1] = (ba & 0xffff0000u) | ((bidx[k] >> 16) * 64u + (uint32_t)lane);
+            B[2 * k] = (bb << 16) | ((bidx[k + 4] & 0xffffu) * 64u + (uint32_t)lane);
+            B[2 * k + 1] = (bb & 0xffff0000u) | ((bidx[k + 4] >> 16) * 64u + (uint32_t)lane);
+        }
+        constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                          // lane ^ 1 holds the same rows in its OTHER slot set
+            const uint32_t oa = (uint32_t)dpp_i<kXor1>((int)B[j]), ob = (uint32_t)dpp_i<kXor1>((int)A[j]);
+            A[j] = min(A[j], oa); B[j] = min(B[j], ob);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            A[j] = min(A[j], (uint32_t)dpp_i<kXor2>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kXor2>((int)B[j]));
+            A[j] = min(A[j], (uint32_t)dpp_i<kRor4>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor4>((int)B[j]));
+            A[j] = min(A[j], (uint32_t)dpp_i<kRor8>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor8>((int)B[j]));
+        }
+        uint32_t mine = 0;                                     // lane r < 16 ends up with row r's key (lanes 0, 16, 32, 48 are pr = 0: A = rows 0..7)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t x = r < 8 ? A[r] : B[r - 8];
+            const uint32_t s0 = __builtin_amdgcn_readlane(x, 0), s1 = __builtin_amdgcn_readlane(x, 16), s2 = __builtin_amdgcn_readlane(x, 32), s3 = __builtin_amdgcn_readlane(x, 48);
+            const uint32_t s = min(min(s0, s1), min(s2, s3));
+            if (lane == r) mine = s;
+        }
+        if (lane < kQRows && row0 + lane < n_lt) {
+            const float2 rc = rowc[lt0 + row0 + lane];
+            const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
+            rm_val[o] = rc.x - rc.y * (float)(mine >> 16);
+            rm_arg[o] = (int32_t)(mine & 0xffffu);
+        }
+    }
+}
+
+hipError_t launch_lutq_build(const QueryDev& q, int n_rows_total, const float* codewords, float* row_min, float* row_rng, void* tiles, void* rowc, hipStream_t stream)
+{
+    if (q.n_tiles16 <= 0 || n_rows_total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_lutq_stats, dim3(n_rows_total), dim3(256), 0, stream, q, codewords, row_min, row_rng);
+    hipLaunchKernelGGL(k_lutq_build, dim3(q.n_tiles16 * 16), dim3(256), 0, stream, q, codewords, row_min, row_rng, (uint4*)tiles, (float2*)rowc);
+    return hipGetLastError();
+}
+
+hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, hipStream_t stream)
+{
+    if (g.G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_codes_q, dim3(g.G), dim3(64), 0, stream, g, q_blk, (uint4*)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
+                               int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream)
+{
+    if (q.n_tiles16 <= 0 || g.G <= 0) return hipSuccess;
+    const int n_chunks = (g.G + chunk - 1) / chunk;
+    const long long blocks = (long long)((n_chunks + 7) / 8) * 8 * q.n_tiles16;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_adc_rowmin_q<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
+                       (const float2*)rowc, chunk, n_chunks, rm_val, rm_arg);
+    return hipGetLastError();
+}
+
 }  // namespace afis

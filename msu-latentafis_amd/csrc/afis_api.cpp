@@ -40,11 +40,11 @@ struct DevBuf {
 // One group of latents resident on the device.
 struct QueryGroup {
     QueryDev dev;
-    DevBuf lm_off, lm_xy, lm_ori, lm_des, lm_frag, lm_tile_off, lt_off, lt_xy, lt_ori, lt_des, tile_off, tex_slot, status;
-    int nq = 0; int max_nL = 0; int64_t lut_rows_x_tiles = 0;
+    DevBuf lm_off, lm_xy, lm_ori, lm_des, lm_frag, lm_tile_off, lt_off, lt_xy, lt_ori, lt_des, tile_off, tile16_off, tex_slot, status;
+    int nq = 0; int max_nL = 0; int n_lt_rows = 0; int64_t lut_rows_x_tiles = 0;
     std::vector<int32_t> h_lt_n;
     void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lm_frag.release(); lm_tile_off.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
-                     lt_des.release(); tile_off.release(); tex_slot.release(); status.release(); }
+                     lt_des.release(); tile_off.release(); tile16_off.release(); tex_slot.release(); status.release(); }
 };
 
 struct afis_queries {
@@ -63,12 +63,16 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_empty;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_tex_codes_q, g_tex_q_blk, g_empty;
+    bool codes_q_built = false;          // the quantised path's code stream is laid out on first use (lut_dtype 16)
+    int64_t q_blocks = 0;
     int max_nR = 0;
     int64_t total_tex_points = 0;
+    DevBuf lutq, lutq_min, lutq_rng, lutq_rowc;      // lut_dtype 16: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step)
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 7;
+    int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
@@ -181,7 +185,7 @@ std::vector<float> fragment_tiles(const std::vector<float>& des, const std::vect
 void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
-    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_empty.release();
+    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_empty.release();
 }
 
 }  // namespace
@@ -234,7 +238,7 @@ void afis_destroy(afis_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
-    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release();
+    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release();
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -482,6 +486,14 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
         HIPCHK(ctx, upload(ctx->g_tex_cf_blk, cfb, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    {   // block offsets of the quantised path's code stream (ceil(n/64) blocks per template); the stream itself is made on first use
+        std::vector<int32_t> qb(G + 1);
+        int64_t nb = 0;
+        for (int64_t t = 0; t < G; ++t) { qb[t] = (int32_t)nb; nb += (hg.tex_off[t + 1] - hg.tex_off[t] + 63) / 64; }
+        qb[G] = (int32_t)nb;
+        ctx->q_blocks = nb;
+        HIPCHK(ctx, upload(ctx->g_tex_q_blk, qb, ctx->stream));
+    }
     HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     GalleryDev& g = ctx->gal;
@@ -510,7 +522,7 @@ static const int kSelected[3] = {27 - 1, 3 - 1, 12 - 1};                   // ma
 // template spec[i*4 + 3] (-1 = none), and is never "latent empty".
 static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, QueryGroup& grp, std::vector<int32_t>& status_out, const int* spec = nullptr)
 {
-    std::vector<int32_t> lm_off{0}, lt_off{0}, tile_off{0}, tex_slot, status;
+    std::vector<int32_t> lm_off{0}, lt_off{0}, tile_off{0}, tile16_off{0}, tex_slot, status;
     std::vector<short2> lm_xy, lt_xy; std::vector<float> lm_ori, lm_des, lt_ori, lt_des;
     int max_nL = 0, lt_max = 0;
     for (int i = 0; i < nq; ++i) {
@@ -544,6 +556,7 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
         }
         lt_off.push_back((int32_t)lt_xy.size());
         tile_off.push_back(tile_off.back() + (n_lt + kTileRows - 1) / kTileRows);
+        tile16_off.push_back(tile16_off.back() + (n_lt + 15) / 16);
         tex_slot.push_back(tex_ind >= 0 && t.n_tex > tex_ind ? t.n_minu : -1);
         lt_max = std::max(lt_max, n_lt);
         grp.h_lt_n.push_back(n_lt);
@@ -554,7 +567,7 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
     std::vector<int32_t> lm_tile_off;
     const std::vector<float> lm_frag = fragment_tiles(lm_des, lm_off, lm_tile_off);
     HIPCHK(ctx, upload(grp.lm_frag, lm_frag, s)); HIPCHK(ctx, upload(grp.lm_tile_off, lm_tile_off, s)); HIPCHK(ctx, upload(grp.lt_xy, lt_xy, s));
-    HIPCHK(ctx, upload(grp.lt_ori, lt_ori, s)); HIPCHK(ctx, upload(grp.lt_des, lt_des, s)); HIPCHK(ctx, upload(grp.tile_off, tile_off, s));
+    HIPCHK(ctx, upload(grp.lt_ori, lt_ori, s)); HIPCHK(ctx, upload(grp.lt_des, lt_des, s)); HIPCHK(ctx, upload(grp.tile_off, tile_off, s)); HIPCHK(ctx, upload(grp.tile16_off, tile16_off, s));
     HIPCHK(ctx, upload(grp.tex_slot, tex_slot, s)); HIPCHK(ctx, upload(grp.status, status, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     QueryDev& d = grp.dev;
@@ -563,6 +576,7 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
     d.lt_off = grp.lt_off.as<int32_t>(); d.lt_xy = grp.lt_xy.as<short2>(); d.lt_ori = grp.lt_ori.as<float>(); d.lt_des = grp.lt_des.as<float>();
     d.tile_off = grp.tile_off.as<int32_t>(); d.tex_slot = grp.tex_slot.as<int32_t>(); d.status = grp.status.as<int32_t>();
     d.n_tiles = tile_off.back();
+    d.tile16_off = grp.tile16_off.as<int32_t>(); d.n_tiles16 = tile16_off.back(); grp.n_lt_rows = lt_off.back();
     d.lt_pad = std::max(kTileRows, (lt_max + kTileRows - 1) / kTileRows * kTileRows);
     grp.nq = nq; grp.max_nL = max_nL;
     status_out.insert(status_out.end(), status.begin(), status.end());
@@ -595,6 +609,28 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q)
     if (ctx) (void)hipSetDevice(ctx->device);
     for (QueryGroup& g : q->groups) g.release();
     delete q;
+}
+
+// S4 + S5 + S6 of the opt-in quantised path for one query group (rm_val / rm_arg sized by the caller)
+static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, hipEvent_t after_lut = nullptr)
+{
+    const QueryDev& d = grp.dev;
+    hipStream_t s = ctx->stream;
+    if (d.n_tiles16 <= 0 || ctx->gal.G <= 0) { if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s)); return AFIS_OK; }
+    if (!ctx->codes_q_built) {
+        HIPCHK(ctx, ctx->g_tex_codes_q.ensure(std::max<size_t>((size_t)ctx->q_blocks * 64 * 16, 16)));
+        HIPCHK(ctx, launch_codes_q(ctx->gal, ctx->g_tex_q_blk.as<int32_t>(), ctx->g_tex_codes_q.p, s));
+        ctx->codes_q_built = true;
+    }
+    HIPCHK(ctx, ctx->lutq.ensure((size_t)d.n_tiles16 * 131072));
+    HIPCHK(ctx, ctx->lutq_min.ensure(std::max<size_t>((size_t)grp.n_lt_rows * kM * 4, 16)));
+    HIPCHK(ctx, ctx->lutq_rng.ensure(std::max<size_t>((size_t)grp.n_lt_rows * kM * 4, 16)));
+    HIPCHK(ctx, ctx->lutq_rowc.ensure(std::max<size_t>((size_t)grp.n_lt_rows * 8, 16)));
+    HIPCHK(ctx, launch_lutq_build(d, grp.n_lt_rows, ctx->codewords.as<float>(), ctx->lutq_min.as<float>(), ctx->lutq_rng.as<float>(), ctx->lutq.p, ctx->lutq_rowc.p, s));
+    if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
+    HIPCHK(ctx, launch_adc_rowmax_q(d, ctx->gal, ctx->g_tex_codes_q.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->lutq.p, ctx->lutq_rowc.p, chunk,
+                                    ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+    return AFIS_OK;
 }
 
 // Rank lists are made on the device for k <= kDeviceTopK (k passes of a workgroup-wide maximum per query); larger k sorts on the host.
@@ -639,12 +675,17 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
             float* grp_scores = ctx->scores.as<float>() + (size_t)q0 * G;
-            HIPCHK(ctx, hipEventRecord(ev[0], s));
-            HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
-            HIPCHK(ctx, hipEventRecord(ev[1], s));
             // larger chunks amortise the 128 KB LUT tile load; smaller ones keep enough workgroups in flight on a small gallery
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 65536 ? 512 : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32)));
-            HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+            HIPCHK(ctx, hipEventRecord(ev[0], s));
+            if (ctx->lut_dtype == 16) {                                    // opt-in tolerance path: 16-bit fixed-point LUT (adc.hip)
+                int rc16 = adc_stage_q(ctx, grp, chunk, ev[1]);
+                if (rc16 != AFIS_OK) return rc16;
+            } else {
+                HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
+                HIPCHK(ctx, hipEventRecord(ev[1], s));
+                HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+            }
             HIPCHK(ctx, hipEventRecord(ev[2], s));
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
@@ -864,6 +905,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
     if (n == "adc_variant") { if (value < 0 || value > 7 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6 or 7"); ctx->adc_variant = (int)value; }
+    else if (n == "lut_dtype") { if (value != 16 && value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype must be 32 (exact, default) or 16 (16-bit fixed-point LUT, tolerance path)"); ctx->lut_dtype = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
@@ -937,8 +979,11 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
         HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * d.lt_pad * 4));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_val.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_arg.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
+        if (ctx->lut_dtype == 16) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
+        else {
         HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, ctx->stream));
         HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk > 0 ? ctx->chunk : 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
+        }
         HIPCHK(ctx, hipMemcpyAsync(val, ctx->rm_val.as<float>() + (size_t)gidx * d.lt_pad, (size_t)n_lt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(arg, ctx->rm_arg.as<int32_t>() + (size_t)gidx * d.lt_pad, (size_t)n_lt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
