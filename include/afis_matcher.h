@@ -183,11 +183,12 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
                          int32_t* counts /*[n][3]*/, int16_t* xy /*[n][3][120][4]*/);
 
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
-/* Tunables: "adc_variant" (0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups —
- * kept as references; 6 = conflict-free lane classes with 512-thread workgroups, 7 = the same with 1024 [default]; all
- * bit-identical; 4 and 5 were earlier forms of 6/7 and are rejected), "query_batch" (latents per
- * launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel),
- * "rowmax_budget_mb", and "lut_dtype": 32 (default) = the exact fp32 look-up table, every result bit-identical to the reference
+/* Tunables: "adc_variant" — every variant gives bit-identical results: 8 [default] = a 16-bit fixed-point pass over all points bounds the
+ * candidates of every row maximum, which are then evaluated exactly (fp32, the reference's order) — 0.78 x the time of 7; 7 = direct
+ * exact kernel, conflict-free lane classes, 1024-thread workgroups; 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad
+ * rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
+ * "query_batch" (latents per launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae
+ * candidate kernel), "rowmax_budget_mb", and "lut_dtype": 32 (default) = the exact fp32 look-up table, every result bit-identical to the reference
  * arithmetic; 16 = opt-in TOLERANCE path: the per-query table quantised to 16-bit fixed point (16 latent rows per 128 KB LDS tile,
  * integer sums; BASELINE.json configs[4]).  Its only error is the quantisation (|d sim| <= 16 steps / 2, about 4e-3), so row maxima
  * and arg-maxima can differ from the exact path where two candidates are closer than that; scores are NOT bit-exact.

@@ -591,9 +591,18 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
 
-template <int kAdcThreads>
+// kExact = false: the tolerance path described above.
+// kExact = true (adc_variant 8): the quantised pass is only a BOUND, the results are the exact fp32 ones, bit for bit.  With
+// e = 8 q_i + a few 1e-6 the bound on |q_i * S_j - exact part of sim(i, j)|, every point whose exact similarity equals the row's
+// exact maximum has an integer sum S_j <= S* + T_i, T_i = 16 + ceil(1.5e-5 / q_i) + 2 (S* = the smallest sum).  Each lane also tracks
+// its SECOND smallest sum per row; if no lane's second sum is <= S* + T_i, the lanes whose smallest sum is <= S* + T_i hold every
+// candidate — almost always exactly one, the arg-min itself.  The candidates (typically 1.03 per row) are then evaluated exactly:
+// 16 look-ups in the fp32 table kept in HBM/L2 (reference layout [row][m][code]) in the reference's four-chain order
+// (matcher.cpp:571-592), first maximum by point index.  A row with a second-sum hit (two points of one lane within the
+// threshold, about 1 in 2000) has ALL its points evaluated exactly.  So 800 x 16 exact look-ups per (row, template) become 16.5.
+template <int kAdcThreads, bool kExact>
 __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, GalleryDev g, const uint4* __restrict__ codes_q, const int32_t* __restrict__ q_blk,
-                                                               const uint4* __restrict__ lutq_tiles, const float2* __restrict__ rowc,
+                                                               const uint4* __restrict__ lutq_tiles, const float2* __restrict__ rowc, const float* __restrict__ lut32,
                                                                int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
 {
     __shared__ uint4 s_lut[kQTileVec];                        // 128 KB
@@ -624,24 +633,24 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
         if (lane == 0) c = atomicAdd(&s_next, 1);
         return g_lo + __builtin_amdgcn_readfirstlane(c);
     };
-    auto stream_of = [&](int gidx, int& n, int& blk0) {
-        n = 0; blk0 = 0;
-        if (gidx < g_hi) { n = g.tex_off[gidx + 1] - g.tex_off[gidx]; blk0 = q_blk[gidx]; }
+    auto stream_of = [&](int gidx, int& n, int& blk0, int& pt0) {
+        n = 0; blk0 = 0; pt0 = 0;
+        if (gidx < g_hi) { pt0 = g.tex_off[gidx]; n = g.tex_off[gidx + 1] - pt0; blk0 = q_blk[gidx]; }
     };
-    int gi = claim(), n_pts, blk0;
-    stream_of(gi, n_pts, blk0);
+    int gi = claim(), n_pts, blk0, pt0;
+    stream_of(gi, n_pts, blk0, pt0);
     uint4 cw_next = make_uint4(0, 0, 0, 0);
     if (n_pts > 0) cw_next = codes_q[(size_t)blk0 * 64 + lane];
     while (gi < g_hi) {
-        const int gi_cur = gi, n_cur = n_pts, n_blocks = (n_pts + 63) >> 6;
+        const int gi_cur = gi, n_cur = n_pts, n_blocks = (n_pts + 63) >> 6, p0_cur = pt0;
         const uint4* cfp = codes_q + ((size_t)blk0 * 64 + lane);
         gi = claim();
-        stream_of(gi, n_pts, blk0);                           // the next template: its offsets and first entry are fetched early
+        stream_of(gi, n_pts, blk0, pt0);                      // the next template: its offsets and first entry are fetched early
         const uint4* cfp_next = codes_q + ((size_t)blk0 * 64 + lane);
         if (n_cur <= 0) { if (n_pts > 0) cw_next = cfp_next[0]; continue; }
-        u16x2 best[8]; uint32_t bidx[8];
+        u16x2 best[8], sb[8]; uint32_t bidx[8];              // sb: the lane's SECOND smallest sum per row (kExact only)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { best[k] = as_u16x2(0x7fff7fffu); bidx[k] = 0u; }
+        for (int k = 0; k < 8; ++k) { best[k] = as_u16x2(0x7fff7fffu); sb[k] = as_u16x2(0x7fff7fffu); bidx[k] = 0u; }
         // one block = 64 points x 16 rows.  Only the LAST block of a template can hold lanes without a point: their sums are forced to
         // 0x7fff (never a minimum) there; every other block runs without any validity test, and nothing in a block is conditional, so
         // the compiler keeps reads and adds interleaved as written.
@@ -703,6 +712,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
                     const u16x2 sum = kLast ? as_u16x2(as_u32(acc[k]) | inv) : acc[k];
                     const s16x2 d = __builtin_bit_cast(s16x2, sum) - __builtin_bit_cast(s16x2, best[k]);       // both < 2^15: no overflow
                     const uint32_t m = __builtin_bit_cast(uint32_t, d >> 15);                                   // 0xffff where sum < best
+                    if (kExact) sb[k] = __builtin_elementwise_min(sb[k], __builtin_elementwise_max(best[k], sum));       // the loser of (best, sum)
                     best[k] = __builtin_elementwise_min(best[k], sum);
                     bidx[k] = (blkpk & m) | (bidx[k] & ~m);
                 }
@@ -721,6 +731,9 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
             B[2 * k] = (bb << 16) | ((bidx[k + 4] & 0xffffu) * 64u + (uint32_t)lane);
             B[2 * k + 1] = (bb & 0xffff0000u) | ((bidx[k + 4] >> 16) * 64u + (uint32_t)lane);
         }
+        uint32_t A0[8], B0[8];                                 // this lane's own keys (kExact: candidate test after the reduction)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { A0[j] = A[j]; B0[j] = B[j]; }
         constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
 #pragma unroll
         for (int j = 0; j < 8; ++j) {                          // lane ^ 1 holds the same rows in its OTHER slot set
@@ -734,18 +747,78 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
             A[j] = min(A[j], (uint32_t)dpp_i<kRor8>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor8>((int)B[j]));
         }
         uint32_t mine = 0;                                     // lane r < 16 ends up with row r's key (lanes 0, 16, 32, 48 are pr = 0: A = rows 0..7)
+        uint32_t skey[16];                                     // wave-uniform
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t x = r < 8 ? A[r] : B[r - 8];
             const uint32_t s0 = __builtin_amdgcn_readlane(x, 0), s1 = __builtin_amdgcn_readlane(x, 16), s2 = __builtin_amdgcn_readlane(x, 32), s3 = __builtin_amdgcn_readlane(x, 48);
-            const uint32_t s = min(min(s0, s1), min(s2, s3));
-            if (lane == r) mine = s;
+            skey[r] = min(min(s0, s1), min(s2, s3));
+            if (lane == r) mine = skey[r];
         }
-        if (lane < kQRows && row0 + lane < n_lt) {
-            const float2 rc = rowc[lt0 + row0 + lane];
-            const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
-            rm_val[o] = rc.x - rc.y * (float)(mine >> 16);
-            rm_arg[o] = (int32_t)(mine & 0xffffu);
+        const bool row_ok = lane < kQRows && row0 + lane < n_lt;
+        const float2 rc = row_ok ? rowc[lt0 + row0 + lane] : make_float2(0.f, 1.f);
+        if (!kExact) {
+            if (row_ok) {
+                const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
+                rm_val[o] = rc.x - rc.y * (float)(mine >> 16);
+                rm_arg[o] = (int32_t)(mine & 0xffffu);
+            }
+        } else {
+            // exact similarity of (tile row r, point p of the current template), the reference's four chains (matcher.cpp:571-592)
+            auto exact_sim = [&](int r, int p) -> float {
+                const uint4 c = g.tex_codes[p0_cur + p];
+                const float* lr = lut32 + (size_t)(lt0 + row0 + r) * (kM * kK);
+                const uint32_t w4[4] = {c.x, c.y, c.z, c.w};
+                float l[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) l[m] = lr[m * kK + ((w4[m >> 2] >> (8 * (m & 3))) & 255u)];
+                float d1 = 6.0f, d2 = 0.0f, d3 = 0.0f, d4 = 0.0f;
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) { d1 -= l[4 * mg]; d2 -= l[4 * mg + 1]; d3 -= l[4 * mg + 2]; d4 -= l[4 * mg + 3]; }
+                return (d1 + d2) + (d3 + d4);
+            };
+            // fast path: lane r evaluates the arg-min of row r
+            float out_v = 0.f; int out_i = 0;
+            if (row_ok) { out_i = (int)(mine & 0xffffu); out_v = exact_sim(lane, out_i); }
+            // candidate census per row (uniform): more than one lane within S* + T, or any second-smallest sum within it -> slow row
+            const int Tl = row_ok ? 18 + (int)fminf(1.5e-5f / rc.y, 30000.0f) : 0;
+            uint32_t slow_rows = 0, sb_rows = 0;
+            uint32_t myk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool in_a = pr == (r >> 3);
+                myk[r] = in_a ? A0[r & 7] : B0[r & 7];
+                const uint32_t sbp = as_u32(in_a ? sb[(r & 7) >> 1] : sb[4 + ((r & 7) >> 1)]);
+                const uint32_t mysb = (r & 1) ? (sbp >> 16) : (sbp & 0xffffu);
+                const uint32_t thr = min((skey[r] >> 16) + (uint32_t)__builtin_amdgcn_readlane(Tl, r), 0x7fffu);
+                const unsigned long long cm = __ballot(myk[r] <= ((thr << 16) | 0xffffu));
+                const unsigned long long sm2 = __ballot(mysb <= thr);
+                const bool valid = row0 + r < n_lt;                                 // uniform
+                if (valid && (sm2 != 0ull || __popcll(cm) != 1)) slow_rows |= 1u << r;
+                if (valid && sm2 != 0ull) sb_rows |= 1u << r;
+            }
+            while (slow_rows) {                                                    // uniform loop over the rare rows
+                const int r = __ffs(slow_rows) - 1;
+                slow_rows &= slow_rows - 1;
+                const uint32_t thr = min((skey[r] >> 16) + (uint32_t)__builtin_amdgcn_readlane(Tl, r), 0x7fffu);
+                float v = -INFINITY; int i = 0x7fffffff;
+                // myk[] is indexed by a runtime r: fetch it through a select chain (registers cannot be indexed dynamically)
+                uint32_t mk = 0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) mk = (t == r) ? myk[t] : mk;
+                if ((sb_rows >> r) & 1u) {                                         // two points of one lane within the threshold: every point, exactly
+                    for (int p = lane; p < n_cur; p += 64) { const float e = exact_sim(r, p); if (e > v) { v = e; i = p; } }
+                } else if (mk <= ((thr << 16) | 0xffffu) && (int)(mk & 0xffffu) < n_cur) {   // this lane's smallest sum is a candidate (and a real point)
+                    i = (int)(mk & 0xffffu); v = exact_sim(r, i);
+                }
+                wave_argmax(v, i);                                                 // value descending, point index ascending: the FIRST maximum
+                if (lane == r) { out_v = v; out_i = i; }
+            }
+            if (row_ok) {
+                const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
+                rm_val[o] = out_v;
+                rm_arg[o] = out_i;
+            }
         }
     }
 }
@@ -766,14 +839,16 @@ hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, 
 }
 
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
-                               int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream)
+                               const float* lut32, int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream)
 {
     if (q.n_tiles16 <= 0 || g.G <= 0) return hipSuccess;
     const int n_chunks = (g.G + chunk - 1) / chunk;
     const long long blocks = (long long)((n_chunks + 7) / 8) * 8 * q.n_tiles16;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_adc_rowmin_q<1024>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                       (const float2*)rowc, chunk, n_chunks, rm_val, rm_arg);
+    if (lut32) hipLaunchKernelGGL((k_adc_rowmin_q<1024, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
+                                  (const float2*)rowc, lut32, chunk, n_chunks, rm_val, rm_arg);
+    else hipLaunchKernelGGL((k_adc_rowmin_q<1024, false>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
+                            (const float2*)rowc, lut32, chunk, n_chunks, rm_val, rm_arg);
     return hipGetLastError();
 }
 

@@ -68,10 +68,10 @@ struct afis_ctx {
     int64_t q_blocks = 0;
     int max_nR = 0;
     int64_t total_tex_points = 0;
-    DevBuf lutq, lutq_min, lutq_rng, lutq_rowc;      // lut_dtype 16: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step)
+    DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // lut_dtype 16: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step)
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
-    int adc_variant = 7;
+    int adc_variant = 8;                 // 8: 16-bit bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
@@ -238,7 +238,7 @@ void afis_destroy(afis_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
-    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release();
+    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -612,7 +612,8 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q)
 }
 
 // S4 + S5 + S6 of the opt-in quantised path for one query group (rm_val / rm_arg sized by the caller)
-static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, hipEvent_t after_lut = nullptr)
+// exact == true (adc_variant 8): the quantised pass bounds the candidates, the fp32 table (reference layout, all rows of the group) settles them
+static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hipEvent_t after_lut = nullptr)
 {
     const QueryDev& d = grp.dev;
     hipStream_t s = ctx->stream;
@@ -627,9 +628,13 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, hipEvent_t aft
     HIPCHK(ctx, ctx->lutq_rng.ensure(std::max<size_t>((size_t)grp.n_lt_rows * kM * 4, 16)));
     HIPCHK(ctx, ctx->lutq_rowc.ensure(std::max<size_t>((size_t)grp.n_lt_rows * 8, 16)));
     HIPCHK(ctx, launch_lutq_build(d, grp.n_lt_rows, ctx->codewords.as<float>(), ctx->lutq_min.as<float>(), ctx->lutq_rng.as<float>(), ctx->lutq.p, ctx->lutq_rowc.p, s));
+    if (exact) {
+        HIPCHK(ctx, ctx->lut32.ensure((size_t)grp.n_lt_rows * kM * kK * 4));
+        HIPCHK(ctx, launch_lut_reference_layout(d.lt_des, grp.n_lt_rows, ctx->codewords.as<float>(), ctx->lut32.as<float>(), s));
+    }
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
-    HIPCHK(ctx, launch_adc_rowmax_q(d, ctx->gal, ctx->g_tex_codes_q.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->lutq.p, ctx->lutq_rowc.p, chunk,
-                                    ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+    HIPCHK(ctx, launch_adc_rowmax_q(d, ctx->gal, ctx->g_tex_codes_q.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->lutq.p, ctx->lutq_rowc.p,
+                                    exact ? ctx->lut32.as<float>() : nullptr, chunk, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
     return AFIS_OK;
 }
 
@@ -678,8 +683,8 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             // larger chunks amortise the 128 KB LUT tile load; smaller ones keep enough workgroups in flight on a small gallery
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 65536 ? 512 : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32)));
             HIPCHK(ctx, hipEventRecord(ev[0], s));
-            if (ctx->lut_dtype == 16) {                                    // opt-in tolerance path: 16-bit fixed-point LUT (adc.hip)
-                int rc16 = adc_stage_q(ctx, grp, chunk, ev[1]);
+            if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {           // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
+                int rc16 = adc_stage_q(ctx, grp, chunk, ctx->lut_dtype != 16, ev[1]);
                 if (rc16 != AFIS_OK) return rc16;
             } else {
                 HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
@@ -904,7 +909,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
-    if (n == "adc_variant") { if (value < 0 || value > 7 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6 or 7"); ctx->adc_variant = (int)value; }
+    if (n == "adc_variant") { if (value < 0 || value > 8 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7 or 8"); ctx->adc_variant = (int)value; }
     else if (n == "lut_dtype") { if (value != 16 && value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype must be 32 (exact, default) or 16 (16-bit fixed-point LUT, tolerance path)"); ctx->lut_dtype = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
@@ -979,7 +984,7 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
         HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * d.lt_pad * 4));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_val.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_arg.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
-        if (ctx->lut_dtype == 16) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
+        if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32, ctx->lut_dtype != 16); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
         else {
         HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, ctx->stream));
         HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk > 0 ? ctx->chunk : 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
@@ -1022,8 +1027,9 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             if (d.n_tiles <= 0) return AFIS_OK;
             HIPCHK(ctx, ctx->lut.ensure((size_t)d.n_tiles * kTileFloats * 4));
             HIPCHK(ctx, ctx->rm_val.ensure((size_t)d.lt_pad * 4)); HIPCHK(ctx, ctx->rm_arg.ensure((size_t)d.lt_pad * 4));
-            HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
-            HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+            const int av = ctx->adc_variant == 8 ? 7 : ctx->adc_variant;     // the tap always uses a direct exact kernel (same bits)
+            HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), av, s));
+            HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, av, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(),
                                              d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
         } else {

@@ -87,8 +87,10 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
 // stream it reads (ceil(n/64) blocks per template, first block q_blk[t]); S5+S6 with integer sums.  NOT bit-exact (quantisation error only).
 hipError_t launch_lutq_build(const QueryDev& q, int n_rows_total, const float* codewords, float* row_min, float* row_rng, void* tiles, void* rowc, hipStream_t stream);
 hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, hipStream_t stream);
+// lut32 != NULL (adc_variant 8): the quantised pass only bounds the candidates, which are then evaluated exactly from the fp32 table in the
+// reference layout [row][16][256] (launch_lut_reference_layout over all latent texture rows of the group): exact results, bit for bit.
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
-                               int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream);
+                               const float* lut32, int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream);
 // one correspondence of a minutiae-template list (S3 output), 8 bytes
 struct MinuCand { float sim; short li, ri; };
 // S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]

@@ -48,7 +48,7 @@ def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8])
 def test_rowmax_bit_exact(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -581,7 +581,7 @@ def test_medium_properties_and_sharding(codebook_bytes, cb, oracle, medium):
     assert np.array_equal(fused.astype(np.float32), r1["scores"])
     assert (r1["scores"] >= 0).all()
     # (5) every ADC variant and the generic minutiae candidate kernel give identical bits
-    for v in (0, 1, 6):
+    for v in (0, 1, 6, 8):                                              # 8 = 16-bit bound pass + exact refine
         m.set_option("adc_variant", v)
         r0 = m.search(lats, k=0)
         assert np.array_equal(r0["scores"], r1["scores"]), v
@@ -807,3 +807,59 @@ def test_quantised_lut_path_scores_within_tolerance(codebook_bytes, cb, medium):
         mates = [g for g, _ in planted[qi]]
         assert list(quant["topk_idx"][qi][:len(mates)]) == mates
         assert not far[qi, mates].any(), (qi, e[qi, mates], q[qi, mates])
+
+
+def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes, cb, medium):
+    """adc_variant 8 (16-bit bound pass + exact evaluation of the candidates) against the direct exact kernel (7): every row maximum and
+    every first arg-max of 6 latents x 40 gallery templates (about 160 000 rows), bit for bit."""
+    lats, gal, planted = medium
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add_packed(gal); m.gallery_commit(0)
+    rng = np.random.default_rng(8)
+    n = 0
+    for qi in range(len(lats)):
+        gs = [g for g, _ in planted[qi]] + [int(x) for x in rng.integers(0, gal.G, 36)]
+        for g in gs:
+            m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lats[qi], g)
+            m.set_option("adc_variant", 8); v8, a8 = m.debug_texture_rowmax(lats[qi], g)
+            assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)) and np.array_equal(a7, a8), (qi, g, np.argwhere(a7 != a8)[:4])
+            n += len(v7)
+    m.close()
+    assert n > 100000
+
+
+def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
+    """The bound logic at its edges: rolled templates whose points are all identical (every quantised sum ties: each lane's second
+    sum equals its best, so the whole row is evaluated exactly and the FIRST point must win), alternate between two codes, or differ
+    from one another in a single sub-quantizer (exact similarities closer than the quantisation step); latent rows with zero, tiny and
+    duplicated descriptors (degenerate table ranges).  Variant 8 must reproduce variant 7 bit for bit, values and first arg-maxima."""
+    rng = np.random.default_rng(21)
+    base = S.make_latent(rng, n_tex_lo=330, n_tex_hi=360)
+    lt = base.tex[0]
+    des = lt.des.copy()
+    des[0] = 0.0; des[1] = 1e-6 * des[1]; des[2] = des[3]; des[5:9] = des[4]
+    lat = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=des)])
+    def rolled(codes):
+        r = S.make_rolled(rng, cb, n_tex=len(codes))
+        r.tex[0].codes[:] = codes
+        return r
+    n = 700
+    same = np.tile(rng.integers(0, 256, (1, 16)).astype(np.uint8), (n, 1))
+    two = np.where((np.arange(n) % 2 == 0)[:, None], same, rng.integers(0, 256, (1, 16)).astype(np.uint8))
+    near = np.tile(cb.encode(des[10:11]), (n, 1)).astype(np.uint8)
+    near[np.arange(n), rng.integers(0, 16, n)] = rng.integers(0, 256, n).astype(np.uint8)           # one sub-quantizer off the row's own best code
+    near2 = near.copy(); near2[::3] = near[0]                                                     # many exact duplicates among near ties
+    enc = np.repeat(cb.encode(des[:350]), 2, axis=0)[:n].astype(np.uint8)                         # every latent row's best code, twice
+    gal = [rolled(same), rolled(two), rolled(near), rolled(near2), rolled(enc), rolled(rng.integers(0, 256, (65, 16)).astype(np.uint8)),
+           rolled(rng.integers(0, 256, (1, 16)).astype(np.uint8))]
+    m = _matcher(codebook_bytes, gal)
+    for g in range(len(gal)):
+        m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
+        m.set_option("adc_variant", 8); v8, a8 = m.debug_texture_rowmax(lat, g)
+        assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (g, np.argwhere(v7 != v8)[:4])
+        assert np.array_equal(a7, a8), (g, np.argwhere(a7 != a8)[:4], a7[:8], a8[:8])
+    assert (m.debug_texture_rowmax(lat, 0)[1] == 0).all()                                          # all points identical: the first one
+    m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
+    m.set_option("adc_variant", 8); r8 = m.search([lat], k=0, want_parts=True)
+    m.close()
+    assert np.array_equal(r7["parts"].view(np.uint32), r8["parts"].view(np.uint32))

@@ -16,6 +16,7 @@ G = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read(); cb = T.Codebook.from_bytes(cbb)
 lats = S.make_latents(seed, Q); gal = S.make_packed_gallery(seed, G, cb); S.plant_mates(seed, gal, cb, lats, G=G)
 m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0)
+if os.environ.get("AFIS_ADC_VARIANT"): m.set_option("adc_variant", int(os.environ["AFIS_ADC_VARIANT"]))
 r = m.search(lats, k=0, want_parts=True)
 orc = Oracle(); ocb = orc.codebook(cbb)
 hr = [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(G)]
