@@ -26,8 +26,8 @@ M = importlib.import_module("msu-latentafis_amd.host.matcher")
 SH = importlib.import_module("msu-latentafis_amd.host.sharding")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-LDS_PEAK_LOOKUPS = 256 * 64 * 2.4e9   # 256 CUs x 256 B/clk (ds_read_b128) / 4 B x 2.4 GHz (MI355X_MICROARCH.md §LDS); measured 3.87e13/s
-                                      # with tools/ubench/lds_rate.hip (profiles/r01_lds_peak.json)
+LDS_PEAK_BYTES = 256 * 256 * 2.4e9     # 256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz = 157 TB/s (MI355X_MICROARCH.md §LDS); 154.8 TB/s measured with
+                                      # tools/ubench/lds_rate.hip (profiles/r01_lds_peak.json)
 BYTES_PER_TEX_POINT = 2 + 2 + 4 + 16  # x, y, ori, 16 PQ code bytes per rolled texture point
 BYTES_PER_MINUTIA = 2 + 2 + 4 + 96 * 4
 
@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--query-batch", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--tile-share", type=int, default=0)
     ap.add_argument("--lut-dtype", type=int, default=32, help="32 = exact fp32 LUT (the headline path); 16 = opt-in 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
@@ -151,6 +152,7 @@ def main():
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)
     if a.lut_dtype != 32: m.set_option("lut_dtype", a.lut_dtype)
+    if a.tile_share > 0: m.set_option("tile_share", a.tile_share)
     t_up = time.perf_counter()
     m.gallery_add_packed(gal)
     m.gallery_commit(lo)
@@ -202,6 +204,8 @@ def main():
         alg_bytes_launch = q_per_launch * shard_tex_points * BYTES_PER_TEX_POINT
         achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
         lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
+        quantised = a.lut_dtype == 16 or a.variant in (-1, 8)              # the 16-bit pass (default variant 8 and the tolerance path): 2 LDS bytes per look-up
+        lds_bytes_per_lookup = 2 if quantised else 4
         traffic = None; traffic_source = None
         tp = os.path.join(ROOT, "profiles", "adc_hbm_traffic.json")
         if os.path.exists(tp) and world == 1 and G == 100000 and Q == 100:      # measured for the default workload only
@@ -209,6 +213,7 @@ def main():
                 tj = json.load(open(tp))
                 traffic = tj.get("traffic_bytes_per_launch")
                 traffic_source = "profiles/adc_hbm_traffic.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, %s; PMC counters cannot be read inside this run)" % tj.get("round", "round 1")
+                if a.variant not in (-1, 8) or a.lut_dtype != 32: traffic = None; traffic_source = None
             except Exception:
                 traffic = None
         pipeline_bytes = Q * (int(nt_all.sum()) * BYTES_PER_TEX_POINT + int(nm_all.sum()) * BYTES_PER_MINUTIA)
@@ -220,12 +225,13 @@ def main():
                                    f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists" + ("" if a.lut_dtype == 32 else "; 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4] kernel on one GPU)"), "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
                        "adc_variant": a.variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
-            "roofline": {"bound": "hbm", "kernel": "k_adc_rowmax" if a.lut_dtype == 32 else "k_adc_rowmin_q (lut build included in its time)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_adc_rowmin_q<1024,true> (16-bit bound pass + exact refine)" if a.variant in (-1, 8) else "k_adc_rowmax (direct exact kernel)") if a.lut_dtype == 32 else "k_adc_rowmin_q<1024,false> (tolerance path)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                          "achieved_is": "ALGORITHMIC bytes (24 B per rolled texture point per query of the launch) / kernel time; the kernel reads each code byte from HBM once per launch and is bound by LDS/VALU issue, see lds_frac",
                          "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),
-                         "lds_lookups_per_s": lookups_per_s, "lds_peak_lookups_per_s": LDS_PEAK_LOOKUPS,
-                         "lds_frac": round(lookups_per_s / LDS_PEAK_LOOKUPS, 4),
+                         "lds_lookups_per_s": lookups_per_s, "lds_bytes_per_lookup": lds_bytes_per_lookup, "lds_peak_bytes_per_s": LDS_PEAK_BYTES,
+                         "lds_frac": round(lookups_per_s * lds_bytes_per_lookup / LDS_PEAK_BYTES, 4),
+                         "limiting_resource": "VALU issue (about one VALU instruction per 4.4 cycles per SIMD, profiles/r02_pmc_sq_summary.txt); LDS array about half busy",
                          "pipeline_achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / 1.0, 3)},
             "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
             "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},

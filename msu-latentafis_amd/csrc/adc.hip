@@ -603,13 +603,16 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(
 template <int kAdcThreads, bool kExact>
 __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, GalleryDev g, const uint4* __restrict__ codes_q, const int32_t* __restrict__ q_blk,
                                                                const uint4* __restrict__ lutq_tiles, const float2* __restrict__ rowc, const float* __restrict__ lut32,
-                                                               int chunk, int n_chunks, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
+                                                               int chunk, int n_chunks, int share, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
 {
     __shared__ uint4 s_lut[kQTileVec];                        // 128 KB
     __shared__ int s_next;
-    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;      // XCD-aware: the tiles of one gallery chunk run back to back on one XCD
-    const int tile = seq % q.n_tiles16;
-    const int chunk_id = (seq / q.n_tiles16) * 8 + xcd;
+    // XCD-aware (block b runs on XCD b % 8): the blocks that follow one another on an XCD take `share` consecutive gallery chunks against
+    // the SAME tile before moving to the next tile, so at any time the XCD's L2 serves 32 / share tiles (u16 tile + the fp32 table of the
+    // refine) and `share` chunks of codes
+    const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
+    const int tile = (seq / share) % q.n_tiles16;
+    const int chunk_id = ((seq / (share * q.n_tiles16)) * share + seq % share) * 8 + xcd;
     if (chunk_id >= n_chunks) return;
     int qi = 0;
     while (qi + 1 < q.nq && tile >= q.tile16_off[qi + 1]) ++qi;
@@ -677,21 +680,18 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
                     v[u][1] = *reinterpret_cast<const uint4*>(lut_b + a1);
                 }
             };
+            // the packed 16-bit halves never carry into one another (every partial sum is < 2^15), so the two steps of a group are
+            // folded in with ONE three-operand 32-bit add per register (v_add3_u32) instead of two packed adds
             auto adds = [&](bool first, const uint4 (&v)[2][2]) {
+                uint32_t r[8];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const uint4 v0 = v[u][0], v1 = v[u][1];
-                    if (first && u == 0) {
-                        acc[0] = as_u16x2(v0.x); acc[1] = as_u16x2(v0.y); acc[2] = as_u16x2(v0.z); acc[3] = as_u16x2(v0.w);
-                        acc[4] = as_u16x2(v1.x); acc[5] = as_u16x2(v1.y); acc[6] = as_u16x2(v1.z); acc[7] = as_u16x2(v1.w);
-                    } else {
-                        acc[0] += as_u16x2(v0.x); acc[1] += as_u16x2(v0.y); acc[2] += as_u16x2(v0.z); acc[3] += as_u16x2(v0.w);
-                        acc[4] += as_u16x2(v1.x); acc[5] += as_u16x2(v1.y); acc[6] += as_u16x2(v1.z); acc[7] += as_u16x2(v1.w);
-                    }
-                }
-                uint32_t r0 = as_u32(acc[0]), r1 = as_u32(acc[1]), r2 = as_u32(acc[2]), r3 = as_u32(acc[3]), r4 = as_u32(acc[4]), r5 = as_u32(acc[5]), r6 = as_u32(acc[6]), r7 = as_u32(acc[7]);
-                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) :: "memory");
-                acc[0] = as_u16x2(r0); acc[1] = as_u16x2(r1); acc[2] = as_u16x2(r2); acc[3] = as_u16x2(r3); acc[4] = as_u16x2(r4); acc[5] = as_u16x2(r5); acc[6] = as_u16x2(r6); acc[7] = as_u16x2(r7);
+                for (int k = 0; k < 8; ++k) r[k] = first ? 0u : as_u32(acc[k]);
+                const uint4 p0 = v[0][0], p1 = v[1][0], q0 = v[0][1], q1 = v[1][1];
+                r[0] = r[0] + p0.x + p1.x; r[1] = r[1] + p0.y + p1.y; r[2] = r[2] + p0.z + p1.z; r[3] = r[3] + p0.w + p1.w;
+                r[4] = r[4] + q0.x + q1.x; r[5] = r[5] + q0.y + q1.y; r[6] = r[6] + q0.z + q1.z; r[7] = r[7] + q0.w + q1.w;
+                asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) :: "memory");
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = as_u16x2(r[k]);
             };
             {
                 uint4 va[2][2], vb[2][2];
@@ -839,16 +839,17 @@ hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, 
 }
 
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
-                               const float* lut32, int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream)
+                               const float* lut32, int chunk, int share, float* rm_val, int32_t* rm_arg, hipStream_t stream)
 {
     if (q.n_tiles16 <= 0 || g.G <= 0) return hipSuccess;
     const int n_chunks = (g.G + chunk - 1) / chunk;
-    const long long blocks = (long long)((n_chunks + 7) / 8) * 8 * q.n_tiles16;
+    if (share < 1) share = 1;
+    const long long blocks = (long long)((n_chunks + 8 * share - 1) / (8 * share)) * 8 * share * q.n_tiles16;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (lut32) hipLaunchKernelGGL((k_adc_rowmin_q<1024, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                                  (const float2*)rowc, lut32, chunk, n_chunks, rm_val, rm_arg);
+                                  (const float2*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
     else hipLaunchKernelGGL((k_adc_rowmin_q<1024, false>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                            (const float2*)rowc, lut32, chunk, n_chunks, rm_val, rm_arg);
+                            (const float2*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
     return hipGetLastError();
 }
 

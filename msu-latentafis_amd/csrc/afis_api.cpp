@@ -72,6 +72,7 @@ struct afis_ctx {
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 8;                 // 8: 16-bit bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
+    int tile_share = 1;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD (L2 locality of the tables)
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
@@ -634,7 +635,7 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
     }
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
     HIPCHK(ctx, launch_adc_rowmax_q(d, ctx->gal, ctx->g_tex_codes_q.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->lutq.p, ctx->lutq_rowc.p,
-                                    exact ? ctx->lut32.as<float>() : nullptr, chunk, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+                                    exact ? ctx->lut32.as<float>() : nullptr, chunk, ctx->tile_share, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
     return AFIS_OK;
 }
 
@@ -911,6 +912,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     const std::string n(name);
     if (n == "adc_variant") { if (value < 0 || value > 8 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7 or 8"); ctx->adc_variant = (int)value; }
     else if (n == "lut_dtype") { if (value != 16 && value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype must be 32 (exact, default) or 16 (16-bit fixed-point LUT, tolerance path)"); ctx->lut_dtype = (int)value; }
+    else if (n == "tile_share") { if (value < 1 || value > 32) return fail(ctx, AFIS_EINVAL, "tile_share must be 1..32"); ctx->tile_share = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }

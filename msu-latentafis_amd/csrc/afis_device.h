@@ -90,7 +90,7 @@ hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, 
 // lut32 != NULL (adc_variant 8): the quantised pass only bounds the candidates, which are then evaluated exactly from the fp32 table in the
 // reference layout [row][16][256] (launch_lut_reference_layout over all latent texture rows of the group): exact results, bit for bit.
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
-                               const float* lut32, int chunk, float* rm_val, int32_t* rm_arg, hipStream_t stream);
+                               const float* lut32, int chunk, int share, float* rm_val, int32_t* rm_arg, hipStream_t stream);
 // one correspondence of a minutiae-template list (S3 output), 8 bytes
 struct MinuCand { float sim; short li, ri; };
 // S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]
