@@ -249,34 +249,65 @@ __device__ __forceinline__ bool pair_compatible(const Pt& a, const Pt& o, const 
 // two commutes with every rounding involved: dist = |d1 - d2| = 16 * |RN(sqrt n1) - RN(sqrt n2)| exactly.
 typedef short v2s16 __attribute__((ext_vector_type(2)));
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+template <bool RANGE_TEST>
 __device__ __forceinline__ bool tex_pair_n(int2 a, int2 o, float& s1, float& s2)
 {
     const v2s16 dl = __builtin_bit_cast(v2s16, a.x) - __builtin_bit_cast(v2s16, o.x);
     const v2s16 dr = __builtin_bit_cast(v2s16, a.y) - __builtin_bit_cast(v2s16, o.y);
     s1 = (float)__builtin_amdgcn_sdot2(dl, dl, 0, false);
     s2 = (float)__builtin_amdgcn_sdot2(dr, dr, 0, false);
+    if (!RANGE_TEST) return true;                                        // every coordinate of the list is in [0, 49]: |d| < 50 always
     // |d| < 50 for all four components (matcher.cpp:1257)  <=>  (d + 49) as u16 <= 98
     const v2u16 bias = {49, 49};
     const v2u16 tl = __builtin_bit_cast(v2u16, dl) + bias, tr = __builtin_bit_cast(v2u16, dr) + bias;
     const v2u16 mx = __builtin_elementwise_max(tl, tr);
     return max((unsigned)mx.x, (unsigned)mx.y) <= 98u;
 }
+template <bool RANGE_TEST>
 __device__ __forceinline__ bool tex_pair_dist(int2 a, int2 o, float& dist)
 {
     float s1, s2;
-    const bool ok = tex_pair_n(a, o, s1, s2);
+    const bool ok = tex_pair_n<RANGE_TEST>(a, o, s1, s2);
     dist = 16.0f * fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2));
     return ok;
 }
+template <bool RANGE_TEST>
 __device__ __forceinline__ bool tex_pair_compatible(int2 a, int2 o)
 {
     float s1, s2;
-    const bool ok = tex_pair_n(a, o, s1, s2);
+    const bool ok = tex_pair_n<RANGE_TEST>(a, o, s1, s2);
     const float q1 = __builtin_amdgcn_sqrtf(s1), q2 = __builtin_amdgcn_sqrtf(s2);
     const float diff = fabsf(q1 - q2);                                   // dist / 16
     const float slack = fmaxf(q1, q2) * 4.76837158e-7f;                  // 2^-21, as in pair_compatible
     if (fabsf(diff - 1.875f) > slack) return ok && diff < 1.875f;
     return ok && 16.0f * fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2)) < 30.0f;
+}
+
+// ---- minutiae lists whose pixel coordinates all lie in [0, 2047] (any image up to 2048 px): the reference's float arithmetic
+// dx*dx + dy*dy (matcher.cpp:1372-1385) is exact there (each square < 2^22, the sum < 2^23), so it equals the integer
+// v_dot2_i32_i16 of the packed differences; the rest is pair_dist / pair_compatible unchanged.
+__device__ __forceinline__ void minu_pair_n(int2 a, int2 o, float& s1, float& s2)
+{
+    const v2s16 dl = __builtin_bit_cast(v2s16, a.x) - __builtin_bit_cast(v2s16, o.x);
+    const v2s16 dr = __builtin_bit_cast(v2s16, a.y) - __builtin_bit_cast(v2s16, o.y);
+    s1 = (float)__builtin_amdgcn_sdot2(dl, dl, 0, false);
+    s2 = (float)__builtin_amdgcn_sdot2(dr, dr, 0, false);
+}
+__device__ __forceinline__ float minu_pair_dist(int2 a, int2 o)
+{
+    float s1, s2;
+    minu_pair_n(a, o, s1, s2);
+    return fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2));
+}
+__device__ __forceinline__ bool minu_pair_compatible(int2 a, int2 o)
+{
+    float s1, s2;
+    minu_pair_n(a, o, s1, s2);
+    const float d1 = __builtin_amdgcn_sqrtf(s1), d2 = __builtin_amdgcn_sqrtf(s2);
+    const float dist = fabsf(d1 - d2);
+    const float slack = fmaxf(d1, d2) * 4.76837158e-7f;                  // 2^-21, as in pair_compatible
+    if (fabsf(dist - 30.0f) > slack) return dist < 30.0f;
+    return fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2)) < 30.0f;
 }
 
 // H = clamp((30 - dist)/(25.0), 0, 1) for dist <= 30 (matcher.cpp:1268-1272 / :1389-1393): float numerator, double divide,
@@ -294,10 +325,14 @@ __device__ __forceinline__ float h_value(float dist)
 }
 
 // S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
-template <class SM, bool LOOKUP, int ITERS, bool PACKED>
+// MODE 0: generic arithmetic; 1: packed 16-bit coordinates (texture: with the |d| < 50 test); 2: texture, every coordinate in [0, 49]
+template <class SM, bool LOOKUP, int ITERS, int MODE>
 __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
 {
-    constexpr bool fast = LOOKUP && PACKED;
+    constexpr bool fast = MODE > 0;
+    constexpr bool range_test = MODE == 1;
+    auto compat_fast = [](int2 a, int2 o) -> bool { if (LOOKUP) return tex_pair_compatible<range_test>(a, o); return minu_pair_compatible(a, o); };
+    auto dist_fast = [](int2 a, int2 o) -> float { float d; if (LOOKUP) { tex_pair_dist<range_test>(a, o, d); return d; } return minu_pair_dist(a, o); };
     constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX, CACHE = SM::CACHE;
     constexpr int PH = LOOKUP ? 8 : 0;
     GPH_INIT();
@@ -321,7 +356,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
             const int t = lane + 64 * u;
             if (t < num && !(d == half && even && t >= half)) {       // even num: the antipodal pairs belong to the lower half
                 int k = t + d; if (k >= num) k -= num;
-                if (fast ? tex_pair_compatible(me[u], sm.xy[k]) : pair_compatible<LOOKUP>(unpack_xy(me[u]), unpack_xy(sm.xy[k]), table)) {
+                if (fast ? compat_fast(me[u], sm.xy[k]) : pair_compatible<LOOKUP>(unpack_xy(me[u]), unpack_xy(sm.xy[k]), table)) {
                     atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
                     atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
                 }
@@ -365,7 +400,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     // value and stashes the first CACHE of each row; later iterations read those back and recompute only the rest.
     auto value = [&](int2 own, int k) -> float {
         float dist;
-        if (fast) tex_pair_dist(own, sm.xy[k], dist);
+        if (fast) dist = dist_fast(own, sm.xy[k]);
         else pair_dist<LOOKUP>(unpack_xy(own), unpack_xy(sm.xy[k]), table, dist);
         return h_value(dist);
     };
@@ -417,10 +452,10 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     GPH(PH + 1);
     sort_scores(sm, num);
     GPH(PH + 2);
-    const int nsel = greedy(sm, num, 0.0001, [&sm, table](int a, int o) {
+    const int nsel = greedy(sm, num, 0.0001, [&sm, table, dist_fast](int a, int o) {
         if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
         float dist;
-        if (fast) tex_pair_dist(sm.xy[a], sm.xy[o], dist);
+        if (fast) dist = dist_fast(sm.xy[a], sm.xy[o]);
         else pair_dist<LOOKUP>(unpack_xy(sm.xy[a]), unpack_xy(sm.xy[o]), table, dist);
         return !((double)h_value(dist) < 0.00001);
     });
@@ -524,12 +559,14 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
 template <class SM, bool LOOKUP, int ITERS>
 __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
-                                             const float* __restrict__ rori, int& n_survivors, int stop_after = 2, bool packed_ok = false)
+                                             const float* __restrict__ rori, int& n_survivors, int stop_after = 2, int mode = 0)
 {
     n_survivors = num;                                                     // stop_after 0: the candidate list itself (S3 / S7)
     if (stop_after == 0) return 0.0f;
-    // two instantiations rather than a flag inside the loops: the register budget is that of the path taken
-    num = (LOOKUP && packed_ok) ? dist_filter<SM, LOOKUP, ITERS, true>(sm, num, table) : dist_filter<SM, LOOKUP, ITERS, false>(sm, num, table);
+    // instantiations rather than flags inside the loops: the register budget is that of the path taken
+    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2>(sm, num, table);
+    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table);
+    else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table);
     n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
     if (stop_after == 1) return 0.0f;
     n_survivors = 0;
@@ -625,17 +662,18 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             for (int t = lane; t < num; t += 64) { sm.sim[t] = rm_val[o + t]; sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
         }
         WSYNC();
-        int out_of_range = 0;                                            // any block coordinate outside [0, 8191]: generic arithmetic for this list
-        for (int t = lane; t < num; t += 64) {
+        int out_of_range = 0, not_small = 0;                             // any block coordinate outside [0, 8191]: generic arithmetic for this list;
+        for (int t = lane; t < num; t += 64) {                           // all inside [0, 49] (always, for real templates): no |d| < 50 test needed
             const int a = sm.li[t], b = sm.ri[t];
             const short2 lp = q.lt_xy[l0 + a], rp = g.tex_xy[r0 + b];
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
             out_of_range |= (lp.x | lp.y | rp.x | rp.y) & ~8191;
+            not_small |= ((unsigned)lp.x > 49u) | ((unsigned)lp.y > 49u) | ((unsigned)rp.x > 49u) | ((unsigned)rp.y > 49u);
         }
-        const bool packed_ok = __ballot(out_of_range != 0) == 0ull;
+        const int mode = __ballot(out_of_range != 0) != 0ull ? 0 : (__ballot(not_small != 0) == 0ull ? 2 : 1);
         WSYNC();
         int n_surv;
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv, tap.out ? tap.stage : 2, packed_ok);   // :759, :767
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, task, n_surv, kTopTex);
         WSYNC();
@@ -678,15 +716,18 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         if (num <= 0) { if (lane == 0) { *out = 0.0f; if (corr_n) corr_n[task] = 0; if (tap.out) tap.n[task] = -1; } continue; }   // matcher.cpp:400-404
         const int l0 = q.lm_off[qs], r0 = g.minu_off[gi];
         const MinuCand* c = cands + (size_t)task * kTopMinu;
+        int out_of_range = 0;                                            // any pixel coordinate outside [0, 2047]: generic float arithmetic
         for (int t = lane; t < num; t += 64) {
             const MinuCand cd = c[t];
             sm.sim[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
             const short2 lp = q.lm_xy[l0 + cd.li], rp = g.minu_xy[r0 + cd.ri];
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
+            out_of_range |= (lp.x | lp.y | rp.x | rp.y) & ~2047;
         }
+        const int mode = __ballot(out_of_range != 0) == 0ull ? 1 : 0;
         WSYNC();
         int n_surv;
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, n_surv, tap.out ? tap.stage : 2);   // :492, :495
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, n_surv, tap.out ? tap.stage : 2, mode);   // :492, :495
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, task, n_surv, kTopMinu);
         if (corr_out) {

@@ -863,3 +863,34 @@ def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
     m.set_option("adc_variant", 8); r8 = m.search([lat], k=0, want_parts=True)
     m.close()
     assert np.array_equal(r7["parts"].view(np.uint32), r8["parts"].view(np.uint32))
+
+
+def test_minutiae_coordinates_beyond_the_packed_path(codebook_bytes, cb, oracle):
+    """S8a arithmetic paths: pixel coordinates within [0, 2047] take the packed 16-bit predicate (v_pk_sub_i16 + v_dot2), anything larger
+    — here offsets of 2040 (straddling the limit), 5000 and 30000 — the generic float arithmetic, where dx*dx + dy*dy is no longer exact.
+    Stage lists of the three minutiae scorers and the scores against the oracle, bit for bit."""
+    rng = np.random.default_rng(33)
+    base = S.make_latent(rng, n_tex_lo=210, n_tex_hi=240)
+    ocb = oracle.codebook(codebook_bytes)
+    R0 = S.make_mate(rng, cb, base, frac=0.8, n_tex=300)
+    for ci, (off_l, off_r, scale) in enumerate(((0, 0, 1), (2040, 1500, 1), (5000, 4000, 3), (30000, 250, 1))):
+        def shift(m, off):
+            x = (m.x.astype(np.int64) * scale + off).astype(np.uint16).view(np.int16)
+            y = (m.y.astype(np.int64) * scale + off).astype(np.uint16).view(np.int16)
+            return T.MinutiaeTemplate(x, y, m.ori, m.des)
+        L = T.FPTemplate(minu=[shift(m_, off_l) for m_ in base.minu], tex=list(base.tex))
+        R = T.FPTemplate(minu=[shift(R0.minu[0], off_r)], tex=list(R0.tex))
+        m = M.Matcher(codebook_bytes); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
+        hl, _ = oracle.latent(ocb, T.write_latent(L)); hr, _ = oracle.rolled(T.write_rolled(R))
+        for which in (1, 2, 3):
+            for stage in (1, 2):
+                want = oracle.trace(ocb, hl, hr, which=which, stage=stage, tie_mode=1)
+                got = m.debug_stage_list(L, 0, which, stage)
+                assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (ci, which, stage)
+                assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (ci, which, stage)
+        rc, want_sc = oracle.pair(ocb, hl, hr, 1)
+        got_sc = m.search([L], k=0, want_parts=True)["parts"][0, 0]
+        assert np.array_equal(got_sc.view(np.uint32), want_sc[:4].view(np.uint32)), (ci, got_sc, want_sc)
+        if ci == 0:
+            assert want_sc[0] > 10
+        m.close()
