@@ -710,11 +710,18 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const u16x2 sum = kLast ? as_u16x2(as_u32(acc[k]) | inv) : acc[k];
-                    const s16x2 d = __builtin_bit_cast(s16x2, sum) - __builtin_bit_cast(s16x2, best[k]);       // both < 2^15: no overflow
-                    const uint32_t m = __builtin_bit_cast(uint32_t, d >> 15);                                   // 0xffff where sum < best
+                    // m = 0xffff in every half where sum < best (both < 2^15: the signed difference cannot overflow), then
+                    // bidx = m ? blk : bidx.  Written as the three instructions meant — left to itself the compiler turns the mask
+                    // arithmetic into two 16-bit compares and two selects per register (23 more VALU per block).  op_sel_hi:[0,1]: the
+                    // inline constant 15 has no high half, both lanes of the packed shift must take its low one
+                    uint32_t m;
+                    const uint32_t su = as_u32(sum), be = as_u32(best[k]);
+                    asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(m) : "v"(su), "v"(be));
                     if (kExact) sb[k] = __builtin_elementwise_min(sb[k], __builtin_elementwise_max(best[k], sum));       // the loser of (best, sum)
                     best[k] = __builtin_elementwise_min(best[k], sum);
-                    bidx[k] = (blkpk & m) | (bidx[k] & ~m);
+                    uint32_t bi = bidx[k];
+                    asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(bi) : "v"(m), "v"(blkpk));
+                    bidx[k] = bi;
                 }
             }
         };

@@ -30,16 +30,20 @@ namespace afis {
 #define AFIS_PI 3.1415926   /* matching/include.h:22 — a double literal; comparisons against it are in double */
 typedef unsigned long long u64;
 
-// optional per-phase cycle accounting (make PHASE_TIMING=1): slots 0..7 minutiae lists, 8..15 texture lists.  The counters
-// are global atomics, and a global LOAD that follows them (the orientation gather of the angle stage) waits for them to retire,
-// so that phase reads far too high; the distance stage's split (pair predicate ~25 %, power iterations ~60 %) is reliable.
+// optional per-phase cycle accounting (make PHASE_TIMING=1): slots 0..7 minutiae lists, 8..15 texture lists.  The stopwatch values are
+// accumulated in LDS (WaveSmem::ph) and flushed with one global atomic per slot at the end of the kernel: a global atomic inside
+// the loop stalls the global loads that follow it and distorts the phase it ends (round 1's timer did exactly that to the angle stage).
 #ifdef AFIS_PHASE_TIMING
 __device__ u64 g_graph_phase[16];
 #define GPH_INIT() u64 gph_t0 = __builtin_readcyclecounter()
-#define GPH(i) do { if (threadIdx.x == 0) { const u64 t1_ = __builtin_readcyclecounter(); atomicAdd(&g_graph_phase[(i)], t1_ - gph_t0); gph_t0 = t1_; } } while (0)
+#define GPH(i) do { if (threadIdx.x == 0) { const u64 t1_ = __builtin_readcyclecounter(); sm.ph[(i)] += t1_ - gph_t0; gph_t0 = t1_; } } while (0)
+#define GPH_ZERO() do { if (threadIdx.x < 16) sm.ph[threadIdx.x] = 0; WSYNC(); } while (0)
+#define GPH_FLUSH() do { WSYNC(); if (threadIdx.x < 16 && sm.ph[threadIdx.x]) atomicAdd(&g_graph_phase[threadIdx.x], sm.ph[threadIdx.x]); } while (0)
 #else
 #define GPH_INIT() do {} while (0)
 #define GPH(i) do {} while (0)
+#define GPH_ZERO() do {} while (0)
+#define GPH_FLUSH() do {} while (0)
 #endif
 
 __device__ __forceinline__ uint32_t g_ord_f32(float v)
@@ -80,6 +84,9 @@ struct __attribute__((aligned(16))) WaveSmem {
         struct { u64 keys[N4]; float tval[NMAX]; short te[NMAX], targ[NMAX]; } pick;   // texture rows picked by S7, before they are ranked
     } x;
     int nsel;
+#ifdef AFIS_PHASE_TIMING
+    u64 ph[16];
+#endif
 };
 
 // ranks (0 = largest) of this lane's U keys among keys[0..n); keys are unique
@@ -602,6 +609,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
 {
     __shared__ TexSmem sm;
     const int lane = threadIdx.x;
+    GPH_ZERO();
     const long long n_tasks = (long long)q.nq * g.G;
     for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         const int qi = (int)(task / g.G), gi = (int)(task - (long long)qi * g.G);
@@ -678,6 +686,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
         if (tap.out) tap_write(tap, sm, task, n_surv, kTopTex);
         WSYNC();
     }
+    GPH_FLUSH();
 }
 
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
@@ -705,6 +714,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
 {
     __shared__ MinuGraphSmem sm;
     const int lane = threadIdx.x;
+    GPH_ZERO();
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
         // task order as in k_minu_cands: gallery template fastest, then selected template, then query
@@ -739,6 +749,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         }
         WSYNC();
     }
+    GPH_FLUSH();
 }
 
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
