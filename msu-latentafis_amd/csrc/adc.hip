@@ -753,13 +753,20 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
             A[j] = min(A[j], (uint32_t)dpp_i<kRor4>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor4>((int)B[j]));
             A[j] = min(A[j], (uint32_t)dpp_i<kRor8>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor8>((int)B[j]));
         }
-        uint32_t mine = 0;                                     // lane r < 16 ends up with row r's key (lanes 0, 16, 32, 48 are pr = 0: A = rows 0..7)
+        // across the four rows of 16 lanes: row_bcast:15 (lane 15 of a row into the next row) and row_bcast:31 leave the minimum over
+        // all 64 lanes in lane 63 — an ODD lane (pr = 1: its A slots are rows 8..15, its B slots rows 0..7); only odd lanes feed it
+        uint32_t mine = 0;                                     // lane r < 16 ends up with row r's key
         uint32_t skey[16];                                     // wave-uniform
 #pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x142, 0xa, 0xf, false));
+            B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x142, 0xa, 0xf, false));
+            A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x143, 0xc, 0xf, false));
+            B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x143, 0xc, 0xf, false));
+        }
+#pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t x = r < 8 ? A[r] : B[r - 8];
-            const uint32_t s0 = __builtin_amdgcn_readlane(x, 0), s1 = __builtin_amdgcn_readlane(x, 16), s2 = __builtin_amdgcn_readlane(x, 32), s3 = __builtin_amdgcn_readlane(x, 48);
-            skey[r] = min(min(s0, s1), min(s2, s3));
+            skey[r] = (uint32_t)__builtin_amdgcn_readlane((int)(r < 8 ? B[r] : A[r - 8]), 63);
             if (lane == r) mine = skey[r];
         }
         const bool row_ok = lane < kQRows && row0 + lane < n_lt;
@@ -772,13 +779,14 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
             }
         } else {
             // exact similarity of (tile row r, point p of the current template), the reference's four chains (matcher.cpp:571-592)
+            const float* tile32 = lut32 + (size_t)(lt0 + row0) * (kM * kK);      // uniform: the fp32 table of the tile's 16 rows (64 K floats)
             auto exact_sim = [&](int r, int p) -> float {
                 const uint4 c = g.tex_codes[p0_cur + p];
-                const float* lr = lut32 + (size_t)(lt0 + row0 + r) * (kM * kK);
                 const uint32_t w4[4] = {c.x, c.y, c.z, c.w};
+                const uint32_t ro = (uint32_t)r * (uint32_t)(kM * kK);           // 32-bit offsets from the uniform base: no 64-bit address math
                 float l[16];
 #pragma unroll
-                for (int m = 0; m < 16; ++m) l[m] = lr[m * kK + ((w4[m >> 2] >> (8 * (m & 3))) & 255u)];
+                for (int m = 0; m < 16; ++m) l[m] = tile32[ro + (uint32_t)(m * kK) + ((w4[m >> 2] >> (8 * (m & 3))) & 255u)];
                 float d1 = 6.0f, d2 = 0.0f, d3 = 0.0f, d4 = 0.0f;
 #pragma unroll
                 for (int mg = 0; mg < 4; ++mg) { d1 -= l[4 * mg]; d2 -= l[4 * mg + 1]; d3 -= l[4 * mg + 2]; d4 -= l[4 * mg + 3]; }
