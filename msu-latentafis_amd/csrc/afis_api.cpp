@@ -1,5 +1,5 @@
 // afis_api.cpp — implementation of the C ABI in include/afis_matcher.h: gallery packing (SoA), upload, query
-// grouping and the launch sequence of the HIP kernels.  Host C++ only; device code lives in adc.hip / tail.hip.
+// grouping and the launch sequence of the HIP kernels.  Host C++ only; device code lives in adc.hip, minu.hip, graph.hip and pq_encode.hip.
 #include "../../include/afis_matcher.h"
 
 #include <algorithm>
