@@ -631,6 +631,21 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
 #pragma unroll
     for (int s = 0; s < 8; ++s) so[s] = 0x01000000u | (uint32_t)(((((s + pc) & 7) << 1) | pr) << 4);
     const char* lut_b = reinterpret_cast<const char*>(s_lut);
+    // kExact: candidate margins T_i = 18 + 1.5e-5 / q_i of the tile's 16 rows (see above), packed in this lane's slot order
+    uint32_t Tphys[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kExact) {
+        uint32_t T[16];
+#pragma unroll
+        for (int lr = 0; lr < 16; ++lr) {
+            const float qs = row0 + lr < n_lt ? rowc[lt0 + row0 + lr].y : 1.0f;
+            T[lr] = 18u + (uint32_t)fminf(1.5e-5f / qs, 28000.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ta = T[2 * i] | (T[2 * i + 1] << 16), tb = T[8 + 2 * i] | (T[9 + 2 * i] << 16);
+            Tphys[i] = pr ? tb : ta; Tphys[4 + i] = pr ? ta : tb;
+        }
+    }
     auto claim = [&]() -> int {
         int c = 0;
         if (lane == 0) c = atomicAdd(&s_next, 1);
@@ -727,57 +742,128 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
         };
         for (int blk = 0; blk + 1 < n_blocks; ++blk) block(blk, std::false_type{});
         block(n_blocks - 1, std::true_type{});
-        // ---- minimum over the 64 lanes: 32-bit keys (sum << 16 | point index) make "smallest sum, then first point" one v_min_u32 ----
-        // physical slots: A[j] (j < 8) = rows 8*pr + j, B[j] = rows 8*(pr^1) + j
-        uint32_t A[8], B[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t ba = as_u32(best[k]), bb = as_u32(best[k + 4]);
-            A[2 * k] = (ba << 16) | ((bidx[k] & 0xffffu) * 64u + (uint32_t)lane);
-            A[2 * k + 1] = (ba & 0xffff0000u) | ((bidx[k] >> 16) * 64u + (uint32_t)lane);
-            B[2 * k] = (bb << 16) | ((bidx[k + 4] & 0xffffu) * 64u + (uint32_t)lane);
-            B[2 * k + 1] = (bb & 0xffff0000u) | ((bidx[k + 4] >> 16) * 64u + (uint32_t)lane);
-        }
-        uint32_t A0[8], B0[8];                                 // this lane's own keys (kExact: candidate test after the reduction)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { A0[j] = A[j]; B0[j] = B[j]; }
         constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {                          // lane ^ 1 holds the same rows in its OTHER slot set
-            const uint32_t oa = (uint32_t)dpp_i<kXor1>((int)B[j]), ob = (uint32_t)dpp_i<kXor1>((int)A[j]);
-            A[j] = min(A[j], oa); B[j] = min(B[j], ob);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            A[j] = min(A[j], (uint32_t)dpp_i<kXor2>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kXor2>((int)B[j]));
-            A[j] = min(A[j], (uint32_t)dpp_i<kRor4>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor4>((int)B[j]));
-            A[j] = min(A[j], (uint32_t)dpp_i<kRor8>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor8>((int)B[j]));
-        }
-        // across the four rows of 16 lanes: row_bcast:15 (lane 15 of a row into the next row) and row_bcast:31 leave the minimum over
-        // all 64 lanes in lane 63 — an ODD lane (pr = 1: its A slots are rows 8..15, its B slots rows 0..7); only odd lanes feed it
-        uint32_t mine = 0;                                     // lane r < 16 ends up with row r's key
-        uint32_t skey[16];                                     // wave-uniform
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x142, 0xa, 0xf, false));
-            B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x142, 0xa, 0xf, false));
-            A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x143, 0xc, 0xf, false));
-            B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x143, 0xc, 0xf, false));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            skey[r] = (uint32_t)__builtin_amdgcn_readlane((int)(r < 8 ? B[r] : A[r - 8]), 63);
-            if (lane == r) mine = skey[r];
-        }
         const bool row_ok = lane < kQRows && row0 + lane < n_lt;
-        const float2 rc = row_ok ? rowc[lt0 + row0 + lane] : make_float2(0.f, 1.f);
-        if (!kExact) {
+        if constexpr (!kExact) {
+            // ---- minimum over the 64 lanes: 32-bit keys (sum << 16 | point index) make "smallest sum, then first point" one v_min_u32 ----
+            // physical slots: A[j] (j < 8) = rows 8*pr + j, B[j] = rows 8*(pr^1) + j
+            uint32_t A[8], B[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t ba = as_u32(best[k]), bb = as_u32(best[k + 4]);
+                A[2 * k] = (ba << 16) | ((bidx[k] & 0xffffu) * 64u + (uint32_t)lane);
+                A[2 * k + 1] = (ba & 0xffff0000u) | ((bidx[k] >> 16) * 64u + (uint32_t)lane);
+                B[2 * k] = (bb << 16) | ((bidx[k + 4] & 0xffffu) * 64u + (uint32_t)lane);
+                B[2 * k + 1] = (bb & 0xffff0000u) | ((bidx[k + 4] >> 16) * 64u + (uint32_t)lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                      // lane ^ 1 holds the same rows in its OTHER slot set
+                const uint32_t oa = (uint32_t)dpp_i<kXor1>((int)B[j]), ob = (uint32_t)dpp_i<kXor1>((int)A[j]);
+                A[j] = min(A[j], oa); B[j] = min(B[j], ob);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                A[j] = min(A[j], (uint32_t)dpp_i<kXor2>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kXor2>((int)B[j]));
+                A[j] = min(A[j], (uint32_t)dpp_i<kRor4>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor4>((int)B[j]));
+                A[j] = min(A[j], (uint32_t)dpp_i<kRor8>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor8>((int)B[j]));
+                // across the four rows of 16 lanes: row_bcast:15 / row_bcast:31 leave the minimum over all 64 lanes in lane 63 — an ODD
+                // lane (pr = 1: its A slots are rows 8..15, its B slots rows 0..7); only odd lanes feed it
+                A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x142, 0xa, 0xf, false));
+                B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x142, 0xa, 0xf, false));
+                A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x143, 0xc, 0xf, false));
+                B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x143, 0xc, 0xf, false));
+            }
+            uint32_t mine = 0;                                 // lane r < 16 ends up with row r's key
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)(r < 8 ? B[r] : A[r - 8]), 63);
+                if (lane == r) mine = sk;
+            }
             if (row_ok) {
+                const float2 rc = rowc[lt0 + row0 + lane];
                 const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
                 rm_val[o] = rc.x - rc.y * (float)(mine >> 16);
                 rm_arg[o] = (int32_t)(mine & 0xffffu);
             }
         } else {
+            // ---- exact tail.  (1) the packed minimum S* of the 16 row sums over the wave (no indices: 8 registers instead of 16 keys) ----
+            auto pkmin = [](uint32_t x, uint32_t y) { return as_u32(__builtin_elementwise_min(as_u16x2(x), as_u16x2(y))); };
+            uint32_t Mn[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) Mn[k] = as_u32(best[k]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                      // lane ^ 1 holds the same rows in its OTHER slot set
+                const uint32_t t1 = (uint32_t)dpp_i<kXor1>((int)Mn[j + 4]), t2 = (uint32_t)dpp_i<kXor1>((int)Mn[j]);
+                Mn[j] = pkmin(Mn[j], t1); Mn[j + 4] = pkmin(Mn[j + 4], t2);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                Mn[k] = pkmin(Mn[k], (uint32_t)dpp_i<kXor2>((int)Mn[k]));
+                Mn[k] = pkmin(Mn[k], (uint32_t)dpp_i<kRor4>((int)Mn[k]));
+                Mn[k] = pkmin(Mn[k], (uint32_t)dpp_i<kRor8>((int)Mn[k]));
+                Mn[k] = pkmin(Mn[k], (uint32_t)__builtin_amdgcn_update_dpp(0x7fff7fff, (int)Mn[k], 0x142, 0xa, 0xf, false));   // row_bcast:15
+                Mn[k] = pkmin(Mn[k], (uint32_t)__builtin_amdgcn_update_dpp(0x7fff7fff, (int)Mn[k], 0x143, 0xc, 0xf, false));   // row_bcast:31
+            }
+            // lane 63 holds the minimum over the wave, in the slot order of an ODD lane (slots 0..3 = rows 8..15, 4..7 = rows 0..7)
+            uint32_t s63[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s63[k] = (uint32_t)__builtin_amdgcn_readlane((int)Mn[k], 63);
+            // (2) thresholds S* + T in this lane's slot order, (3) per-half masks: candidate = smallest sum <= threshold, second-sum hit
+            // Masks are kept INVERTED (0xffff in a half = "no": smallest sum > threshold / second sum > threshold), which is what the
+            // sign-propagating shift of (threshold - sum) gives directly; written as the two instructions meant (see the block loop).
+            uint32_t thr[8], candm[8], nsb_all = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = pr ? s63[j] : s63[j + 4], hi = pr ? s63[j + 4] : s63[j];
+                thr[j] = as_u32(__builtin_elementwise_min(as_u16x2(lo) + as_u16x2(Tphys[j]), as_u16x2(0x7fff7fffu)));
+                thr[j + 4] = as_u32(__builtin_elementwise_min(as_u16x2(hi) + as_u16x2(Tphys[j + 4]), as_u16x2(0x7fff7fffu)));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t t = thr[k], be = as_u32(best[k]), se = as_u32(sb[k]);
+                uint32_t nc, ns;                                                                                // thr - x < 0  <=>  x > thr (all < 2^15)
+                asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(nc) : "v"(t), "v"(be));
+                asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(ns) : "v"(t), "v"(se));
+                candm[k] = nc;
+                nsb_all &= ns;
+            }
+            const bool any_sb = __ballot(nsb_all != 0xffffffffu) != 0ull;                                       // uniform; about 1 template-tile in 100
+            // the same registers in LOGICAL row order (identical for every lane): [i] = rows 2i, 2i+1 (i < 4), [4 + i] = rows 8 + 2i, 9 + 2i
+            uint32_t candL[8], bidxL[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                candL[i] = pr ? candm[4 + i] : candm[i]; candL[4 + i] = pr ? candm[i] : candm[4 + i];
+                bidxL[i] = pr ? bidx[4 + i] : bidx[i];   bidxL[4 + i] = pr ? bidx[i] : bidx[4 + i];
+            }
+            // (4) per row: the candidate lanes (one ballot); exactly one -> its point goes to lane r; otherwise a slow row
+            uint32_t slow_rows = 0, sb_rows = 0;
+            int myp = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t reg = candL[r >> 1];
+                const unsigned long long cm = __ballot(((r & 1) ? (reg >> 16) : (reg & 0xffffu)) == 0u);         // inverted mask: 0 = candidate
+                const int L = (int)__ffsll((long long)cm) - 1;                                                 // wave-uniform
+                const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)bidxL[r >> 1], L & 63);
+                const int p = (int)((r & 1) ? (bw >> 16) : (bw & 0xffffu)) * 64 + L;
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(myp) : "s"(p), "n"(r));                                  // lane r <- p (p is wave-uniform)
+                if (row0 + r < n_lt && __popcll(cm) != 1) slow_rows |= 1u << r;
+            }
+            if (any_sb) {                                                                                       // rare: which rows have a second-sum hit
+                uint32_t sbL[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const s16x2 d0 = __builtin_bit_cast(s16x2, thr[i]) - __builtin_bit_cast(s16x2, sb[i]);
+                    const s16x2 d1 = __builtin_bit_cast(s16x2, thr[4 + i]) - __builtin_bit_cast(s16x2, sb[4 + i]);
+                    const uint32_t h0 = __builtin_bit_cast(uint32_t, d0 >> 15), h1 = __builtin_bit_cast(uint32_t, d1 >> 15);   // inverted: 0 = hit
+                    sbL[i] = pr ? h1 : h0; sbL[4 + i] = pr ? h0 : h1;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t reg = sbL[r >> 1];
+                    if (row0 + r < n_lt && __ballot(((r & 1) ? (reg >> 16) : (reg & 0xffffu)) == 0u) != 0ull) sb_rows |= 1u << r;
+                }
+                slow_rows |= sb_rows;
+            }
             // exact similarity of (tile row r, point p of the current template), the reference's four chains (matcher.cpp:571-592)
             const float* tile32 = lut32 + (size_t)(lt0 + row0) * (kM * kK);      // uniform: the fp32 table of the tile's 16 rows (64 K floats)
             auto exact_sim = [&](int r, int p) -> float {
@@ -792,39 +878,24 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
                 for (int mg = 0; mg < 4; ++mg) { d1 -= l[4 * mg]; d2 -= l[4 * mg + 1]; d3 -= l[4 * mg + 2]; d4 -= l[4 * mg + 3]; }
                 return (d1 + d2) + (d3 + d4);
             };
-            // fast path: lane r evaluates the arg-min of row r
+            // (5) fast path: lane r evaluates the single candidate of row r
             float out_v = 0.f; int out_i = 0;
-            if (row_ok) { out_i = (int)(mine & 0xffffu); out_v = exact_sim(lane, out_i); }
-            // candidate census per row (uniform): more than one lane within S* + T, or any second-smallest sum within it -> slow row
-            const int Tl = row_ok ? 18 + (int)fminf(1.5e-5f / rc.y, 30000.0f) : 0;
-            uint32_t slow_rows = 0, sb_rows = 0;
-            uint32_t myk[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool in_a = pr == (r >> 3);
-                myk[r] = in_a ? A0[r & 7] : B0[r & 7];
-                const uint32_t sbp = as_u32(in_a ? sb[(r & 7) >> 1] : sb[4 + ((r & 7) >> 1)]);
-                const uint32_t mysb = (r & 1) ? (sbp >> 16) : (sbp & 0xffffu);
-                const uint32_t thr = min((skey[r] >> 16) + (uint32_t)__builtin_amdgcn_readlane(Tl, r), 0x7fffu);
-                const unsigned long long cm = __ballot(myk[r] <= ((thr << 16) | 0xffffu));
-                const unsigned long long sm2 = __ballot(mysb <= thr);
-                const bool valid = row0 + r < n_lt;                                 // uniform
-                if (valid && (sm2 != 0ull || __popcll(cm) != 1)) slow_rows |= 1u << r;
-                if (valid && sm2 != 0ull) sb_rows |= 1u << r;
-            }
-            while (slow_rows) {                                                    // uniform loop over the rare rows
+            if (row_ok) { out_i = myp; out_v = exact_sim(lane, myp); }
+            // (6) the rare rows: several candidate lanes, or a second-sum hit (then every point of the row)
+            while (slow_rows) {                                                    // uniform loop
                 const int r = __ffs(slow_rows) - 1;
                 slow_rows &= slow_rows - 1;
-                const uint32_t thr = min((skey[r] >> 16) + (uint32_t)__builtin_amdgcn_readlane(Tl, r), 0x7fffu);
-                float v = -INFINITY; int i = 0x7fffffff;
-                // myk[] is indexed by a runtime r: fetch it through a select chain (registers cannot be indexed dynamically)
-                uint32_t mk = 0;
+                const int li = ((r >> 3) << 2) | ((r & 7) >> 1);                   // logical register index of row r (runtime: select chains)
+                uint32_t cw = 0, bw = 0;
 #pragma unroll
-                for (int t = 0; t < 16; ++t) mk = (t == r) ? myk[t] : mk;
+                for (int t = 0; t < 8; ++t) { cw = (t == li) ? candL[t] : cw; bw = (t == li) ? bidxL[t] : bw; }
+                const bool cand = ((r & 1) ? (cw >> 16) : (cw & 0xffffu)) == 0u;                         // inverted mask
+                const int p = (int)((r & 1) ? (bw >> 16) : (bw & 0xffffu)) * 64 + lane;
+                float v = -INFINITY; int i = 0x7fffffff;
                 if ((sb_rows >> r) & 1u) {                                         // two points of one lane within the threshold: every point, exactly
-                    for (int p = lane; p < n_cur; p += 64) { const float e = exact_sim(r, p); if (e > v) { v = e; i = p; } }
-                } else if (mk <= ((thr << 16) | 0xffffu) && (int)(mk & 0xffffu) < n_cur) {   // this lane's smallest sum is a candidate (and a real point)
-                    i = (int)(mk & 0xffffu); v = exact_sim(r, i);
+                    for (int pp = lane; pp < n_cur; pp += 64) { const float e = exact_sim(r, pp); if (e > v) { v = e; i = pp; } }
+                } else if (cand && p < n_cur) {                                    // this lane's smallest sum is a candidate (and a real point)
+                    i = p; v = exact_sim(r, p);
                 }
                 wave_argmax(v, i);                                                 // value descending, point index ascending: the FIRST maximum
                 if (lane == r) { out_v = v; out_i = i; }
