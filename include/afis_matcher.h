@@ -213,6 +213,13 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
  * [-R, R]^2: out[(dy + R) * (2R + 1) + (dx + R)] = line angle atan2(dy, dx) as the device evaluates it.  R <= 4096. */
 int afis_debug_atan2_grid(afis_ctx* ctx, int R, float* out);
 
+/* S8: the distance stage's packed arithmetic (csrc/graph_arith.h: a one-transcendental correctly rounded square root of integers and
+ * a square-root-free "H != 0" test with a guard band) against the plain evaluation of matching/matcher.cpp:1246-1272, :1372-1393 that
+ * it replaces, on the device.  out8[0] = integers n in [0, 2*2047^2] whose root differs; out8[1..3] = texture pairs checked (all of
+ * [0, 4802]^2), pairs inside the guard band, wrong decisions; out8[4..6] = the same for minutiae pairs near the 30 px threshold
+ * (4e8 of them).  out8[0], [3], [6] must be 0. */
+int afis_debug_graph_arith(afis_ctx* ctx, unsigned long long* out8);
+
 /* In-kernel phase timers (only when the library is built with PHASE_TIMING=1; all zeros otherwise): 32 cycle counters
  * accumulated since the last reset.  Development aid. */
 int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset);

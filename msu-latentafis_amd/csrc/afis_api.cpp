@@ -948,6 +948,20 @@ int afis_debug_atan2_grid(afis_ctx* ctx, int R, float* out)
     return AFIS_OK;
 }
 
+int afis_debug_graph_arith(afis_ctx* ctx, unsigned long long* out8)
+{
+    if (!ctx || !out8) return fail(ctx, AFIS_EINVAL, "afis_debug_graph_arith: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    HIPCHK(ctx, d.ensure(64));
+    hipError_t e = launch_debug_graph_arith(d.as<unsigned long long>(), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out8, d.p, 64, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e != hipSuccess) return fail(ctx, AFIS_EDEVICE, std::string("afis_debug_graph_arith: ") + hipGetErrorString(e));
+    return AFIS_OK;
+}
+
 int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, int32_t* n_rows)
 {
     if (!ctx || !query || !out) return fail(ctx, AFIS_EINVAL, "afis_debug_lut: null argument");

@@ -119,6 +119,7 @@ hipError_t read_graph_phase_cycles(unsigned long long* out16, bool reset);
 
 // debug tap: the angle stage's atan2 on the integer grid [-R, R]^2, out[(dy + R) * (2R + 1) + (dx + R)] (device pointer)
 hipError_t launch_debug_atan2_grid(int R, float* out, hipStream_t stream);
+hipError_t launch_debug_graph_arith(unsigned long long* cnt8, hipStream_t stream);
 // debug tap: LUT in the reference layout [n][16][256]
 hipError_t launch_lut_reference_layout(const float* des, int n, const float* codewords, float* out, hipStream_t stream);
 

@@ -24,6 +24,7 @@
 //                                        demand and cached per row; a zero entry would only add +0.0f, so skipping it is exact.
 #include "afis_device.h"
 #include "atan2f_libm.h"
+#include "graph_arith.h"
 
 namespace afis {
 
@@ -266,67 +267,37 @@ __device__ __forceinline__ bool pair_compatible(const Pt& a, const Pt& o, const 
 // packed (x | y << 16) words as they sit in LDS.  One v_pk_sub_i16 gives (dx, dy), one v_dot2_i32_i16 gives n = dx^2 + dy^2
 // (<= 4802 for an in-range pair), and table_dist[dx*50+dy] = RN(sqrt(256 n)) = 16 * RN(sqrt(n)) because scaling by a power of
 // two commutes with every rounding involved: dist = |d1 - d2| = 16 * |RN(sqrt n1) - RN(sqrt n2)| exactly.
-typedef short v2s16 __attribute__((ext_vector_type(2)));
-typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
-template <bool RANGE_TEST>
-__device__ __forceinline__ bool tex_pair_n(int2 a, int2 o, float& s1, float& s2)
-{
-    const v2s16 dl = __builtin_bit_cast(v2s16, a.x) - __builtin_bit_cast(v2s16, o.x);
-    const v2s16 dr = __builtin_bit_cast(v2s16, a.y) - __builtin_bit_cast(v2s16, o.y);
-    s1 = (float)__builtin_amdgcn_sdot2(dl, dl, 0, false);
-    s2 = (float)__builtin_amdgcn_sdot2(dr, dr, 0, false);
-    if (!RANGE_TEST) return true;                                        // every coordinate of the list is in [0, 49]: |d| < 50 always
-    // |d| < 50 for all four components (matcher.cpp:1257)  <=>  (d + 49) as u16 <= 98
-    const v2u16 bias = {49, 49};
-    const v2u16 tl = __builtin_bit_cast(v2u16, dl) + bias, tr = __builtin_bit_cast(v2u16, dr) + bias;
-    const v2u16 mx = __builtin_elementwise_max(tl, tr);
-    return max((unsigned)mx.x, (unsigned)mx.y) <= 98u;
-}
 template <bool RANGE_TEST>
 __device__ __forceinline__ bool tex_pair_dist(int2 a, int2 o, float& dist)
 {
-    float s1, s2;
-    const bool ok = tex_pair_n<RANGE_TEST>(a, o, s1, s2);
-    dist = 16.0f * fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2));
-    return ok;
+    float n1, n2;
+    pair_n(a, o, n1, n2);
+    dist = 16.0f * fabsf(sqrt_rn_int(n1) - sqrt_rn_int(n2));
+    return RANGE_TEST ? tex_in_range(a, o) : true;
 }
 template <bool RANGE_TEST>
 __device__ __forceinline__ bool tex_pair_compatible(int2 a, int2 o)
 {
-    float s1, s2;
-    const bool ok = tex_pair_n<RANGE_TEST>(a, o, s1, s2);
-    const float q1 = __builtin_amdgcn_sqrtf(s1), q2 = __builtin_amdgcn_sqrtf(s2);
-    const float diff = fabsf(q1 - q2);                                   // dist / 16
-    const float slack = fmaxf(q1, q2) * 4.76837158e-7f;                  // 2^-21, as in pair_compatible
-    if (fabsf(diff - 1.875f) > slack) return ok && diff < 1.875f;
-    return ok && 16.0f * fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2)) < 30.0f;
+    float n1, n2;
+    pair_n(a, o, n1, n2);
+    const bool ok = RANGE_TEST ? tex_in_range(a, o) : true;              // out of range: n may exceed 2^24, the answer is masked
+    return pair_compatible_n<true>(n1, n2) && ok;
 }
 
 // ---- minutiae lists whose pixel coordinates all lie in [0, 2047] (any image up to 2048 px): the reference's float arithmetic
 // dx*dx + dy*dy (matcher.cpp:1372-1385) is exact there (each square < 2^22, the sum < 2^23), so it equals the integer
-// v_dot2_i32_i16 of the packed differences; the rest is pair_dist / pair_compatible unchanged.
-__device__ __forceinline__ void minu_pair_n(int2 a, int2 o, float& s1, float& s2)
-{
-    const v2s16 dl = __builtin_bit_cast(v2s16, a.x) - __builtin_bit_cast(v2s16, o.x);
-    const v2s16 dr = __builtin_bit_cast(v2s16, a.y) - __builtin_bit_cast(v2s16, o.y);
-    s1 = (float)__builtin_amdgcn_sdot2(dl, dl, 0, false);
-    s2 = (float)__builtin_amdgcn_sdot2(dr, dr, 0, false);
-}
+// v_dot2_i32_i16 of the packed differences.
 __device__ __forceinline__ float minu_pair_dist(int2 a, int2 o)
 {
-    float s1, s2;
-    minu_pair_n(a, o, s1, s2);
-    return fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2));
+    float n1, n2;
+    pair_n(a, o, n1, n2);
+    return fabsf(sqrt_rn_int(n1) - sqrt_rn_int(n2));
 }
 __device__ __forceinline__ bool minu_pair_compatible(int2 a, int2 o)
 {
-    float s1, s2;
-    minu_pair_n(a, o, s1, s2);
-    const float d1 = __builtin_amdgcn_sqrtf(s1), d2 = __builtin_amdgcn_sqrtf(s2);
-    const float dist = fabsf(d1 - d2);
-    const float slack = fmaxf(d1, d2) * 4.76837158e-7f;                  // 2^-21, as in pair_compatible
-    if (fabsf(dist - 30.0f) > slack) return dist < 30.0f;
-    return fabsf(sqrt_rn_pos(s1) - sqrt_rn_pos(s2)) < 30.0f;
+    float n1, n2;
+    pair_n(a, o, n1, n2);
+    return pair_compatible_n<false>(n1, n2);
 }
 
 // H = clamp((30 - dist)/(25.0), 0, 1) for dist <= 30 (matcher.cpp:1268-1272 / :1389-1393): float numerator, double divide,
@@ -338,9 +309,8 @@ __device__ __forceinline__ float h_value(float dist)
     const float x = 30.0f - dist;
     const float q0 = x * 0.04f;
     const float r = fmaf(-q0, 25.0f, x);
-    float h = fmaf(r, 0.04f, q0);
-    if (h > 1.0f) h = 1.0f; else if (h < 0.0f) h = 0.0f;
-    return h;
+    const float h = fmaf(r, 0.04f, q0);
+    return __builtin_amdgcn_fmed3f(h, 0.0f, 1.0f);                       // h is never NaN here; clamp to [0, 1] in one instruction
 }
 
 // S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
@@ -353,7 +323,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     auto compat_fast = [](int2 a, int2 o) -> bool { if (LOOKUP) return tex_pair_compatible<range_test>(a, o); return minu_pair_compatible(a, o); };
     auto dist_fast = [](int2 a, int2 o) -> float { float d; if (LOOKUP) { tex_pair_dist<range_test>(a, o, d); return d; } return minu_pair_dist(a, o); };
     constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX, CACHE = SM::CACHE;
-    constexpr int PH = LOOKUP ? 8 : 0;
+    [[maybe_unused]] constexpr int PH = LOOKUP ? 8 : 0;
     GPH_INIT();
     const int lane = threadIdx.x;
     for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
@@ -369,17 +339,40 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     // (t, t+d mod num), d = 1..num/2, so every unordered pair is evaluated once.  H != 0  <=>  in range and dist < 30.
     const int half = num >> 1;
     const bool even = !(num & 1);
-    for (int d = 1; d <= half; ++d) {
+    uint32_t* const hb0 = &sm.hb[0][0];
+    auto pair = [&](int2 own, int t, int k) {
+        if (fast ? compat_fast(own, sm.xy[k]) : pair_compatible<LOOKUP>(unpack_xy(own), unpack_xy(sm.xy[k]), table)) {
+            atomicOr(hb0 + (t * W + (k >> 5)), 1u << (k & 31));
+            atomicOr(hb0 + (__umul24(k, W) + (t >> 5)), 1u << (t & 31));
+        }
+    };
+    // The last block of 64 rows is usually far from full (a texture list has 200 rows: 8 in its fourth block).  When it holds <= 32
+    // rows, its lanes are split into 64/RG groups that take different offsets d of the same RG rows, instead of idling.
+    const int tail0 = num & ~63, R = num - tail0;
+    const bool grouped = R > 0 && R <= 32;
+    const int n_wide = grouped ? tail0 : num;                             // rows handled one per lane and block
+    int kk[U];                                                            // t + d (mod num), kept incrementally: add, compare, select
+#pragma unroll
+    for (int u = 0; u < U; ++u) kk[u] = lane + 64 * u;
+    for (int d = 1; n_wide > 0 && d <= half; ++d) {
+        const bool last = d == half && even;                              // even num: the antipodal pairs belong to the lower half
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = lane + 64 * u;
-            if (t < num && !(d == half && even && t >= half)) {       // even num: the antipodal pairs belong to the lower half
-                int k = t + d; if (k >= num) k -= num;
-                if (fast ? compat_fast(me[u], sm.xy[k]) : pair_compatible<LOOKUP>(unpack_xy(me[u]), unpack_xy(sm.xy[k]), table)) {
-                    atomicOr(&sm.hb[t][k >> 5], 1u << (k & 31));
-                    atomicOr(&sm.hb[k][t >> 5], 1u << (t & 31));
-                }
-            }
+            int k = kk[u] + 1; k = k == num ? 0 : k; kk[u] = k;
+            if (t < n_wide && !(last && t >= half)) pair(me[u], t, k);
+        }
+    }
+    if (grouped) {
+        const int sh = R <= 8 ? 3 : R <= 16 ? 4 : 5, RG = 1 << sh, dstep = 64 >> sh;
+        const int r = lane & (RG - 1), t = tail0 + r;
+        const bool row = r < R;
+        const int2 own = row ? sm.xy[t] : make_int2(0, 0);
+        int d = 1 + (lane >> sh);
+        int k = t + d; k = k >= num ? k - num : k;                        // d <= half < num: one wrap
+        for (int d0 = 1; d0 <= half; d0 += dstep) {
+            if (row && d <= half && !(d == half && even && t >= half)) pair(own, t, k);
+            d += dstep; k += dstep; k = k >= num ? k - num : k;           // exact while d <= half (k < num + dstep <= 2 num there)
         }
     }
     WSYNC();
@@ -561,7 +554,7 @@ template <class SM>
 __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori)
 {
     constexpr int W = SM::W;
-    constexpr int PH = SM::NMAX > 128 ? 8 : 0;
+    [[maybe_unused]] constexpr int PH = SM::NMAX > 128 ? 8 : 0;
     GPH_INIT();
     const int lane = threadIdx.x;
     for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
@@ -569,18 +562,36 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
     const float s0 = (float)(1.0 / num);                                   // :1558
     for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.y.cc[t] = 0.0f; }
     WSYNC();
-    // row t visits the pairs (t, t+d mod num), d = 1..num/2: every unordered pair once, evaluated as (lower, higher) index
+    // row t visits the pairs (t, t+d mod num), d = 1..num/2: every unordered pair once, evaluated as (lower, higher) index.
+    // Survivor lists are short (usually < 32): the lanes of a partial block of <= 32 rows are split into groups that take different
+    // offsets d of the same rows, as in dist_filter.
     const int half = num >> 1;
     const bool even = !(num & 1);
-    for (int d = 1; d <= half; ++d) {
-        for (int t = lane; t < num; t += 64) {
+    auto pair = [&](int t, int k) {
+        const int i = t < k ? t : k, j = t < k ? k : t;
+        if (angle_compatible(unpack_xy(sm.xy[i]), sm.x.s.lo[i], sm.x.s.ro[i], unpack_xy(sm.xy[j]), sm.x.s.lo[j], sm.x.s.ro[j])) {
+            atomicOr(&sm.hb[i][j >> 5], 1u << (j & 31));
+            atomicOr(&sm.hb[j][i >> 5], 1u << (i & 31));
+        }
+    };
+    const int tail0 = num & ~63, R = num - tail0;
+    const bool grouped = R > 0 && R <= 32;
+    const int n_wide = grouped ? tail0 : num;
+    for (int d = 1; n_wide > 0 && d <= half; ++d) {
+        for (int t = lane; t < n_wide; t += 64) {
             if (d == half && even && t >= half) continue;
             int k = t + d; if (k >= num) k -= num;
-            const int i = t < k ? t : k, j = t < k ? k : t;
-            if (angle_compatible(unpack_xy(sm.xy[i]), sm.x.s.lo[i], sm.x.s.ro[i], unpack_xy(sm.xy[j]), sm.x.s.lo[j], sm.x.s.ro[j])) {
-                atomicOr(&sm.hb[i][j >> 5], 1u << (j & 31));
-                atomicOr(&sm.hb[j][i >> 5], 1u << (i & 31));
-            }
+            pair(t, k);
+        }
+    }
+    if (grouped) {
+        const int sh = R <= 8 ? 3 : R <= 16 ? 4 : 5, RG = 1 << sh, dstep = 64 >> sh;
+        const int r = lane & (RG - 1), t = tail0 + r;
+        int d = 1 + (lane >> sh);
+        int k = t + d; k = k >= num ? k - num : k;
+        for (int d0 = 1; d0 <= half; d0 += dstep) {
+            if (r < R && d <= half && !(d == half && even && t >= half)) pair(t, k);
+            d += dstep; k += dstep; k = k >= num ? k - num : k;
         }
     }
     WSYNC();
@@ -643,7 +654,7 @@ __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, lon
 // texture lists: S7 (top-200 rows of the ADC row maxima) + S8b + S9
 // =====================================================================================================================
 #ifndef AFIS_TEX_CACHE
-#define AFIS_TEX_CACHE 3
+#define AFIS_TEX_CACHE 4
 #endif
 typedef WaveSmem<kTopTex, AFIS_TEX_CACHE> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
@@ -820,6 +831,52 @@ hipError_t launch_debug_atan2_grid(int R, float* out, hipStream_t stream)
 {
     const long long n = (long long)(2 * R + 1) * (2 * R + 1);
     hipLaunchKernelGGL(k_debug_atan2_grid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, R, out);
+    return hipGetLastError();
+}
+
+// parity tap: the packed paths' arithmetic (graph_arith.h) against the straightforward evaluation it replaces.
+//   part 0: sqrt_rn_int(n) vs sqrt_rn_pos(n), every integer n in [0, 2 * 2047^2]                      -> cnt[0] = mismatches
+//   part 1: texture "H != 0", every (n1, n2) in [0, 4802]^2                                            -> cnt[1..3] = pairs, inside the band, wrong outside it
+//   part 2: minutiae "H != 0", n1 over [0, 2 * 2047^2], n2 within +-12 of (sqrt n1 +- 30)^2            -> cnt[4..6]
+__device__ __forceinline__ void arith_check(bool tex, float f1, float f2, unsigned long long* cnt)
+{
+    const float d = fabsf(sqrt_rn_pos(f1) - sqrt_rn_pos(f2));
+    const bool ref = tex ? 16.0f * d < 30.0f : d < 30.0f;
+    const int a = tex ? pair_compatible_alg<true>(f1, f2) : pair_compatible_alg<false>(f1, f2);
+    const bool full = tex ? pair_compatible_n<true>(f1, f2) : pair_compatible_n<false>(f1, f2);
+    atomicAdd(cnt + 0, 1ull);
+    if (a == 2) atomicAdd(cnt + 1, 1ull);
+    if ((a != 2 && (a == 1) != ref) || full != ref) atomicAdd(cnt + 2, 1ull);
+}
+__global__ __launch_bounds__(256) void k_debug_graph_arith(int part, unsigned long long* __restrict__ cnt)
+{
+    constexpr unsigned kMaxN = 2u * 2047u * 2047u;
+    if (part == 0) {
+        const unsigned n = blockIdx.x * 256u + threadIdx.x;
+        if (n <= kMaxN && __float_as_uint(sqrt_rn_int((float)n)) != __float_as_uint(sqrt_rn_pos((float)n))) atomicAdd(cnt, 1ull);
+    } else if (part == 1) {
+        const unsigned n1 = blockIdx.x, n2 = blockIdx.y * 256u + threadIdx.x;
+        if (n1 <= 4802u && n2 <= 4802u) arith_check(true, (float)n1, (float)n2, cnt + 1);
+    } else {
+        const unsigned n1 = blockIdx.x * 256u + threadIdx.x;
+        if (n1 > kMaxN) return;
+        const double a = sqrt((double)n1);
+        for (int sg = -1; sg <= 1; sg += 2) {
+            const double b = a + 30.0 * sg;
+            if (b < 0) continue;
+            const long long c = (long long)(b * b + 0.5);
+            for (int j = -12; j <= 12; ++j) { const long long n2 = c + j; if (n2 >= 0 && n2 <= (long long)kMaxN) arith_check(false, (float)n1, (float)n2, cnt + 4); }
+        }
+    }
+}
+hipError_t launch_debug_graph_arith(unsigned long long* cnt8, hipStream_t stream)
+{
+    constexpr unsigned kMaxN = 2u * 2047u * 2047u;
+    hipError_t e = hipMemsetAsync(cnt8, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_debug_graph_arith, dim3((kMaxN + 256) / 256), dim3(256), 0, stream, 0, cnt8);
+    hipLaunchKernelGGL(k_debug_graph_arith, dim3(4803, 19), dim3(256), 0, stream, 1, cnt8);
+    hipLaunchKernelGGL(k_debug_graph_arith, dim3((kMaxN + 256) / 256), dim3(256), 0, stream, 2, cnt8);
     return hipGetLastError();
 }
 

@@ -1,0 +1,76 @@
+// graph_arith.h — the arithmetic of the graph kernels' packed paths (graph.hip), in a header of its own so that
+// tools/ubench/graph_arith.hip checks exactly this code against the straightforward evaluation (exhaustively where the domain allows).
+#pragma once
+#include "afis_device.h"
+
+namespace afis {
+
+typedef short ga_v2s16 __attribute__((ext_vector_type(2)));
+typedef unsigned short ga_v2u16 __attribute__((ext_vector_type(2)));
+
+// n = dx^2 + dy^2 of the latent (n1) and of the rolled (n2) point pair from the packed (x | y << 16) words, as floats (exact
+// below 2^24).  v_dot2_i32_i16 with an inline 0 accumulator (the builtin selects the accumulate-in-place form and pays a v_mov per
+// call); a DOT result needs 3 wait states before a VALU reads it, which the compiler cannot know about inside an asm.
+__device__ __forceinline__ void pair_n(int2 a, int2 o, float& n1, float& n2)
+{
+    const ga_v2s16 dl = __builtin_bit_cast(ga_v2s16, a.x) - __builtin_bit_cast(ga_v2s16, o.x);
+    const ga_v2s16 dr = __builtin_bit_cast(ga_v2s16, a.y) - __builtin_bit_cast(ga_v2s16, o.y);
+    int i1, i2;
+    asm("v_dot2_i32_i16 %0, %2, %2, 0\n\tv_dot2_i32_i16 %1, %3, %3, 0\n\ts_nop 2" : "=&v"(i1), "=v"(i2) : "v"(dl), "v"(dr));
+    n1 = (float)i1; n2 = (float)i2;
+}
+// |d| < 50 for all four coordinate differences (matcher.cpp:1257)  <=>  (d + 49) as u16 <= 98
+__device__ __forceinline__ bool tex_in_range(int2 a, int2 o)
+{
+    const ga_v2s16 dl = __builtin_bit_cast(ga_v2s16, a.x) - __builtin_bit_cast(ga_v2s16, o.x);
+    const ga_v2s16 dr = __builtin_bit_cast(ga_v2s16, a.y) - __builtin_bit_cast(ga_v2s16, o.y);
+    const ga_v2u16 bias = {49, 49};
+    const ga_v2u16 tl = __builtin_bit_cast(ga_v2u16, dl) + bias, tr = __builtin_bit_cast(ga_v2u16, dr) + bias;
+    const ga_v2u16 mx = __builtin_elementwise_max(tl, tr);
+    return max((unsigned)mx.x, (unsigned)mx.y) <= 98u;
+}
+
+// RN(sqrt(x)) for an INTEGER-valued x in [0, 2 * 2047^2] (the packed paths' dx^2 + dy^2): v_rsq_f32 (1 ulp) and one fma
+// correction step.  Equal to sqrt_rn_pos for every such integer (exhaustive check).  x = 0: rsq = inf, clamped to 1 (rsq <= 1 for
+// x >= 1 anyway), and the chain gives 0.  One transcendental + 5 instructions; sqrt_rn_pos: one + 9.
+__device__ __forceinline__ float sqrt_rn_int(float x)
+{
+    const float y = fminf(__builtin_amdgcn_rsqf(x), 1.0f);
+    const float r0 = x * y;
+    const float e = __builtin_fmaf(-r0, r0, x);
+    return __builtin_fmaf(e, 0.5f * y, r0);
+}
+
+// "H != 0" on the packed paths without a square root.  With a = sqrt n1, b = sqrt n2, s = n1 + n2 and thr = 30 px (minutiae) or
+// 30/16 blocks (texture, whose table entry is 16 RN(sqrt n) exactly: scaling by a power of two commutes with every rounding):
+//   |a - b| < thr  <=>  u < 0  or  u^2 < n1 n2,   u = (s - thr^2) / 2       (u is exact in fp32; u |u| folds the sign test in).
+// The reference compares the ROUNDED |RN a - RN b| with thr; that differs from the real |a - b| by at most 1.5 ulp(max(a, b)), and
+// t = u^2 - n1 n2 = (|a-b|^2 - thr^2)((a+b)^2 - thr^2)/4, so the two decisions can only differ where |t| <= 3 * 2^-23 s^2 (uses
+// (a+b)^3 <= (a+b)^4 / thr <= 4 s^2 / thr on u >= 0); the fp32 evaluation of t adds at most 2^-23 s^2.  The band used is
+// 2^-18 u^2 + 2^-20 thr^4 >= 2^-21 s^2 (s = 2u + thr^2), a function of u alone; outside it the sign of the computed t decides, inside
+// it (about 1e-4 of the pairs) the rounded roots are compared.  Checked against the rounded-root predicate on every (n1, n2) in
+// [0, 4802]^2 and on 1.3e10 near-threshold / random minutiae pairs: no disagreement outside the band.  8 instructions; the
+// rounded-root test with its own slack: 5 + two transcendentals (4 issue slots each).
+template <bool TEX>
+__device__ __forceinline__ int pair_compatible_alg(float n1, float n2)   // 1 / 0: decided; 2: inside the band
+{
+    constexpr float c = TEX ? 3.515625f : 900.0f;                          // thr^2
+    const float s = n1 + n2;
+    const float u = __builtin_fmaf(s, 0.5f, -0.5f * c);
+    const float uu = u * fabsf(u);
+    const float p = n1 * n2;
+    const float t = uu - p;
+    const float band = __builtin_fmaf(fabsf(uu), 3.814697265625e-6f, c * c * 9.5367431640625e-7f);
+    if (!(fabsf(t) > band)) return 2;
+    return t < 0.0f ? 1 : 0;
+}
+template <bool TEX>
+__device__ __forceinline__ bool pair_compatible_n(float n1, float n2)
+{
+    const int a = pair_compatible_alg<TEX>(n1, n2);
+    if (a != 2) return a != 0;
+    const float d = fabsf(sqrt_rn_pos(n1) - sqrt_rn_pos(n2));
+    return TEX ? 16.0f * d < 30.0f : d < 30.0f;
+}
+
+}  // namespace afis

@@ -728,6 +728,20 @@ def test_angle_stage_atan2_equals_libm_on_every_coordinate_difference(codebook_b
     assert not diff.any(), (int(diff.sum()), np.argwhere(diff)[:5] - R, got[diff][:5], want[diff][:5])
 
 
+def test_distance_stage_packed_arithmetic_equals_the_plain_evaluation(codebook_bytes):
+    """S8 on the packed paths (csrc/graph_arith.h) takes two shortcuts around matcher.cpp:1246-1272 / :1372-1393: RN(sqrt n) of the
+    integer n = dx^2 + dy^2 from v_rsq_f32 + one fma step, and "H != 0" (dist < 30) from n1, n2 without square roots outside a guard
+    band.  Both are compared on the device with the plain evaluation (correctly rounded roots, float subtraction, compare): every
+    integer up to 2 * 2047^2; every texture pair of [0, 4802]^2 (|d| < 50 blocks per axis, matcher.cpp:1257); 4e8 minutiae pairs
+    within +-12 of the 30 px threshold.  Not one root and not one decision may differ; the band must stay a rare case."""
+    m = M.Matcher(codebook_bytes)
+    c = m.debug_graph_arith()
+    m.close()
+    assert c[0] == 0, c
+    assert c[1] == 4803 * 4803 and c[3] == 0 and c[2] < 1e-3 * c[1], c
+    assert c[4] > 4e8 and c[6] == 0, c
+
+
 def test_rank_lists_device_kernel_equals_host_sort(codebook_bytes, cb, medium, small):
     """S11 (matcher.cpp:306-309 + the documented tie rule): k <= 64 is ranked by the device kernel, k > 64 by a host partial_sort of the
     copied score matrix; both must give the lexsort (score descending, index ascending) — including the 99 % of pairs tied at 0 —
