@@ -63,7 +63,7 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_tex_codes_q, g_tex_q_blk, g_empty;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_tex_codes_q, g_tex_q_blk, g_empty, g_task_ctr;
     bool codes_q_built = false;          // the quantised path's code stream is laid out on first use (lut_dtype 16)
     int64_t q_blocks = 0;
     int max_nR = 0;
@@ -186,7 +186,7 @@ std::vector<float> fragment_tiles(const std::vector<float>& des, const std::vect
 void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
-    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_empty.release();
+    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_empty.release(); c->g_task_ctr.release();
 }
 
 }  // namespace
@@ -496,12 +496,14 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
         HIPCHK(ctx, upload(ctx->g_tex_q_blk, qb, ctx->stream));
     }
     HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
+    HIPCHK(ctx, ctx->g_task_ctr.ensure(64));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     GalleryDev& g = ctx->gal;
     g.G = (int32_t)G;
     g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
     g.minu_des = ctx->g_minu_des.as<float>(); g.minu_frag = ctx->g_minu_frag.as<float4>(); g.minu_tile_off = ctx->g_minu_tile_off.as<int32_t>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
     g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
+    g.task_ctr = ctx->g_task_ctr.as<int32_t>();
     ctx->max_nR = max_nR;
     ctx->total_tex_points = (int64_t)hg.tx.size();
     ctx->index_base = index_base;
@@ -681,8 +683,11 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
             float* grp_scores = ctx->scores.as<float>() + (size_t)q0 * G;
-            // larger chunks amortise the 128 KB LUT tile load; smaller ones keep enough workgroups in flight on a small gallery
-            const int chunk = ctx->chunk > 0 ? ctx->chunk : (G >= 65536 ? 512 : (G >= 32768 ? 256 : (G >= 4096 ? 128 : 32)));
+            // One ADC workgroup fills a CU (128 KB LUT tile), so nothing overlaps its tile load: chunks of ~640 templates keep that
+            // under 3 % of a workgroup's life.  The blocks of XCD x are the chunks c % 8 == x, so the chunk COUNT is a multiple of 8
+            // (measured at a 12.5k shard: 98 chunks of 128 -> 24 of 521: -9 % ADC time; at 100k: 196 of 512 -> 160 of 625: -2.5 %).
+            const long long n_chunks_auto = ((G + 639) / 640 + 7) / 8 * 8;
+            const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
             if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {           // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
                 int rc16 = adc_stage_q(ctx, grp, chunk, ctx->lut_dtype != 16, ev[1]);

@@ -36,6 +36,7 @@ struct GalleryDev {
                                             // lane class and half-period shifted for the conflict-free ADC kernel (adc.hip)
     const int32_t* tex_cf_blk = nullptr;    // [G+1] offset of each template's stream in tex_codes_cf, in 64-entry blocks
     const uint8_t* empty = nullptr;      // [G] 1 = rolled template has neither minutiae nor texture (score -1)
+    int32_t* task_ctr = nullptr;         // [2] next-task counters of the graph kernels (texture, minutiae): zeroed by their launchers
 };
 
 // A group of latents resident on the device (selected minutiae templates 26, 2, 11 + texture template 0).

@@ -102,6 +102,18 @@ struct __attribute__((aligned(16))) WaveSmem {
 #endif
 };
 
+// The wave's next task: a ticket from a global counter, one draw per list (a list costs 50-2000 us).  Every lane takes part in the
+// atomic — lane 0 adds 1, the others 0, and the value lane 0 gets back is the ticket — so that there is NO divergent branch here.
+// The usual "t = 0; if (lane == 0) t = atomicAdd(..); t = readfirstlane(t)" is not safe inside this loop: the compiler threads the
+// lanes != 0 through a copy of the loop head in which t is the constant 0 (readfirstlane of a constant folds), and a task whose
+// list is empty (`continue`) then spins forever; handing the ticket over through LDS behind wave barriers livelocks the same way
+// (both were observed on the device).  The backend merges the 64 atomics into one.
+__device__ __forceinline__ int next_task(int32_t* ctr)
+{
+    const int t = atomicAdd(ctr, threadIdx.x == 0 ? 1 : 0);
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
 // ranks (0 = largest) of this lane's U keys among keys[0..n); keys are unique
 template <int U>
 __device__ __forceinline__ void rank_keys(const u64* keys, int n, const u64 (&mine)[U], int (&r)[U])
@@ -666,9 +678,11 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
     __shared__ TexSmem sm;
     const int lane = threadIdx.x;
     GPH_ZERO();
-    const long long n_tasks = (long long)q.nq * g.G;
-    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
-        const int qi = (int)(task / g.G), gi = (int)(task - (long long)qi * g.G);
+    const int n_tasks = q.nq * g.G;
+    for (;;) {
+        const int task = next_task(g.task_ctr + 0);                       // lists differ widely in cost (a mate's is 10 x a non-mate's): tasks are drawn, not dealt
+        if (task >= n_tasks) break;
+        const int qi = task / g.G, gi = task - qi * g.G;
         const int l0 = q.lt_off[qi], n_lt = q.lt_off[qi + 1] - l0;
         const int r0 = g.tex_off[gi], n_rt = g.tex_off[gi + 1] - r0;
         float* out = parts + (size_t)task * 4 + 3;
@@ -750,7 +764,10 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 {
     const long long n_tasks = (long long)q.nq * g.G;
     if (n_tasks <= 0) return hipSuccess;
+    if (n_tasks > 0x7ffffff0LL || !g.task_ctr) return hipErrorInvalidValue;
     const int grid = (int)(n_tasks < 16384 ? n_tasks : 16384);
+    hipError_t e0 = hipMemsetAsync(g.task_ctr + 0, 0, 4, stream);
+    if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, parts, GraphTap{tap_out, tap_n, tap_stage});
     return hipGetLastError();
 }
@@ -771,11 +788,13 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
     __shared__ MinuGraphSmem sm;
     const int lane = threadIdx.x;
     GPH_ZERO();
-    const long long n_tasks = (long long)q.nq * 3 * g.G;
-    for (long long task = blockIdx.x; task < n_tasks; task += gridDim.x) {
+    const int n_tasks = q.nq * 3 * g.G;
+    for (;;) {
+        const int task = next_task(g.task_ctr + 1);
+        if (task >= n_tasks) break;
         // task order as in k_minu_cands: gallery template fastest, then selected template, then query
-        const int gi = (int)(task % g.G);
-        const int qs = (int)(task / g.G);
+        const int gi = task % g.G;
+        const int qs = task / g.G;
         const int qi = qs / 3, s = qs - qi * 3;
         float* out = parts + ((size_t)qi * g.G + gi) * 4 + s;
         const int num = cand_n[task];
@@ -813,7 +832,10 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
 {
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
+    if (n_tasks > 0x7ffffff0LL || !g.task_ctr) return hipErrorInvalidValue;
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
+    hipError_t e0 = hipMemsetAsync(g.task_ctr + 1, 0, 4, stream);
+    if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, GraphTap{tap_out, tap_n, tap_stage});
     return hipGetLastError();
 }
