@@ -107,11 +107,19 @@ struct __attribute__((aligned(16))) WaveSmem {
 // The usual "t = 0; if (lane == 0) t = atomicAdd(..); t = readfirstlane(t)" is not safe inside this loop: the compiler threads the
 // lanes != 0 through a copy of the loop head in which t is the constant 0 (readfirstlane of a constant folds), and a task whose
 // list is empty (`continue`) then spins forever; handing the ticket over through LDS behind wave barriers livelocks the same way
-// (both were observed on the device).  The backend merges the 64 atomics into one.
+// (both were observed on the device).  So the single-lane atomic is one opaque asm block — exec narrowed to lane 0 around the
+// instruction — which is also cheaper than what the backend makes of a 64-lane atomicAdd(ctr, lane == 0) (a 64-step scalar loop).
 __device__ __forceinline__ int next_task(int32_t* ctr)
 {
-    const int t = atomicAdd(ctr, threadIdx.x == 0 ? 1 : 0);
-    return __builtin_amdgcn_readfirstlane(t);
+    int t;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(t), "=&s"(saved) : "v"(0), "v"(1), "s"(ctr) : "memory");
+    return __builtin_amdgcn_readfirstlane(t);                            // all lanes are active again: lane 0 holds the ticket
 }
 
 // ranks (0 = largest) of this lane's U keys among keys[0..n); keys are unique
