@@ -360,8 +360,8 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     const int half = num >> 1;
     const bool even = !(num & 1);
     uint32_t* const hb0 = &sm.hb[0][0];
-    auto pair = [&](int2 own, int t, int k) {
-        if (fast ? compat_fast(own, sm.xy[k]) : pair_compatible<LOOKUP>(unpack_xy(own), unpack_xy(sm.xy[k]), table)) {
+    auto pair = [&](int2 own, int t, int k, int2 other) {
+        if (fast ? compat_fast(own, other) : pair_compatible<LOOKUP>(unpack_xy(own), unpack_xy(other), table)) {
             atomicOr(hb0 + (t * W + (k >> 5)), 1u << (k & 31));
             atomicOr(hb0 + (__umul24(k, W) + (t >> 5)), 1u << (t & 31));
         }
@@ -373,14 +373,46 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
     const int n_wide = grouped ? tail0 : num;                             // rows handled one per lane and block
     int kk[U];                                                            // t + d (mod num), kept incrementally: add, compare, select
 #pragma unroll
-    for (int u = 0; u < U; ++u) kk[u] = lane + 64 * u;
+    for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; kk[u] = t < num ? t : 0; }
     for (int d = 1; n_wide > 0 && d <= half; ++d) {
         const bool last = d == half && even;                              // even num: the antipodal pairs belong to the lower half
+        int2 other[U];                                                    // the U partner points are fetched together: one LDS round trip per d, not U
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = lane + 64 * u;
             int k = kk[u] + 1; k = k == num ? 0 : k; kk[u] = k;
-            if (t < n_wide && !(last && t >= half)) pair(me[u], t, k);
+            other[u] = sm.xy[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (fast) {
+            // the U predicates are evaluated without control flow between them (rows beyond the list compute on zeros), so their
+            // instruction chains interleave; the rare band case of any of them is one uniform branch for all
+            float n1[U], n2[U]; bool hit[U], near[U]; bool any_near = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pair_n(me[u], other[u], n1[u], n2[u]);
+                hit[u] = pair_compatible_t<LOOKUP>(n1[u], n2[u], near[u]);
+                any_near |= near[u];
+            }
+            if (__builtin_amdgcn_ballot_w64(any_near) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) if (near[u]) hit[u] = pair_compatible_exact<LOOKUP>(n1[u], n2[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = lane + 64 * u, k = kk[u];
+                bool ok = hit[u] && t < n_wide && !(last && t >= half);
+                if (LOOKUP && range_test) ok = ok && tex_in_range(me[u], other[u]);
+                if (ok) {
+                    atomicOr(hb0 + (t * W + (k >> 5)), 1u << (k & 31));
+                    atomicOr(hb0 + (__umul24(k, W) + (t >> 5)), 1u << (t & 31));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = lane + 64 * u;
+                if (t < n_wide && !(last && t >= half)) pair(me[u], t, kk[u], other[u]);
+            }
         }
     }
     if (grouped) {
@@ -391,7 +423,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
         int d = 1 + (lane >> sh);
         int k = t + d; k = k >= num ? k - num : k;                        // d <= half < num: one wrap
         for (int d0 = 1; d0 <= half; d0 += dstep) {
-            if (row && d <= half && !(d == half && even && t >= half)) pair(own, t, k);
+            if (row && d <= half && !(d == half && even && t >= half)) pair(own, t, k, sm.xy[k]);
             d += dstep; k += dstep; k = k >= num ? k - num : k;           // exact while d <= half (k < num + dstep <= 2 num there)
         }
     }

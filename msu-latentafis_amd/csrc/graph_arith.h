@@ -64,13 +64,48 @@ __device__ __forceinline__ int pair_compatible_alg(float n1, float n2)   // 1 / 
     if (!(fabsf(t) > band)) return 2;
     return t < 0.0f ? 1 : 0;
 }
+// the same test split in two for callers that evaluate several independent pairs at once: pair_compatible_t gives the sign test and
+// says whether the pair is inside the band; pair_compatible_exact is the rounded-root comparison for those that are
+template <bool TEX>
+__device__ __forceinline__ bool pair_compatible_t(float n1, float n2, bool& near)
+{
+    constexpr float c = TEX ? 3.515625f : 900.0f;
+    const float s = n1 + n2;
+    const float u = __builtin_fmaf(s, 0.5f, -0.5f * c);
+    const float uu = u * fabsf(u);
+    const float p = n1 * n2;
+    const float t = uu - p;
+    const float band = __builtin_fmaf(fabsf(uu), 3.814697265625e-6f, c * c * 9.5367431640625e-7f);
+    near = !(fabsf(t) > band);
+    return t < 0.0f;
+}
+template <bool TEX>
+__device__ __forceinline__ bool pair_compatible_exact(float n1, float n2)
+{
+    const float d = fabsf(sqrt_rn_pos(n1) - sqrt_rn_pos(n2));
+    return TEX ? 16.0f * d < 30.0f : d < 30.0f;
+}
 template <bool TEX>
 __device__ __forceinline__ bool pair_compatible_n(float n1, float n2)
 {
-    const int a = pair_compatible_alg<TEX>(n1, n2);
-    if (a != 2) return a != 0;
-    const float d = fabsf(sqrt_rn_pos(n1) - sqrt_rn_pos(n2));
-    return TEX ? 16.0f * d < 30.0f : d < 30.0f;
+    constexpr float c = TEX ? 3.515625f : 900.0f;
+    const float s = n1 + n2;
+    const float u = __builtin_fmaf(s, 0.5f, -0.5f * c);
+    const float uu = u * fabsf(u);
+    const float p = n1 * n2;
+    const float t = uu - p;
+    const float band = __builtin_fmaf(fabsf(uu), 3.814697265625e-6f, c * c * 9.5367431640625e-7f);
+    bool hit = t < 0.0f;
+    const bool near = !(fabsf(t) > band);
+    // one UNIFORM branch around the rare case (a lane of the wave inside the band: once in ~150 calls) instead of a divergent if / else
+    // per call, whose exec bookkeeping costs as many scalar instructions as the test itself costs vector ones
+    if (__builtin_amdgcn_ballot_w64(near) != 0ull) {
+        if (near) {
+            const float d = fabsf(sqrt_rn_pos(n1) - sqrt_rn_pos(n2));
+            hit = TEX ? 16.0f * d < 30.0f : d < 30.0f;
+        }
+    }
+    return hit;
 }
 
 }  // namespace afis
