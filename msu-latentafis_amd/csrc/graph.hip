@@ -75,9 +75,15 @@ struct Pt { int lx, ly, rx, ry; };
 __device__ __forceinline__ int2 pack_xy(int lx, int ly, int rx, int ry) { return make_int2((lx & 0xffff) | (ly << 16), (rx & 0xffff) | (ry << 16)); }
 __device__ __forceinline__ Pt unpack_xy(int2 v) { Pt p; p.lx = (int)(short)v.x; p.ly = v.x >> 16; p.rx = (int)(short)v.y; p.ry = v.y >> 16; return p; }
 
-template <int NMAX_, int CACHE_>
-struct __attribute__((aligned(16))) WaveSmem {
+// The list's similarities: kept in LDS (minutiae lists: they exist nowhere else), or re-read from where they came from (texture lists:
+// sim[t] is the row maximum of latent row li[t], still in L2 — 800 B less LDS is what lets a twelfth texture list share a CU).
+template <int N, bool OWN> struct SimStore { float simv[N]; };
+template <int N> struct SimStore<N, false> {};
+
+template <int NMAX_, int CACHE_, bool OWN_SIM_>
+struct __attribute__((aligned(16))) WaveSmem : SimStore<NMAX_, OWN_SIM_> {
     static constexpr int NMAX = NMAX_, CACHE = CACHE_;
+    static constexpr bool OWN_SIM = OWN_SIM_;
     static constexpr int W = (NMAX + 31) / 32;
     static constexpr int N4 = (NMAX + 3) / 4 * 4;
     static constexpr int U = (NMAX + 63) / 64;
@@ -86,7 +92,6 @@ struct __attribute__((aligned(16))) WaveSmem {
         float cc[N4];
         struct { short order[NMAX]; short sel[NMAX]; } os;     // rank -> candidate index; accepted candidates
     } y;
-    float sim[NMAX];
     short li[NMAX], ri[NMAX];
     int2 xy[NMAX];                         // .x = lx | ly << 16 (latent point), .y = rx | ry << 16 (rolled point)
     uint32_t hb[NMAX][W];                  // bit rows: non-zero pattern of H (distance stage), then the boolean H of the angle stage
@@ -94,13 +99,19 @@ struct __attribute__((aligned(16))) WaveSmem {
     union {
         float stash[CACHE * NMAX];                                                  // power iterations: [n][t] = value of the n-th non-zero of row t
         struct { u64 keys[N4]; float lo[NMAX], ro[NMAX]; } s;                       // sorts (after the iterations); orientations (angle stage only)
-        struct { u64 keys[N4]; float tval[NMAX]; short te[NMAX], targ[NMAX]; } pick;   // texture rows picked by S7, before they are ranked
+        struct { u64 keys[N4]; short te[NMAX], targ[NMAX]; } pick;               // texture rows picked by S7, before they are ranked
     } x;
-    int nsel;
 #ifdef AFIS_PHASE_TIMING
     u64 ph[16];
 #endif
 };
+// similarity of list entry t; ext: the texture list's row maxima (rm_val + the pair's offset), indexed by latent row
+template <class SM>
+__device__ __forceinline__ float list_sim(const SM& sm, const float* __restrict__ ext, int t)
+{
+    if constexpr (SM::OWN_SIM) return sm.simv[t];
+    else return ext[sm.li[t]];
+}
 
 // The wave's next task: a ticket from a global counter, one draw per list (a list costs 50-2000 us).  Every lane takes part in the
 // atomic — lane 0 adds 1, the others 0, and the value lane 0 gets back is the ticket — so that there is NO divergent branch here.
@@ -212,13 +223,14 @@ __device__ void compact(SM& sm, int n)
 #pragma unroll
     for (int u = 0; u < SM::U; ++u) {
         const int t = lane + 64 * u;
-        if (t < n) { const int s = sm.y.os.sel[t]; sim[u] = sm.sim[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; }
+        sim[u] = 0.0f;
+        if (t < n) { const int s = sm.y.os.sel[t]; if constexpr (SM::OWN_SIM) sim[u] = sm.simv[s]; li[u] = sm.li[s]; ri[u] = sm.ri[s]; xy[u] = sm.xy[s]; }
     }
     WSYNC();
 #pragma unroll
     for (int u = 0; u < SM::U; ++u) {
         const int t = lane + 64 * u;
-        if (t < n) { sm.sim[t] = sim[u]; sm.li[t] = li[u]; sm.ri[t] = ri[u]; sm.xy[t] = xy[u]; }
+        if (t < n) { if constexpr (SM::OWN_SIM) sm.simv[t] = sim[u]; sm.li[t] = li[u]; sm.ri[t] = ri[u]; sm.xy[t] = xy[u]; }
     }
     WSYNC();
 }
@@ -336,7 +348,7 @@ __device__ __forceinline__ float h_value(float dist)
 // S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
 // MODE 0: generic arithmetic; 1: packed 16-bit coordinates (texture: with the |d| < 50 test); 2: texture, every coordinate in [0, 49]
 template <class SM, bool LOOKUP, int ITERS, int MODE>
-__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
+__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ ext)
 {
     constexpr bool fast = MODE > 0;
     constexpr bool range_test = MODE == 1;
@@ -351,7 +363,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int t = lane + 64 * u;
-        if (t < SM::N4) { sm.b[t] = t < num ? sm.sim[t] : 0.0f; sm.y.cc[t] = 0.0f; }
+        if (t < SM::N4) { sm.b[t] = t < num ? list_sim(sm, ext, t) : 0.0f; sm.y.cc[t] = 0.0f; }
         me[u] = t < num ? sm.xy[t] : make_int2(0, 0);
     }
     WSYNC();
@@ -674,31 +686,35 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
 template <class SM, bool LOOKUP, int ITERS>
 __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
-                                             const float* __restrict__ rori, int& n_survivors, int stop_after = 2, int mode = 0)
+                                             const float* __restrict__ rori, const float* __restrict__ ext, int& n_survivors, int stop_after = 2, int mode = 0)
 {
     n_survivors = num;                                                     // stop_after 0: the candidate list itself (S3 / S7)
     if (stop_after == 0) return 0.0f;
     // instantiations rather than flags inside the loops: the register budget is that of the path taken
-    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2>(sm, num, table);
-    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table);
-    else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table);
+    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2>(sm, num, table, ext);
+    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table, ext);
+    else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table, ext);
     n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
     if (stop_after == 1) return 0.0f;
     n_survivors = 0;
     if (num < 2) return 0.0f;
     num = angle_filter(sm, num, lori, rori);
-    n_survivors = num;                                                     // sm.sim/li/ri/xy[0..num) = corr3 in the reference's order
-    float score = 0.0f;                                                    // :508-514 / :775-781
-    for (int i = 0; i < num; ++i) score += sm.sim[i];
+    n_survivors = num;                                                     // li/ri/xy[0..num) (+ similarities) = corr3 in the reference's order
+    // :508-514 / :775-781: the sum of the survivors' similarities in list order.  They are gathered into b[] first (one parallel
+    // round trip when they come from global memory) and added up sequentially from LDS.
+    for (int t = threadIdx.x; t < num; t += 64) sm.b[t] = list_sim(sm, ext, t);
+    WSYNC();
+    float score = 0.0f;
+    for (int i = 0; i < num; ++i) score += sm.b[i];
     return score;
 }
 
 // parity tap (tests only): the list a task holds after stage `stage` (0 = candidates, 1 = after S8, 2 = after S9)
 struct GraphTap { MinuCand* out; int32_t* n; int stage; };
 template <class SM>
-__device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, long long task, int n, int cap)
+__device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, const float* __restrict__ ext, long long task, int n, int cap)
 {
-    for (int t = threadIdx.x; t < n; t += 64) { MinuCand c; c.sim = sm.sim[t]; c.li = sm.li[t]; c.ri = sm.ri[t]; tap.out[(size_t)task * cap + t] = c; }
+    for (int t = threadIdx.x; t < n; t += 64) { MinuCand c; c.sim = list_sim(sm, ext, t); c.li = sm.li[t]; c.ri = sm.ri[t]; tap.out[(size_t)task * cap + t] = c; }
     if (threadIdx.x == 0) tap.n[task] = n;
 }
 
@@ -708,7 +724,7 @@ __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, lon
 #ifndef AFIS_TEX_CACHE
 #define AFIS_TEX_CACHE 4
 #endif
-typedef WaveSmem<kTopTex, AFIS_TEX_CACHE> TexSmem;
+typedef WaveSmem<kTopTex, AFIS_TEX_CACHE, false> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
 
 __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
@@ -760,7 +776,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
                 else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
                 if (pos >= 0) {
                     sm.x.pick.keys[pos] = g_make_key(v[u], e);
-                    sm.x.pick.tval[pos] = v[u]; sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)rm_arg[o + e];
+                    sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)rm_arg[o + e];
                 }
                 base_gt += __popcll(mg); base_eq += __popcll(me);
             }
@@ -773,11 +789,11 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
 #pragma unroll
             for (int u = 0; u < TexSmem::U; ++u) {
                 const int t = lane + 64 * u;
-                if (t < num) { sm.sim[r[u]] = sm.x.pick.tval[t]; sm.li[r[u]] = sm.x.pick.te[t]; sm.ri[r[u]] = sm.x.pick.targ[t]; }
+                if (t < num) { sm.li[r[u]] = sm.x.pick.te[t]; sm.ri[r[u]] = sm.x.pick.targ[t]; }
             }
         } else {                                                         // :748-749 rows stay in index order
             num = n_lt;
-            for (int t = lane; t < num; t += 64) { sm.sim[t] = rm_val[o + t]; sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
+            for (int t = lane; t < num; t += 64) { sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
         }
         WSYNC();
         int out_of_range = 0, not_small = 0;                             // any block coordinate outside [0, 8191]: generic arithmetic for this list;
@@ -791,9 +807,9 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
         const int mode = __ballot(out_of_range != 0) != 0ull ? 0 : (__ballot(not_small != 0) == 0ull ? 2 : 1);
         WSYNC();
         int n_surv;
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, rm_val + o, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
         if (lane == 0) *out = score;
-        if (tap.out) tap_write(tap, sm, task, n_surv, kTopTex);
+        if (tap.out) tap_write(tap, sm, rm_val + o, task, n_surv, kTopTex);
         WSYNC();
     }
     GPH_FLUSH();
@@ -818,7 +834,7 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 #ifndef AFIS_MINU_CACHE
 #define AFIS_MINU_CACHE 10
 #endif
-typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE> MinuGraphSmem;
+typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE, true> MinuGraphSmem;
 
 // corr_out / corr_n (optional): the surviving correspondences of every task as (lx, ly, rx, ry), matcher.cpp:497-505
 __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
@@ -844,7 +860,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         int out_of_range = 0;                                            // any pixel coordinate outside [0, 2047]: generic float arithmetic
         for (int t = lane; t < num; t += 64) {
             const MinuCand cd = c[t];
-            sm.sim[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
+            sm.simv[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
             const short2 lp = q.lm_xy[l0 + cd.li], rp = g.minu_xy[r0 + cd.ri];
             sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
             out_of_range |= (lp.x | lp.y | rp.x | rp.y) & ~2047;
@@ -852,9 +868,9 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         const int mode = __ballot(out_of_range != 0) == 0ull ? 1 : 0;
         WSYNC();
         int n_surv;
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, n_surv, tap.out ? tap.stage : 2, mode);   // :492, :495
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, nullptr, n_surv, tap.out ? tap.stage : 2, mode);   // :492, :495
         if (lane == 0) *out = score;
-        if (tap.out) tap_write(tap, sm, task, n_surv, kTopMinu);
+        if (tap.out) tap_write(tap, sm, nullptr, task, n_surv, kTopMinu);
         if (corr_out) {
             for (int t = lane; t < n_surv; t += 64) {
                 const Pt p = unpack_xy(sm.xy[t]);
