@@ -38,11 +38,15 @@ typedef unsigned long long u64;
 __device__ u64 g_graph_phase[16];
 #define GPH_INIT() u64 gph_t0 = __builtin_readcyclecounter()
 #define GPH(i) do { if (threadIdx.x == 0) { const u64 t1_ = __builtin_readcyclecounter(); sm.ph[(i)] += t1_ - gph_t0; gph_t0 = t1_; } } while (0)
+#define GPH_T0() const u64 gph_k0 = __builtin_readcyclecounter()
+#define GPH_K(i) do { if (threadIdx.x == 0) sm.ph[(i)] += __builtin_readcyclecounter() - gph_k0; } while (0)
 #define GPH_ZERO() do { if (threadIdx.x < 16) sm.ph[threadIdx.x] = 0; WSYNC(); } while (0)
 #define GPH_FLUSH() do { WSYNC(); if (threadIdx.x < 16 && sm.ph[threadIdx.x]) atomicAdd(&g_graph_phase[threadIdx.x], sm.ph[threadIdx.x]); } while (0)
 #else
 #define GPH_INIT() do {} while (0)
 #define GPH(i) do {} while (0)
+#define GPH_T0() do {} while (0)
+#define GPH_K(i) do {} while (0)
 #define GPH_ZERO() do {} while (0)
 #define GPH_FLUSH() do {} while (0)
 #endif
@@ -68,6 +72,18 @@ __device__ __forceinline__ int g_wave_max(int x)
     x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false));         // row_ror:8
     x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));         // row_bcast:15
     x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false));         // row_bcast:31
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// sum of x over the wave (wave-uniform result), same DPP ladder as g_wave_max
+__device__ __forceinline__ int g_wave_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);                 // quad_perm [1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);                 // quad_perm [2,3,0,1]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false);                // row_ror:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);                // row_ror:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);                // row_bcast:15 (rows 1, 3)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);                // row_bcast:31 (rows 2, 3)
     return __builtin_amdgcn_readlane(x, 63);
 }
 
@@ -738,6 +754,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
     for (;;) {
         const int task = next_task(g.task_ctr + 0);                       // lists differ widely in cost (a mate's is 10 x a non-mate's): tasks are drawn, not dealt
         if (task >= n_tasks) break;
+        GPH_T0();
         const int qi = task / g.G, gi = task - qi * g.G;
         const int l0 = q.lt_off[qi], n_lt = q.lt_off[qi + 1] - l0;
         const int r0 = g.tex_off[gi], n_rt = g.tex_off[gi + 1] - r0;
@@ -746,46 +763,70 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
         const size_t o = (size_t)task * q.lt_pad;
         int num;
         if (n_lt > kTopTex) {                                            // :736-747: the 200 rows with the largest maxima
-            float v[kTexRegs]; uint32_t key[kTexRegs];
+            const int n_regs = (n_lt + 63) >> 6;                         // registers per lane that hold a row (uniform)
+            uint32_t key[kTexRegs]; int arg[kTexRegs];
 #pragma unroll
             for (int u = 0; u < kTexRegs; ++u) {
                 const int e = u * 64 + lane;
-                v[u] = e < n_lt ? rm_val[o + e] : 0.0f;
-                key[u] = e < n_lt ? g_ord_f32(v[u]) : 0u;                // real keys are never 0
+                const bool in = e < n_lt;
+                key[u] = in ? g_ord_f32(rm_val[o + e]) : 0u;             // real keys are never 0
+                arg[u] = in ? rm_arg[o + e] : 0;                         // fetched with the values: one round trip, not one per picked row
             }
-            uint32_t T = 0;                                              // 200th largest key, built bit by bit
+            uint32_t T = 0;                                              // 200th largest key, built bit by bit ...
             for (int bit = 31; bit >= 0; --bit) {
                 const uint32_t cand = T | (1u << bit);
                 int c = 0;
 #pragma unroll
-                for (int u = 0; u < kTexRegs; ++u) c += g_wave_popc(key[u] >= cand);
-                if (c >= kTopTex) T = cand;
+                for (int u = 0; u < kTexRegs; ++u) if (u < n_regs) c += g_wave_popc(key[u] >= cand);
+                if (c >= kTopTex) { T = cand; if (c == kTopTex) break; } // ... or until exactly 200 keys are >= the prefix: they are the set
             }
             int n_gt = 0;
 #pragma unroll
-            for (int u = 0; u < kTexRegs; ++u) n_gt += g_wave_popc(key[u] > T);
+            for (int u = 0; u < kTexRegs; ++u) if (u < n_regs) n_gt += g_wave_popc(key[u] > T);
             const int need = kTopTex - n_gt;                             // of the keys equal to T keep the lowest indices
             int base_gt = 0, base_eq = 0;
+            uint32_t* const key32 = reinterpret_cast<uint32_t*>(sm.x.pick.keys);   // 200 ordered-float keys, read four at a time below
 #pragma unroll
             for (int u = 0; u < kTexRegs; ++u) {                         // u ascending, lane ascending = index ascending
-                const int e = u * 64 + lane;
-                const bool gt = key[u] > T, eq = key[u] == T;
-                const u64 mg = __ballot(gt), me = __ballot(eq);
-                int pos = -1;
-                if (gt) pos = base_gt + g_lane_prefix(mg);
-                else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
-                if (pos >= 0) {
-                    sm.x.pick.keys[pos] = g_make_key(v[u], e);
-                    sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)rm_arg[o + e];
+                if (u < n_regs) {
+                    const int e = u * 64 + lane;
+                    const bool gt = key[u] > T, eq = key[u] == T;
+                    const u64 mg = __ballot(gt), me = __ballot(eq);
+                    int pos = -1;
+                    if (gt) pos = base_gt + g_lane_prefix(mg);
+                    else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
+                    if (pos >= 0) { key32[pos] = key[u]; sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)arg[u]; }
+                    base_gt += __popcll(mg); base_eq += __popcll(me);
                 }
-                base_gt += __popcll(mg); base_eq += __popcll(me);
             }
             WSYNC();
             num = kTopTex;
-            u64 mine[TexSmem::U]; int r[TexSmem::U];
+            // rank by counting on the 32-bit keys.  Picked rows sit in index order, so equal keys would need the index as a tie-break:
+            // ties make the ranks collide, which their sum shows (a permutation of 0..199 sums to 19900, anything else to less); the
+            // 64-bit (key, ~index) composites are ranked only then.
+            uint32_t m32[TexSmem::U]; int r[TexSmem::U];
 #pragma unroll
-            for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? sm.x.pick.keys[t] : 0ull; }
-            rank_keys<TexSmem::U>(sm.x.pick.keys, num, mine, r);
+            for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; m32[u] = t < num ? key32[t] : 0xffffffffu; r[u] = 0; }
+            const uint4* k4 = reinterpret_cast<const uint4*>(key32);
+#pragma unroll 2
+            for (int k = 0; k < kTopTex / 4; ++k) {
+                const uint4 kk = k4[k];
+#pragma unroll
+                for (int u = 0; u < TexSmem::U; ++u) { r[u] += kk.x > m32[u]; r[u] += kk.y > m32[u]; r[u] += kk.z > m32[u]; r[u] += kk.w > m32[u]; }
+            }
+            int rsum = 0;
+#pragma unroll
+            for (int u = 0; u < TexSmem::U; ++u) rsum += r[u];            // lanes beyond the list hold the maximum key: rank 0
+            if (g_wave_sum(rsum) != kTopTex * (kTopTex - 1) / 2) {
+                u64 mine[TexSmem::U];
+#pragma unroll
+                for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? ((u64)key32[t] << 32) | (uint32_t)(~(uint32_t)sm.x.pick.te[t]) : 0ull; r[u] = 0; }
+                for (int k = 0; k < num; ++k) {
+                    const u64 kk = ((u64)key32[k] << 32) | (uint32_t)(~(uint32_t)sm.x.pick.te[k]);
+#pragma unroll
+                    for (int u = 0; u < TexSmem::U; ++u) r[u] += kk > mine[u];
+                }
+            }
 #pragma unroll
             for (int u = 0; u < TexSmem::U; ++u) {
                 const int t = lane + 64 * u;
@@ -806,6 +847,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
         }
         const int mode = __ballot(out_of_range != 0) != 0ull ? 0 : (__ballot(not_small != 0) == 0ull ? 2 : 1);
         WSYNC();
+        GPH_K(15);                                                       // S7 + list build
         int n_surv;
         const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, rm_val + o, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
         if (lane == 0) *out = score;
@@ -848,6 +890,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
     for (;;) {
         const int task = next_task(g.task_ctr + 1);
         if (task >= n_tasks) break;
+        GPH_T0();
         // task order as in k_minu_cands: gallery template fastest, then selected template, then query
         const int gi = task % g.G;
         const int qs = task / g.G;
@@ -867,6 +910,7 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         }
         const int mode = __ballot(out_of_range != 0) == 0ull ? 1 : 0;
         WSYNC();
+        GPH_K(7);                                                        // list load
         int n_surv;
         const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, nullptr, n_surv, tap.out ? tap.stage : 2, mode);   // :492, :495
         if (lane == 0) *out = score;

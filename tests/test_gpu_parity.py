@@ -440,6 +440,39 @@ def test_texture_coordinates_off_the_beaten_path(codebook_bytes, cb, oracle):
         m.close()
 
 
+def test_texture_top200_with_tied_row_maxima(codebook_bytes, cb, oracle):
+    """S7 (matcher.cpp:736-749) when row maxima tie: latent texture rows that share a descriptor have bit-identical ADC rows, hence equal
+    maxima and arg-maxima.  Ties (a) inside the top 200, (b) straddling the 200th place (lowest indices kept) and (c) none at all exercise
+    the kernel's 32-bit rank with its collision check and the 64-bit (key, ~index) fallback.  Stage lists and scores against the oracle."""
+    rng = np.random.default_rng(33)
+    base = S.make_latent(rng, n_tex_lo=330, n_tex_hi=360)
+    R = S.make_mate(rng, cb, base, frac=0.7, n_tex=600)
+    ocb = oracle.codebook(codebook_bytes)
+    m = M.Matcher(codebook_bytes); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
+    hr, _ = oracle.rolled(T.write_rolled(R))
+    t0 = base.tex[0]
+    n = len(t0.x)
+    for ci, groups in enumerate(([], [(10, 40)], [(5, 330)], [(50, 90), (120, 300)])):
+        des = t0.des.copy()
+        for lo, hi in groups:
+            des[lo:hi] = des[lo]
+        L = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(t0.x, t0.y, t0.ori, des=des)])
+        hl, _ = oracle.latent(ocb, T.write_latent(L))
+        for stage in (0, 1, 2):
+            want = oracle.trace(ocb, hl, hr, which=0, stage=stage, tie_mode=1)
+            got = m.debug_stage_list(L, 0, 0, stage)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (ci, stage, got[1][:12], want[1][:12])
+            assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32)), (ci, stage)
+        if groups:                                                     # the ties are really there
+            sim0 = oracle.trace(ocb, hl, hr, which=0, stage=0, tie_mode=1)[0]
+            assert len(np.unique(sim0)) < len(sim0) - 10, ci
+        rc, want_sc = oracle.pair(ocb, hl, hr, 1)
+        got_sc = m.search([L], k=0, want_parts=True)["parts"][0, 0]
+        assert np.array_equal(got_sc.view(np.uint32), want_sc[:4].view(np.uint32)), (ci, got_sc, want_sc)
+        oracle.lib.orc_latent_free(hl)
+    m.close()
+
+
 def test_python_drivers_equal_cli(codebook_bytes, cb, small, tmp_path):
     """host/matcher.py's One2List_matching / List2List_matching (the reference's two drivers, matcher.h:44-51) write the files the
     `match` binary writes, from a directory and from a packed container."""
