@@ -23,10 +23,9 @@ names = {16: "fast: load+gemm", 17: "fast: sums/norm", 18: "fast: stage1", 19: "
          21: "tex graph: dist H bits", 22: "tex graph: dist power iters", 23: "tex graph: dist sort", 24: "tex graph: dist greedy+compact",
          25: "tex graph: angle H bits (inflated)", 26: "tex graph: angle iters", 27: "tex graph: angle sort+greedy"}
 names[12] = "minu graph: list load"; names[28] = "tex graph: S7 top-200 + list build"
-names[16] = "fast: load+gemm (incl. barrier)"; names[18] = "fast: histogram + candidates + exact keys"; names[20] = "fast: rank + write"
-if any(ph[i] for i in (29, 30, 31)):
-    names.update({29: "slot 29", 30: "slot 30", 31: "slot 31"})
-for grp, idxs in (("minutiae candidates", (16, 17, 18, 19, 20)),  ("minutiae graph", range(5, 13)), ("texture graph", range(21, 29))):
+names[29] = "fast:   pass 1: approximate keys + histogram"; names[30] = "fast:   scan for the threshold bin"; names[31] = "fast:   candidate append"
+names[16] = "fast: load+gemm (incl. barrier)"; names[18] = "fast:   exact keys of the candidates"; names[20] = "fast: rank + write"
+for grp, idxs in (("minutiae candidates", (16, 17, 29, 30, 31, 18, 19, 20)),  ("minutiae graph", range(5, 13)), ("texture graph", range(21, 29))):
     tot = sum(ph[i] for i in idxs) or 1
     print(grp, "total Mcycles", round(tot / 1e6))
     for i in idxs:
