@@ -622,6 +622,14 @@ def test_medium_properties_and_sharding(codebook_bytes, cb, oracle, medium):
     r0 = m.search(lats, k=0)
     assert np.array_equal(r0["scores"], r1["scores"])
     m.set_option("minu_generic", 0)
+    # (5b) the ADC chunk size only shapes the launch (auto: ~640 templates, a multiple of 8 chunks): odd sizes, one template per
+    # workgroup and one chunk for the whole shard give the same bits, on the bound + refine kernel and on the direct one
+    for v in (8, 7):
+        m.set_option("adc_variant", v)
+        for chunk in (1, 7, 33, 500, G):
+            m.set_option("chunk", chunk)
+            assert np.array_equal(m.search(lats[:3], k=0)["scores"], r1["scores"][:3]), (v, chunk)
+    m.set_option("chunk", 0); m.set_option("adc_variant", 8)
     # (6) gallery sharding: two contiguous shards with global indices, merged rank lists == single-shard rank lists
     SH = importlib.import_module("msu-latentafis_amd.host.sharding")
     nm, nt = S.gallery_counts(77, G)
