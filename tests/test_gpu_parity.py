@@ -5,11 +5,14 @@ over strictly positive non-tied scores.  The oracle runs in tie_mode=1 (equal ke
 HIP path implements.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
 
 import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 T = importlib.import_module("msu-latentafis_amd.host.templates")
@@ -471,6 +474,15 @@ def test_texture_top200_with_tied_row_maxima(codebook_bytes, cb, oracle):
         assert np.array_equal(got_sc.view(np.uint32), want_sc[:4].view(np.uint32)), (ci, got_sc, want_sc)
         oracle.lib.orc_latent_free(hl)
     m.close()
+
+
+def test_template_shapes_sweep():
+    """Correspondence lists of every length (2-120 minutiae, 20-1000 texture points per template: short lists, nearly empty last row
+    blocks, lists below and above the top-120 / top-200 cuts): tools/shape_sweep.py compares every part score of 8 x 30 pairs with the
+    oracle, bit for bit (the wide run behind DESIGN section 2 is the same script with more seeds)."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shape_sweep.py"), "5", "8", "30"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "differing bit: 0" in out.stdout, (out.stdout[-600:], out.stderr[-600:])
 
 
 def test_python_drivers_equal_cli(codebook_bytes, cb, small, tmp_path):
