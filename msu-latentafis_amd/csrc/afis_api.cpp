@@ -72,7 +72,7 @@ struct afis_ctx {
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 8;                 // 8: 16-bit bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
-    int tile_share = 1;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD (L2 locality of the tables)
+    int tile_share = 4;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD (L2 locality of the tables)
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
@@ -686,7 +686,12 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             // One ADC workgroup fills a CU (128 KB LUT tile), so nothing overlaps its tile load: chunks of ~640 templates keep that
             // under 3 % of a workgroup's life.  The blocks of XCD x are the chunks c % 8 == x, so the chunk COUNT is a multiple of 8
             // (measured at a 12.5k shard: 98 chunks of 128 -> 24 of 521: -9 % ADC time; at 100k: 196 of 512 -> 160 of 625: -2.5 %).
-            const long long n_chunks_auto = ((G + 639) / 640 + 7) / 8 * 8;
+            // With tile_share s the blocks that follow one another on an XCD take s consecutive chunks against the SAME tile (8 instead of 32
+            // tiles' fp32 tables — the refine's gathers — compete for an XCD's L2 at s = 4), so the count is a multiple of 8 s: -4.5 % ADC time
+            // at 100k, -3 % at 12.5k.  (Round-2's first measurement of tile_share, with 196 chunks of 512, had shown a loss: the unbalanced
+            // chunk count hid the gain.)
+            const long long cmul = 8ll * ((ctx->lut_dtype == 16 || ctx->adc_variant == 8) ? ctx->tile_share : 1);
+            const long long n_chunks_auto = ((G + 639) / 640 + cmul - 1) / cmul * cmul;
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
             if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {           // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
