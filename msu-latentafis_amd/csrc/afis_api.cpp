@@ -72,7 +72,7 @@ struct afis_ctx {
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 8;                 // 8: 16-bit bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
-    int tile_share = 4;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD (L2 locality of the tables)
+    int tile_share = 0;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD; 0 = 4 with the exact refine (its fp32 table stays in L2), 1 without
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
@@ -614,6 +614,8 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q)
     delete q;
 }
 
+static int tile_share_of(const afis_ctx* ctx) { return ctx->tile_share > 0 ? ctx->tile_share : (ctx->lut_dtype == 16 ? 1 : 4); }
+
 // S4 + S5 + S6 of the opt-in quantised path for one query group (rm_val / rm_arg sized by the caller)
 // exact == true (adc_variant 8): the quantised pass bounds the candidates, the fp32 table (reference layout, all rows of the group) settles them
 static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hipEvent_t after_lut = nullptr)
@@ -637,7 +639,7 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
     }
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
     HIPCHK(ctx, launch_adc_rowmax_q(d, ctx->gal, ctx->g_tex_codes_q.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->lutq.p, ctx->lutq_rowc.p,
-                                    exact ? ctx->lut32.as<float>() : nullptr, chunk, ctx->tile_share, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
+                                    exact ? ctx->lut32.as<float>() : nullptr, chunk, tile_share_of(ctx), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
     return AFIS_OK;
 }
 
@@ -690,7 +692,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             // tiles' fp32 tables — the refine's gathers — compete for an XCD's L2 at s = 4), so the count is a multiple of 8 s: -4.5 % ADC time
             // at 100k, -3 % at 12.5k.  (Round-2's first measurement of tile_share, with 196 chunks of 512, had shown a loss: the unbalanced
             // chunk count hid the gain.)
-            const long long cmul = 8ll * ((ctx->lut_dtype == 16 || ctx->adc_variant == 8) ? ctx->tile_share : 1);
+            const long long cmul = 8ll * ((ctx->lut_dtype == 16 || ctx->adc_variant == 8) ? tile_share_of(ctx) : 1);
             const long long n_chunks_auto = ((G + 639) / 640 + cmul - 1) / cmul * cmul;
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
@@ -922,7 +924,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     const std::string n(name);
     if (n == "adc_variant") { if (value < 0 || value > 8 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7 or 8"); ctx->adc_variant = (int)value; }
     else if (n == "lut_dtype") { if (value != 16 && value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype must be 32 (exact, default) or 16 (16-bit fixed-point LUT, tolerance path)"); ctx->lut_dtype = (int)value; }
-    else if (n == "tile_share") { if (value < 1 || value > 32) return fail(ctx, AFIS_EINVAL, "tile_share must be 1..32"); ctx->tile_share = (int)value; }
+    else if (n == "tile_share") { if (value < 0 || value > 32) return fail(ctx, AFIS_EINVAL, "tile_share must be 0 (auto) or 1..32"); ctx->tile_share = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
