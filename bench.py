@@ -46,9 +46,33 @@ def physical_cores():
         return os.cpu_count() or 1, os.cpu_count() or 1
 
 
-def cpu_baseline(cb_bytes, lats, gal, lo, budget_s=12.0):
+def host_cpu_limits():
+    """What this process may actually use: the affinity mask and the cgroup CPU quota (a container can see 256 logical CPUs and own 16)."""
+    info = {"affinity_cpus": None, "cgroup_cpu_max": None, "cgroup_quota_cpus": None}
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for pth in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(pth).read().strip()
+            info["cgroup_cpu_max"] = txt
+            if pth.endswith("cpu.max"):
+                q, per = txt.split()
+                if q != "max": info["cgroup_quota_cpus"] = round(float(q) / float(per), 2)
+            else:
+                q = float(txt)
+                if q > 0: info["cgroup_quota_cpus"] = round(q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+            break
+        except Exception:
+            continue
+    return info
+
+
+def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=20):
     """The CPU restatement of the reference path (oracle/, OpenMP) timed on bounded samples of the same workload:
-       compute-only   gallery parsed once and resident in RAM, all host threads          -> the `value` of cpu_baseline
+       compute-only   gallery parsed once and resident in RAM, T host threads taking one pair at a time (dynamic schedule), for T = 8, 16, 32, ...
+                      up to every CPU this process may use: the CURVE is reported, the best point is the `value` of cpu_baseline
        compute-only   8 threads, schedule(static,16): the reference's OpenMP setting (matcher.cpp:168, :273)
        reference-faithful  8 threads, static 16, and every rolled .dat RE-READ AND RE-PARSED for every pair from page-cache-warm
                       files, which is what the reference's loop does (matcher.cpp:173, :278)."""
@@ -58,22 +82,27 @@ def cpu_baseline(cb_bytes, lats, gal, lo, budget_s=12.0):
     from oracle_lib import Oracle
     orc = Oracle()
     ocb = orc.codebook(cb_bytes)
-    threads = orc.lib.orc_num_threads()
-    n_lat = min(2, len(lats))
-    hl = [orc.latent(ocb, T.write_latent(L))[0] for L in lats[:n_lat]]
-    dats = [T.write_rolled(gal.template(g)) for g in range(min(gal.G, 2 * threads))]
-    probe = [orc.rolled(d)[0] for d in dats]
-    t0 = time.perf_counter(); orc.search(ocb, hl[0], probe, tie_mode=1, threads=threads); dt = time.perf_counter() - t0
-    per_pair_wall = dt / max(1, len(probe))
-    n_gal = int(min(gal.G, max(len(probe), budget_s / n_lat / max(per_pair_wall, 1e-6))))
-    dats += [T.write_rolled(gal.template(g)) for g in range(len(probe), n_gal)]
-    hr = probe + [orc.rolled(d)[0] for d in dats[len(probe):]]
-    t0 = time.perf_counter()
-    for h in hl:
-        orc.search(ocb, h, hr, tie_mode=1, threads=threads)
-    wall = time.perf_counter() - t0
+    lim = host_cpu_limits()
+    usable = lim["affinity_cpus"] or orc.lib.orc_num_threads()
+    if lim["cgroup_quota_cpus"]: usable = max(1, min(usable, int(lim["cgroup_quota_cpus"] + 0.5)))
+    ladder = sorted({t for t in (8, 16, 32, 64, 128, 256) if t < usable} | {usable})
+    hl = orc.latent(ocb, T.write_latent(lats[0]))[0]
+    n_max = int(min(gal.G, max(480, pairs_per_thread * ladder[-1])))
+    dats = [T.write_rolled(gal.template(g)) for g in range(n_max)]
+    hr = [orc.rolled(d)[0] for d in dats]
+    orc.search(ocb, hl, hr[:64], tie_mode=1, threads=min(usable, 64))                 # warm: page in the LUT and the code
+    curve = []
+    for t in ladder:
+        n = min(n_max, max(pairs_per_thread * t, 160))
+        dt = 1e30
+        for _ in range(2):                                                 # the first call at a new thread count also starts the OpenMP team: keep the better of two
+            t0 = time.perf_counter(); orc.search(ocb, hl, hr[:n], tie_mode=1, threads=t); dt = min(dt, time.perf_counter() - t0)
+        curve.append({"threads": t, "pairs": n, "pairs_per_s": round(n / dt, 1)})
+    best = max(curve, key=lambda c: c["pairs_per_s"])
     n8 = min(len(hr), 480)
-    t1 = time.perf_counter(); orc.search(ocb, hl[0], hr[:n8], tie_mode=1, threads=0); wall8 = time.perf_counter() - t1
+    wall8 = 1e30
+    for _ in range(2):
+        t1 = time.perf_counter(); orc.search(ocb, hl, hr[:n8], tie_mode=1, threads=0); wall8 = min(wall8, time.perf_counter() - t1)
     # reference-faithful leg: the same n8 templates as files in a tmpdir (written and read once: page-cache warm)
     tmp = tempfile.mkdtemp(prefix="afis_cpu_baseline_")
     try:
@@ -83,15 +112,43 @@ def cpu_baseline(cb_bytes, lats, gal, lo, budget_s=12.0):
             with open(pth, "wb") as f: f.write(dats[g])
             with open(pth, "rb") as f: f.read()
             paths.append(pth)
-        t2 = time.perf_counter(); _, sf = orc.search_files(ocb, hl[0], paths, tie_mode=1, threads=0); wallf = time.perf_counter() - t2
-        _, sr = orc.search(ocb, hl[0], hr[:n8], tie_mode=1, threads=0)
+        t2 = time.perf_counter(); _, sf = orc.search_files(ocb, hl, paths, tie_mode=1, threads=0); wallf = time.perf_counter() - t2
+        _, sr = orc.search(ocb, hl, hr[:n8], tie_mode=1, threads=0)
         assert np.array_equal(sf, sr)                                    # same scores either way; only the time differs
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"pairs_per_s": n_lat * n_gal / wall, "threads": threads,
-            "sample": f"{n_lat} latents x {n_gal} gallery templates (templates {lo}..{lo + n_gal} of the bench gallery), all {threads} host threads",
+    return {"pairs_per_s": best["pairs_per_s"], "threads": best["threads"], "curve": curve, "limits": lim, "usable_cpus": usable,
+            "sample": f"1 latent x {best['pairs']} gallery templates (templates {lo}..{lo + best['pairs']} of the bench gallery), {best['threads']} threads, one pair at a time (dynamic schedule)",
             "pairs_per_s_8_threads": n8 / wall8, "pairs_per_s_reference_faithful": n8 / wallf,
             "sample_8_threads": f"1 latent x {n8} gallery templates, 8 threads schedule(static,16)"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started by hand or by the driver (no torchrun): become the launcher — N copies of this command line, one
+    process per GPU (LOCAL_RANK = GPU), a free rendezvous port on 127.0.0.1; rank 0 owns stdout (the one JSON line)."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   AFIS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+            if p.returncode != 0:                                         # one rank down: the others would wait in the next collective
+                for q in procs:
+                    if q.poll() is None: q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None: q.terminate()
+        rc = 130
+    return rc
 
 
 def main():
@@ -110,6 +167,8 @@ def main():
     ap.add_argument("--lut-dtype", type=int, default=32, help="32 = exact fp32 LUT (the headline path); 16 = opt-in 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "cpp"], help="the rank-list exchange step: torch = torch.distributed all_gather (host/sharding.py); "
+                    "cpp = the `match` host's own exchange (csrc/rank_exchange.cpp: ncclAllGather, or its TCP stand-in with AFIS_EXCHANGE=tcp) through libafis_exchange.so")
     ap.add_argument("--share-gpu", action="store_true", help="test mode: every rank uses GPU 0 (validates the N>1 path on a 1-GPU box)")
     ap.add_argument("--dump-ranks", default="", help="rank 0 writes the merged rank lists of the last step to this .npz (tests)")
     ap.add_argument("--force-dist", action="store_true", help="test mode: initialise torch.distributed and run the exchange step even when WORLD_SIZE is 1")
@@ -117,7 +176,17 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if a.gpus < 1: sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:                     # the driver's form: python bench.py --gpus N (no launcher)
+        n_dev = torch.cuda.device_count()
+        if n_dev < a.gpus and not a.share_gpu:
+            sys.exit(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible (use --share-gpu to put every rank on GPU 0: test mode)")
+        sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and not a.force_dist:
+        sys.exit(f"bench.py: WORLD_SIZE={world} does not match --gpus {a.gpus}")
+    if world > 1 and not a.share_gpu and torch.cuda.device_count() <= local:
+        sys.exit(f"bench.py: rank {rank} wants GPU {local} but only {torch.cuda.device_count()} visible")
     gpu = 0 if a.share_gpu else local
     use_dist = world > 1 or a.force_dist
     if use_dist:
@@ -159,8 +228,12 @@ def main():
     qh = m.upload_queries(lats)
     t_up = time.perf_counter() - t_up
 
+    xch = SH.CppExchange(gpu) if (a.exchange == "cpp" and use_dist) else None     # rendezvous on MASTER_PORT + 1 (torch's store owns MASTER_PORT)
+
     def step():
         r = m.search_resident(qh, k=a.k)
+        if xch is not None:
+            return xch.gather_topk(r["topk_idx"], r["topk_score"], a.k)
         idx, sc = SH.gather_topk(r["topk_idx"], r["topk_score"], a.k, device=dev, force=a.force_dist)
         return idx, sc
 
@@ -223,6 +296,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if a.lut_dtype == 32 else "u16 fixed-point LUT + f32 (tolerance path, NOT the bit-exact headline configuration)", "data": "synthetic",
             "config": {"workload": f"batch {Q} latents vs {G}-template synthetic rolled gallery "
                                    f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists" + ("" if a.lut_dtype == 32 else "; 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4] kernel on one GPU)"), "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
+                       "exchange": ("none (one rank)" if not use_dist else
+                                    ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
+                                    else f"torch: torch.distributed all_gather, backend {a.backend}"),
                        "adc_variant": a.variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
             "roofline": {"bound": "hbm", "kernel": ("k_adc_rowmin_q<1024,true> (16-bit bound pass + exact refine)" if a.variant in (-1, 8) else "k_adc_rowmax (direct exact kernel)") if a.lut_dtype == 32 else "k_adc_rowmin_q<1024,false> (tolerance path)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -244,16 +320,19 @@ def main():
                 cpu_model = "unknown"
             phys, logical = physical_cores()
             pps = cpu["pairs_per_s"]
-            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": phys, "threads": cpu["threads"], "logical_cpus": logical,
+            out["cpu_baseline"] = {"value": round(pps / G, 6), "unit": "queries/s", "cores": cpu["threads"], "threads": cpu["threads"],
+                                   "usable_cpus": cpu["usable_cpus"], "physical_cores": phys, "logical_cpus": logical, "limits": cpu["limits"],
                                    "kind": "port", "sample": cpu["sample"], "cpu_model": cpu_model, "pairs_per_s": round(pps, 1),
+                                   "thread_curve_pairs_per_s": cpu["curve"],
                                    "compute_only_8_threads_static16_queries_per_s": round(cpu["pairs_per_s_8_threads"] / G, 6),
                                    "reference_faithful_8_threads_static16_reparse_per_pair_queries_per_s": round(cpu["pairs_per_s_reference_faithful"] / G, 6),
                                    "sample_8_threads": cpu["sample_8_threads"],
-                                   "note": "value = compute-only oracle on every host thread (gallery resident in RAM); reference-faithful = the reference's own loop: "
-                                           "8 threads, schedule(static,16), every rolled .dat re-parsed per pair from page-cache-warm files (matcher.cpp:168-173)"}
+                                   "note": "value = the best point of the compute-only thread curve (gallery resident in RAM, one pair at a time per thread); cores = the threads of that point; "
+                                           "reference-faithful = the reference's own loop: 8 threads, schedule(static,16), every rolled .dat re-parsed per pair from page-cache-warm files (matcher.cpp:168-173)"}
             out["speedup_vs_cpu_baseline"] = round(value / (pps / G), 1)
     m.free_queries(qh)
     m.close()
+    if xch is not None: xch.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

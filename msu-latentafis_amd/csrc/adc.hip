@@ -529,9 +529,14 @@ __global__ __launch_bounds__(256) void k_lutq_stats(QueryDev q, const float* __r
     }
 }
 
-// tiles of 16 rows; grid = n_tiles16 * 16 (one block per (tile, m)), block = 256 (codeword).  rowc[row] = (6 - sum_m min_m, q_row)
+// tiles of 16 rows; grid = n_tiles16 * 16 (one block per (tile, m)), block = 256 (codeword).
+// rowc[row] = (6 - sum_m min_m, q_row, T_row, 0): T_row is the candidate margin of the exact refine (k_adc_rowmin_q<., true>) in units of q_row.
+// A point whose fp32 similarity equals the row's fp32 maximum has an integer sum S <= S* + 16 + 2 delta / q, where delta bounds the distance
+// between the reference's fp32 four-chain value and the real number 6 - sum_m lut: at most 19 roundings (16 subtractions, 3 additions) of
+// intermediates no larger than 6 + sum_m max_c lut[row][m][c].  The bound is taken from the row's OWN table (24 half-ulps of that magnitude), so
+// it also holds for latent descriptors that are not normalised to 1.73 (larger table entries: larger rounding errors at the same q).
 __global__ __launch_bounds__(256) void k_lutq_build(QueryDev q, const float* __restrict__ codewords, const float* __restrict__ row_min,
-                                                    const float* __restrict__ row_rng, uint4* __restrict__ tiles, float2* __restrict__ rowc)
+                                                    const float* __restrict__ row_rng, uint4* __restrict__ tiles, float4* __restrict__ rowc)
 {
     const int tile = blockIdx.x >> 4, m = blockIdx.x & 15, k = threadIdx.x;
     int qi = 0;
@@ -549,14 +554,17 @@ __global__ __launch_bounds__(256) void k_lutq_build(QueryDev q, const float* __r
         float des6[kDsub];
 #pragma unroll
         for (int d = 0; d < kDsub; ++d) des6[d] = q.lt_des[gr * kDes + m * kDsub + d];
-        float rng = 0.f, msum = 0.f;
-        for (int mm = 0; mm < kM; ++mm) { rng = fmaxf(rng, row_rng[gr * kM + mm]); msum += row_min[gr * kM + mm]; }
+        float rng = 0.f, msum = 0.f, maxsum = 0.f;
+        for (int mm = 0; mm < kM; ++mm) { rng = fmaxf(rng, row_rng[gr * kM + mm]); msum += row_min[gr * kM + mm]; maxsum += row_min[gr * kM + mm] + row_rng[gr * kM + mm]; }
         const float qstep = fmaxf(rng, 1e-30f) / (float)kQMax;
         const float v = lut_entry(des6, cw6) - row_min[gr * kM + m];
         int iq = (int)floorf(v / qstep + 0.5f);
         iq = iq < 0 ? 0 : (iq > kQMax ? kQMax : iq);
         qv[r] = (unsigned short)iq;
-        if (m == 0 && k == 0 && row0 + r < n) rowc[gr] = make_float2(6.0f - msum, qstep);
+        if (m == 0 && k == 0 && row0 + r < n) {
+            const float delta = 24.0f * 5.9604645e-8f * (6.0f + 1.0001f * maxsum);        // 24 x 2^-24 x the largest intermediate (maxsum itself is a rounded sum)
+            rowc[gr] = make_float4(6.0f - msum, qstep, 18.0f + ceilf(fminf(2.0f * delta / qstep, 28000.0f)), 0.0f);
+        }
     }
     uint4* t = tiles + (size_t)tile * kQTileVec + (((m >> 3) << 16 | k << 8 | (m & 7) << 5) >> 4);
     auto pack = [&](int r) { return (uint32_t)qv[r] | ((uint32_t)qv[r + 1] << 16); };
@@ -594,7 +602,7 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(
 // kExact = false: the tolerance path described above.
 // kExact = true (adc_variant 8): the quantised pass is only a BOUND, the results are the exact fp32 ones, bit for bit.  With
 // e = 8 q_i + a few 1e-6 the bound on |q_i * S_j - exact part of sim(i, j)|, every point whose exact similarity equals the row's
-// exact maximum has an integer sum S_j <= S* + T_i, T_i = 16 + ceil(1.5e-5 / q_i) + 2 (S* = the smallest sum).  Each lane also tracks
+// exact maximum has an integer sum S_j <= S* + T_i, T_i = 16 + ceil(2 delta_i / q_i) + 2 (S* = the smallest sum; delta_i from the row's own table, see k_lutq_build).  Each lane also tracks
 // its SECOND smallest sum per row; if no lane's second sum is <= S* + T_i, the lanes whose smallest sum is <= S* + T_i hold every
 // candidate — almost always exactly one, the arg-min itself.  The candidates (typically 1.03 per row) are then evaluated exactly:
 // 16 look-ups in the fp32 table kept in HBM/L2 (reference layout [row][m][code]) in the reference's four-chain order
@@ -602,7 +610,7 @@ __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(
 // threshold, about 1 in 2000) has ALL its points evaluated exactly.  So 800 x 16 exact look-ups per (row, template) become 16.5.
 template <int kAdcThreads, bool kExact>
 __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, GalleryDev g, const uint4* __restrict__ codes_q, const int32_t* __restrict__ q_blk,
-                                                               const uint4* __restrict__ lutq_tiles, const float2* __restrict__ rowc, const float* __restrict__ lut32,
+                                                               const uint4* __restrict__ lutq_tiles, const float4* __restrict__ rowc, const float* __restrict__ lut32,
                                                                int chunk, int n_chunks, int share, float* __restrict__ rm_val, int32_t* __restrict__ rm_arg)
 {
     __shared__ uint4 s_lut[kQTileVec];                        // 128 KB
@@ -631,14 +639,13 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
 #pragma unroll
     for (int s = 0; s < 8; ++s) so[s] = 0x01000000u | (uint32_t)(((((s + pc) & 7) << 1) | pr) << 4);
     const char* lut_b = reinterpret_cast<const char*>(s_lut);
-    // kExact: candidate margins T_i = 18 + 1.5e-5 / q_i of the tile's 16 rows (see above), packed in this lane's slot order
+    // kExact: candidate margins T_i of the tile's 16 rows (k_lutq_build), packed in this lane's slot order
     uint32_t Tphys[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (kExact) {
         uint32_t T[16];
 #pragma unroll
         for (int lr = 0; lr < 16; ++lr) {
-            const float qs = row0 + lr < n_lt ? rowc[lt0 + row0 + lr].y : 1.0f;
-            T[lr] = 18u + (uint32_t)fminf(1.5e-5f / qs, 28000.0f);
+            T[lr] = row0 + lr < n_lt ? (uint32_t)rowc[lt0 + row0 + lr].z : 18u;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
                 if (lane == r) mine = sk;
             }
             if (row_ok) {
-                const float2 rc = rowc[lt0 + row0 + lane];
+                const float4 rc = rowc[lt0 + row0 + lane];
                 const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
                 rm_val[o] = rc.x - rc.y * (float)(mine >> 16);
                 rm_arg[o] = (int32_t)(mine & 0xffffu);
@@ -815,8 +822,9 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t lo = pr ? s63[j] : s63[j + 4], hi = pr ? s63[j + 4] : s63[j];
-                thr[j] = as_u32(__builtin_elementwise_min(as_u16x2(lo) + as_u16x2(Tphys[j]), as_u16x2(0x7fff7fffu)));
-                thr[j + 4] = as_u32(__builtin_elementwise_min(as_u16x2(hi) + as_u16x2(Tphys[j + 4]), as_u16x2(0x7fff7fffu)));
+                // clamped to 0x7ffe: a lane without a point in the last block carries 0x7fff and must never count as a candidate
+                thr[j] = as_u32(__builtin_elementwise_min(as_u16x2(lo) + as_u16x2(Tphys[j]), as_u16x2(0x7ffe7ffeu)));
+                thr[j + 4] = as_u32(__builtin_elementwise_min(as_u16x2(hi) + as_u16x2(Tphys[j + 4]), as_u16x2(0x7ffe7ffeu)));
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
             };
             // (5) fast path: lane r evaluates the single candidate of row r
             float out_v = 0.f; int out_i = 0;
-            if (row_ok) { out_i = myp; out_v = exact_sim(lane, myp); }
+            if (row_ok && (unsigned)myp < (unsigned)n_cur) { out_i = myp; out_v = exact_sim(lane, myp); }   // (a row with no single candidate is settled below)
             // (6) the rare rows: several candidate lanes, or a second-sum hit (then every point of the row)
             while (slow_rows) {                                                    // uniform loop
                 const int r = __ffs(slow_rows) - 1;
@@ -913,7 +921,7 @@ hipError_t launch_lutq_build(const QueryDev& q, int n_rows_total, const float* c
 {
     if (q.n_tiles16 <= 0 || n_rows_total <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_lutq_stats, dim3(n_rows_total), dim3(256), 0, stream, q, codewords, row_min, row_rng);
-    hipLaunchKernelGGL(k_lutq_build, dim3(q.n_tiles16 * 16), dim3(256), 0, stream, q, codewords, row_min, row_rng, (uint4*)tiles, (float2*)rowc);
+    hipLaunchKernelGGL(k_lutq_build, dim3(q.n_tiles16 * 16), dim3(256), 0, stream, q, codewords, row_min, row_rng, (uint4*)tiles, (float4*)rowc);
     return hipGetLastError();
 }
 
@@ -933,9 +941,9 @@ hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const voi
     const long long blocks = (long long)((n_chunks + 8 * share - 1) / (8 * share)) * 8 * share * q.n_tiles16;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     if (lut32) hipLaunchKernelGGL((k_adc_rowmin_q<1024, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                                  (const float2*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
+                                  (const float4*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
     else hipLaunchKernelGGL((k_adc_rowmin_q<1024, false>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                            (const float2*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
+                            (const float4*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
     return hipGetLastError();
 }
 

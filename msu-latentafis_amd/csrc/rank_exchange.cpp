@@ -96,7 +96,8 @@ bool tcp_broadcast(const RankWorld& w, void* buf, size_t len, std::string& err)
 
 static void set_timeouts(int fd, double seconds)
 {
-    timeval tv; tv.tv_sec = (long)seconds; tv.tv_usec = 0;
+    if (seconds < 0.001) seconds = 0.001;                                  // {0,0} would mean "no timeout"
+    timeval tv; tv.tv_sec = (long)seconds; tv.tv_usec = (long)((seconds - (double)tv.tv_sec) * 1e6);
     setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
     setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
 }
@@ -118,6 +119,7 @@ static bool tcp_all_gather(RankWorld& w, const void* send, void* recv, size_t by
         }
         memcpy(recv, send, bytes);
         std::vector<int> peers;
+        std::vector<char> seen((size_t)w.world, 0);                         // every rank contributes exactly one block per exchange
         bool ok = true;
         for (int i = 1; i < w.world && ok; ++i) {
             pollfd pf{w.listen_fd, POLLIN, 0};
@@ -127,8 +129,10 @@ static bool tcp_all_gather(RankWorld& w, const void* send, void* recv, size_t by
             set_timeouts(c, w.timeout_s);
             peers.push_back(c);
             Hdr h{};
-            ok = recv_all(c, &h, sizeof(h)) && h.rank > 0 && h.rank < w.world && h.seq == seq && h.bytes == bytes && recv_all(c, (char*)recv + (size_t)h.rank * bytes, bytes);
-            if (!ok) err = "rank 0: a peer sent a mismatching block in exchange " + std::to_string(seq);
+            ok = recv_all(c, &h, sizeof(h)) && h.rank > 0 && h.rank < w.world && !seen[(size_t)h.rank] && h.seq == seq && h.bytes == bytes &&
+                 recv_all(c, (char*)recv + (size_t)h.rank * bytes, bytes);
+            if (ok) seen[(size_t)h.rank] = 1;
+            else err = "rank 0: a peer sent a mismatching or duplicate block in exchange " + std::to_string(seq);
         }
         for (int c : peers) { if (ok && !send_all(c, recv, bytes * w.world)) { ok = false; err = "rank 0: returning the gathered blocks failed"; } ::close(c); }
         return ok;
@@ -190,10 +194,11 @@ bool world_all_gather(RankWorld& w, const void* send, void* recv, size_t bytes, 
     for (;;) {
         const hipError_t q = hipStreamQuery(s);
         if (q == hipSuccess) return true;
-        if (q != hipErrorNotReady) { err = std::string("exchange failed: ") + hipGetErrorString(q); return false; }
+        if (q != hipErrorNotReady) { err = std::string("exchange failed: ") + hipGetErrorString(q); (void)hipStreamSynchronize(s); return false; }
         if (std::chrono::steady_clock::now() > deadline) {
             err = "exchange timed out after " + std::to_string((int)w.timeout_s) + " s (a peer rank is gone?)";
             (void)ncclCommAbort((ncclComm_t)w.comm); w.comm = nullptr;
+            (void)hipStreamSynchronize(s);                                 // the D2H copy into the caller's buffer may still be queued: nothing may touch `recv` after we return
             return false;
         }
         std::this_thread::sleep_for(std::chrono::microseconds(200));
@@ -250,3 +255,35 @@ void merge_topk(const std::vector<int64_t>& idx, const std::vector<float>& score
 }
 
 }  // namespace afis
+
+// ---- C entry points (libafis_exchange.so): the SAME exchange step for hosts that are not the C++ `match` binary — bench.py --exchange cpp
+// binds them with ctypes so that the timed step contains this file's ncclAllGather, not torch.distributed's.
+extern "C" {
+
+struct afis_exchange { afis::RankWorld w; std::string err; };
+
+// ranks from the environment (RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT: the rendezvous uses MASTER_PORT + 1); NULL on failure
+afis_exchange* afis_exchange_create(int device, char* errbuf, size_t errcap)
+{
+    afis_exchange* x = new afis_exchange();
+    afis::world_from_env(x->w);
+    if (!afis::world_init(x->w, device, x->err)) {
+        if (errbuf && errcap) { strncpy(errbuf, x->err.c_str(), errcap - 1); errbuf[errcap - 1] = 0; }
+        afis::world_finalize(x->w); delete x; return nullptr;
+    }
+    return x;
+}
+int afis_exchange_world(const afis_exchange* x) { return x ? x->w.world : 0; }
+int afis_exchange_rank(const afis_exchange* x) { return x ? x->w.rank : -1; }
+// 1 = RCCL (ncclAllGather), 0 = the TCP stand-in (AFIS_EXCHANGE=tcp)
+int afis_exchange_is_rccl(const afis_exchange* x) { return x && !x->w.tcp ? 1 : 0; }
+// every rank contributes `bytes` bytes; recv gets world * bytes, rank-major.  0 = ok
+int afis_exchange_all_gather(afis_exchange* x, const void* send, void* recv, size_t bytes)
+{
+    if (!x || !send || !recv) return -1;
+    return afis::world_all_gather(x->w, send, recv, bytes, x->err) ? 0 : -2;
+}
+const char* afis_exchange_last_error(const afis_exchange* x) { return x ? x->err.c_str() : "null handle"; }
+void afis_exchange_destroy(afis_exchange* x) { if (x) { afis::world_finalize(x->w); delete x; } }
+
+}  // extern "C"

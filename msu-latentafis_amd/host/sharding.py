@@ -60,3 +60,55 @@ def gather_topk(idx: np.ndarray, score: np.ndarray, k: int, device=None, force: 
     dist.all_gather(gs, ts)
     ai = torch.stack(gi).cpu().numpy(); as_ = torch.stack(gs).cpu().numpy()
     return merge_topk(ai, as_, k)
+
+
+class CppExchange:
+    """The exchange step of the C++ `match` host (csrc/rank_exchange.cpp: ncclAllGather over RCCL / xGMI on a dedicated HIP stream, staged
+    through device buffers; AFIS_EXCHANGE=tcp swaps in the TCP stand-in that lets ranks share a GPU), bound with ctypes from
+    libafis_exchange.so.  Ranks and rendezvous come from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (the id exchange uses
+    MASTER_PORT + 1, IPv4 literal only).  No fallback: a missing library raises."""
+
+    def __init__(self, device: int):
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc", "libafis_exchange.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `make -C msu-latentafis_amd/csrc`")
+        self._C = C
+        lib = self.lib = C.CDLL(path)
+        lib.afis_exchange_create.restype = C.c_void_p; lib.afis_exchange_create.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        lib.afis_exchange_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.afis_exchange_last_error.restype = C.c_char_p; lib.afis_exchange_last_error.argtypes = [C.c_void_p]
+        lib.afis_exchange_destroy.restype = None; lib.afis_exchange_destroy.argtypes = [C.c_void_p]
+        for f in ("afis_exchange_world", "afis_exchange_rank", "afis_exchange_is_rccl"):
+            getattr(lib, f).argtypes = [C.c_void_p]
+        err = C.create_string_buffer(512)
+        self.h = lib.afis_exchange_create(device, err, 512)
+        if not self.h:
+            raise RuntimeError("afis_exchange_create: " + err.value.decode(errors="replace"))
+        self.world = lib.afis_exchange_world(self.h); self.rank = lib.afis_exchange_rank(self.h)
+        self.is_rccl = bool(lib.afis_exchange_is_rccl(self.h))
+
+    def all_gather(self, block: np.ndarray) -> np.ndarray:
+        """block: any contiguous array, the same shape and dtype on every rank -> [world, *block.shape]."""
+        b = np.ascontiguousarray(block)
+        out = np.empty((self.world,) + b.shape, b.dtype)
+        rc = self.lib.afis_exchange_all_gather(self.h, b.ctypes.data, out.ctypes.data, b.nbytes)
+        if rc != 0:
+            raise RuntimeError("afis_exchange_all_gather: " + self.lib.afis_exchange_last_error(self.h).decode(errors="replace"))
+        return out
+
+    def gather_topk(self, idx: np.ndarray, score: np.ndarray, k: int):
+        """One all-gather of the per-rank block [Q][kk] x (idx i64, score f32), as `match -l` sends it, then the merge."""
+        Q, kk = idx.shape
+        blk = np.empty(Q * kk * 12, np.uint8)
+        blk[:Q * kk * 8] = np.ascontiguousarray(idx, np.int64).view(np.uint8).ravel()
+        blk[Q * kk * 8:] = np.ascontiguousarray(score, np.float32).view(np.uint8).ravel()
+        allb = self.all_gather(blk)
+        ai = allb[:, :Q * kk * 8].copy().view(np.int64).reshape(self.world, Q, kk)
+        as_ = allb[:, Q * kk * 8:].copy().view(np.float32).reshape(self.world, Q, kk)
+        return merge_topk(ai, as_, k)
+
+    def close(self):
+        if self.h:
+            self.lib.afis_exchange_destroy(self.h); self.h = None

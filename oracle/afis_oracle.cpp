@@ -727,7 +727,12 @@ int orc_search(void* cb, void* lat, void** rolled, int n, int tie_mode, int thre
     int result = 0;
     int nt = threads <= 0 ? 8 : threads;
     (void)nt;
-#pragma omp parallel for num_threads(nt) schedule(static, 16)
+    // threads <= 0: the reference's pragma (8 threads, static chunks of 16: n/16 chunks bound the threads that get any work).
+    // threads > 0 (the "best the host can do" legs of bench.py): one pair at a time to whichever thread is free.
+#ifdef _OPENMP
+    omp_set_schedule(threads <= 0 ? omp_sched_static : omp_sched_dynamic, threads <= 0 ? 16 : 1);
+#endif
+#pragma omp parallel for num_threads(nt) schedule(runtime)
     for (int j = 0; j < n; ++j) {
         float out[5];
         scores[j] = -1.f;

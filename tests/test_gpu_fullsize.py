@@ -144,3 +144,96 @@ def test_config2_variants_same_bits_on_a_query_slice(headline):
         r = m.search([lats[i] for i in sub], k=24)
         assert np.array_equal(r["scores"], res["scores"][sub]) and np.array_equal(r["topk_idx"], res["topk_idx"][sub]), (v, gen)
     m.set_option("adc_variant", 7); m.set_option("minu_generic", 0)
+
+
+# ---- BASELINE.json configs[3] and configs[4] on ONE GPU by virtual shards ------------------------------------------------------------
+# No 8-GPU node is available to the suite, so the per-rank work of the sharded configurations runs shard after shard on GPU 0: every
+# shard is generated, planted and committed exactly as rank r of an 8-rank job would (S.make_packed_gallery(seed, G, cb, lo, hi),
+# plant_mates(lo=lo), gallery_commit(lo) -> global indices), searched with the default (bit-exact) kernels, and the per-shard top-24
+# lists are merged with the same merge the exchange step feeds (host/sharding.py::merge_topk == rank_exchange.cpp::merge_topk).
+SH = importlib.import_module("msu-latentafis_amd.host.sharding")
+
+
+def _search_shards(codebook_bytes, cb, seed, G, lats, world, k, keep=None, n_partial=3):
+    """Per-shard searches of a G-template gallery cut into `world` contiguous shards balanced by rolled texture points.
+    keep: {global index} whose templates (after planting) and per-part scores are kept for the oracle sample.
+    Returns merged (idx, score), the per-shard lists, planted, and {g: (template, parts[Q][4], scores[Q])} for g in keep."""
+    nm_all, nt_all = S.gallery_counts(seed, G)
+    bounds = SH.shard_bounds(nt_all, world)
+    assert bounds[0][0] == 0 and bounds[-1][1] == G and all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    per_idx, per_sc, kept, planted = [], [], {}, None
+    for lo, hi in bounds:
+        gal = S.make_packed_gallery(seed, G, cb, lo, hi)
+        planted = S.plant_mates(seed, gal, cb, lats, G=G, lo=lo, n_partial=n_partial)
+        m = M.Matcher(codebook_bytes)
+        m.gallery_add_packed(gal); m.gallery_commit(lo)
+        res = m.search(lats, k=k, want_parts=True)
+        m.close()
+        assert res["scores"].shape == (len(lats), hi - lo)
+        p = res["parts"]
+        fused = ((p[..., 0] + p[..., 1]) + p[..., 2]).astype(np.float64) + p[..., 3].astype(np.float64) * 0.3      # matcher.cpp:188
+        assert np.array_equal(fused.astype(np.float32), res["scores"])
+        ar = np.arange(lo, hi)
+        for q in range(len(lats)):                                       # every shard's list is the lexsort of ITS scores, global indices
+            order = np.lexsort((ar, -res["scores"][q].astype(np.float64)))[:k]
+            assert np.array_equal(res["topk_idx"][q], ar[order]) and np.array_equal(res["topk_score"][q], res["scores"][q][order])
+        per_idx.append(res["topk_idx"]); per_sc.append(res["topk_score"])
+        for g in (keep or ()):
+            if lo <= g < hi:
+                kept[g] = (gal.template(g - lo), res["parts"][:, g - lo].copy(), res["scores"][:, g - lo].copy())
+        del gal, res
+    idx, sc = SH.merge_topk(np.stack(per_idx), np.stack(per_sc), k)
+    return idx, sc, bounds, planted, kept
+
+
+def test_config3_eight_virtual_shards_equal_the_single_gpu_run(headline, codebook_bytes, cb):
+    """configs[3]: 100 latents x 100k gallery over 8 shards of ~12.5k (the per-rank workload at N = 8): the merged rank lists are the
+    single-GPU run's, bit for bit."""
+    lats, gal, planted, m, res = headline
+    G = gal.G
+    idx, sc, bounds, planted8, _ = _search_shards(codebook_bytes, cb, 909, G, lats, 8, 24)
+    assert planted8 == planted
+    sizes = [hi - lo for lo, hi in bounds]
+    assert len(bounds) == 8 and max(sizes) - min(sizes) < 0.02 * G / 8    # balanced by texture points: template counts within 2 %
+    assert np.array_equal(idx, res["topk_idx"]) and np.array_equal(sc, res["topk_score"])
+
+
+def test_config4_one_million_templates_in_eight_virtual_shards(codebook_bytes, cb, oracle):
+    """configs[4]: a 1 M-template gallery, 8 shards of ~125k, 12 latents, the default bit-exact kernels (the 16-bit bound pass + exact
+    refine IS this configuration's reduced-precision-LUT kernel).  Planted mates lead every merged list in planting
+    order with global indices up to 10^6; a bit-for-bit oracle sample of every mate + 200 random templates per sampled query."""
+    G, Q, seed, k = 1000000, 12, 31337, 24
+    if os.environ.get("AFIS_TEST_SMALL_HEADLINE"):
+        G = 80000
+    lats = S.make_latents(seed, Q)
+    slots = S.mate_slots(seed, G, Q, 3)
+    rng = np.random.default_rng(8)
+    sample_q = [0, 5, 11]
+    keep = set(int(g) for g in slots.ravel())
+    rand = {q: rng.integers(0, G, 200) for q in sample_q}
+    for q in sample_q:
+        keep |= set(int(g) for g in rand[q])
+    idx, sc, bounds, planted, kept = _search_shards(codebook_bytes, cb, seed, G, lats, 8, k, keep=keep)
+    assert int(slots.max()) > 0.9 * G                                   # the planted indices do span the million
+    for q in range(Q):
+        want = [g for g, _ in planted[q]]
+        assert list(idx[q][:len(want)]) == want, (q, idx[q][:6], want)
+        assert (np.diff(sc[q].astype(np.float64)) <= 0).all() and sc[q][0] > 50
+        ties = np.flatnonzero(np.diff(sc[q]) == 0)
+        assert all(idx[q][t] < idx[q][t + 1] for t in ties)              # equal scores by ascending GLOBAL index
+    ocb = oracle.codebook(codebook_bytes)
+    n_pairs = n_nz = 0
+    for q in range(Q):
+        gidx = [g for g, _ in planted[q]] + (list(int(g) for g in rand[q]) if q in sample_q else [])
+        hl, _ = oracle.latent(ocb, T.write_latent(lats[q]))
+        hr = [oracle.rolled(T.write_rolled(kept[g][0]))[0] for g in gidx]
+        rc, _, want = oracle.search(ocb, hl, hr, tie_mode=1, threads=oracle.lib.orc_num_threads(), want_parts=True)
+        assert rc == 0
+        got = np.array([np.concatenate([kept[g][1][q], [kept[g][2][q]]]) for g in gidx], np.float32)
+        diff = got.view(np.uint32) != want.view(np.uint32)
+        assert not diff.any(), (q, gidx[int(np.argwhere(diff.any(axis=1))[0, 0])], got[diff.any(axis=1)][:2], want[diff.any(axis=1)][:2])
+        for h in hr:
+            oracle.lib.orc_rolled_free(h)
+        oracle.lib.orc_latent_free(hl)
+        n_pairs += len(gidx); n_nz += int((want[:, :4] > 0).sum())
+    assert n_pairs >= 4 * Q + 3 * 190 and n_nz > 100

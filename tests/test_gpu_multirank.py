@@ -133,3 +133,30 @@ def test_match_rank_failure_stops_the_whole_job(match_case, tmp_path):
     res = _run_match(exe, ["-ldir", str(d / "lat"), "-g", str(g2), "-s", str(tmp_path / "o2") + "/", "-c", str(d / "cb.dat")], d / "work", 2, timeout=120)
     assert res[0][0] != 0 and res[1][0] != 0, res
     assert "des_len must be 96" in res[1][2] and "another rank failed" in res[0][2], (res[0][2][-500:], res[1][2][-500:])
+
+
+def test_bench_driver_command_form_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher — the form the round driver uses — must start two ranks by itself, report
+    n_gpus = 2 and give the 1-rank run's rank lists."""
+    import json
+    common = ["--gallery", "3000", "--queries", "6", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-ranks", str(tmp_path / "one.npz")],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    for exchange in ("torch", "cpp"):
+        two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--exchange", exchange,
+                              *common, "--dump-ranks", str(tmp_path / f"two_{exchange}.npz")], capture_output=True, text=True, timeout=900,
+                             env=dict(env, AFIS_EXCHANGE="tcp"))
+        assert two.returncode == 0, two.stderr[-2000:]
+        lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, two.stdout[-1000:]                       # ONE JSON line, from rank 0
+        j2 = json.loads(lines[0])
+        assert j2["n_gpus"] == 2 and j2["rank1_hits"] == "6/6" and j2["config"]["parallelism"] == "gallery-shard x2" and j2["config"]["exchange"].startswith(exchange)
+        a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / f"two_{exchange}.npz")
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["score"], b["score"]), exchange
+    # asking for more GPUs than the box has is an error, not a silent 1-GPU run
+    import torch
+    n = torch.cuda.device_count()
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(2, n + 1)), *common], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0 and "GPU(s) visible" in bad.stderr

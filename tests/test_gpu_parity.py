@@ -932,6 +932,34 @@ def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
     assert np.array_equal(r7["parts"].view(np.uint32), r8["parts"].view(np.uint32))
 
 
+def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_bytes, cb):
+    """The candidate margin of the bound pass comes from each row's own table (k_lutq_build), not from an assumed descriptor norm of 1.73:
+    latent texture descriptors scaled by 8 and 40, shifted by +3, and mixed per row (table entries up to ~10^5: fp32 rounding errors far
+    above the normalised case's 2e-6) against random and near-tie rolled templates.  Variant 8 must equal the direct exact kernel
+    (variant 7) bit for bit, values and first arg-maxima."""
+    rng = np.random.default_rng(77)
+    base = S.make_latent(rng, n_tex_lo=300, n_tex_hi=340)
+    lt = base.tex[0]
+    def rolled(codes):
+        r = S.make_rolled(rng, cb, n_tex=len(codes))
+        r.tex[0].codes[:] = codes
+        return r
+    n = 900
+    near = np.tile(cb.encode(lt.des[7:8]), (n, 1)).astype(np.uint8)
+    near[np.arange(n), rng.integers(0, 16, n)] = rng.integers(0, 256, n).astype(np.uint8)
+    gal = [rolled(rng.integers(0, 256, (n, 16)).astype(np.uint8)), rolled(near), rolled(rng.integers(0, 256, (130, 16)).astype(np.uint8))]
+    m = _matcher(codebook_bytes, gal)
+    per_row = np.where(np.arange(lt.n)[:, None] % 3 == 0, 1.0, np.where(np.arange(lt.n)[:, None] % 3 == 1, 17.0, 0.01)).astype(np.float32)
+    for name, des in (("x8", lt.des * np.float32(8)), ("x40", lt.des * np.float32(40)), ("+3", lt.des + np.float32(3)), ("mixed", lt.des * per_row)):
+        lat = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=np.ascontiguousarray(des, np.float32))])
+        for g in range(len(gal)):
+            m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
+            m.set_option("adc_variant", 8); v8, a8 = m.debug_texture_rowmax(lat, g)
+            assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (name, g, np.argwhere(v7 != v8)[:4], v7[:3], v8[:3])
+            assert np.array_equal(a7, a8), (name, g, np.argwhere(a7 != a8)[:4])
+    m.close()
+
+
 def test_minutiae_coordinates_beyond_the_packed_path(codebook_bytes, cb, oracle):
     """S8a arithmetic paths: pixel coordinates within [0, 2047] take the packed 16-bit predicate (v_pk_sub_i16 + v_dot2), anything larger
     — here offsets of 2040 (straddling the limit), 5000 and 30000 — the generic float arithmetic, where dx*dx + dy*dy is no longer exact.

@@ -135,3 +135,48 @@ def test_cpp_tcp_all_gather_and_agreement_three_ranks():
         outs = [p.communicate(timeout=90) for p in procs]
         assert all(p.returncode == 0 for p in procs), outs
         assert all(want in o[0] and "gathered ok" in o[0] for o in outs), outs
+
+
+def _cpp_exchange_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      AFIS_EXCHANGE="tcp", AFIS_EXCHANGE_TIMEOUT_S="30")
+    x = SH.CppExchange(0)                                               # tcp stand-in: no device is touched
+    rng = np.random.default_rng(3)
+    Q, G, k = 4, 400, 24
+    scores = np.round(rng.random((Q, G)).astype(np.float32) * 30, 0)
+    lo, hi = SH.shard_bounds(np.ones(G), world)[rank]
+    pi, ps = shard_topk(scores, lo, hi, k)
+    ok = True
+    for _ in range(3):                                                  # the exchange counter must stay in step over repeated steps
+        mi, ms = x.gather_topk(pi, ps, k)
+        wi, ws = brute_topk(scores, k)
+        ok = ok and bool(np.array_equal(mi, wi) and np.array_equal(ms, ws))
+    q.put((rank, ok, x.world, x.is_rccl))
+    x.close()
+
+
+def test_cpp_exchange_binding_world3_tcp():
+    """bench.py --exchange cpp: libafis_exchange.so's afis_exchange_* entry points (the `match` host's own exchange step) from Python,
+    three ranks, over the TCP stand-in — same merged lists as the global top-k."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cpp_exchange_worker, args=(r, 3, port - 1, q)) for r in (2, 1, 0)]
+    for p in procs: p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert sorted(res) == [(0, True, 3, False), (1, True, 3, False), (2, True, 3, False)]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` (the driver's form) is a launcher: with fewer than N devices it must fail loudly, never run one rank."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(2, n + 1))], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "does not match --gpus" in r.stderr
