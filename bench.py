@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--tile-share", type=int, default=0)
     ap.add_argument("--lut-dtype", type=int, default=32, help="32 = exact fp32 LUT (the headline path); 16 = opt-in 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (a few atomics per pair; not for timed runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "cpp"], help="the rank-list exchange step: torch = torch.distributed all_gather (host/sharding.py); "
                     "cpp = the `match` host's own exchange (csrc/rank_exchange.cpp: ncclAllGather, or its TCP stand-in with AFIS_EXCHANGE=tcp) through libafis_exchange.so")
@@ -222,6 +223,7 @@ def main():
     if a.chunk > 0: m.set_option("chunk", a.chunk)
     if a.lut_dtype != 32: m.set_option("lut_dtype", a.lut_dtype)
     if a.tile_share > 0: m.set_option("tile_share", a.tile_share)
+    if a.refine_stats: m.set_option("mf_stats", 1)
     t_up = time.perf_counter()
     m.gallery_add_packed(gal)
     m.gallery_commit(lo)
@@ -310,6 +312,7 @@ def main():
                          "limiting_resource": "VALU issue (about one VALU instruction per 4.4 cycles per SIMD, profiles/r02_pmc_sq_summary.txt); LDS array about half busy",
                          "pipeline_achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / 1.0, 3)},
             "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
+            "refine_stats": m.refine_stats() if a.refine_stats else None,
             "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -219,6 +219,10 @@ int afis_debug_atan2_grid(afis_ctx* ctx, int R, float* out);
  * [0, 4802]^2), pairs inside the guard band, wrong decisions; out8[4..6] = the same for minutiae pairs near the 30 px threshold
  * (4e8 of them).  out8[0], [3], [6] must be 0. */
 int afis_debug_graph_arith(afis_ctx* ctx, unsigned long long* out8);
+/* adc_variant 9 with afis_set_option("mf_stats", 1): counters of the selection / recomputation kernel since the last reset:
+ * out8[0] pairs, [1] latent rows, [2] rows evaluated exactly, [3] candidate cells evaluated, [4] rows evaluated over every point,
+ * [5] rows whose exact maximum lay outside the bounds the selection used (a self-check: must be 0). */
+int afis_debug_refine_stats(afis_ctx* ctx, unsigned long long* out8, int reset);
 
 /* In-kernel phase timers (only when the library is built with PHASE_TIMING=1; all zeros otherwise): 32 cycle counters
  * accumulated since the last reset.  Development aid. */

@@ -26,18 +26,6 @@ namespace afis {
 //   variant 6 : ((mg&1)*4096 + k*16 + c*4 + rq*2 + (mg>>1))*4 + r4   — same bank slots; the byte address is
 //               (mg&1) << 16 | code << 8 | slot << 4, i.e. one v_perm_b32 of the code word (see k_adc_rowmax_cf)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lut_entry(const float* __restrict__ des6, const float* __restrict__ cw6)
-{
-    float dist = 0.0f;
-#pragma unroll
-    for (int d = 0; d < kDsub; ++d) {
-        float t = des6[d] - cw6[d];
-        float t2 = t * t;
-        dist += t2;
-    }
-    return dist;
-}
-
 __global__ __launch_bounds__(256) void k_lut_build(QueryDev q, const float* __restrict__ codewords, float* __restrict__ lut_tiles, int variant)
 {
     const int tile = blockIdx.x >> 4;                       // 16 blocks of 256 threads per tile = 4096 (m,k) entries

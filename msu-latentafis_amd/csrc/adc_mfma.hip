@@ -1,0 +1,573 @@
+// adc_mfma.hip — S5 + S6 (+ the part of S7 that decides which rows matter), adc_variant 9:
+//   a matrix-core BOUND pass over every (latent texture row, rolled texture point) cell, then the reference's own table arithmetic
+//   (include.h:327-359, matcher.cpp:563-595, :723-735) on the few cells that can decide a result.  Results are the reference's bits.
+//
+// Why a contraction is hiding in the table look-ups.  lut[i][m][c] = |a_im - cw_mc|^2 (a = latent descriptor, cw = codeword), so
+//   sim(i, j) = 6 - sum_m lut[i][m][code_jm] = (6 - |a_i|^2) + 2 (a_i . b_j - |b_j|^2 / 2),   b_j = the codewords of point j side by side.
+// The bracket is a 96-long dot product per cell: 671 x 800 x 96 MACs per pair, which the fp16 matrix cores do in a sixth of the time
+// the LDS table look-ups of variant 8 take.  The price is precision: fp16 operands put the computed G(i, j) = a_i~ . b_j~ - |b_j|^2 / 2
+// within E_i of the real number — good enough to BOUND (E_i is computed per latent row from the row's own rounding residuals and the
+// codebook's, no norm assumption) but not to score.  So:
+//   1. k_adc_mfma: per (row, rolled template) the location of the largest G and of everything within T_i = 2 E_i + ... of it — normally
+//      one point.  Lane = latent row (the MFMA's N index), registers = rolled points (M index): the maximum over a template's points is
+//      lane-local, tracked over two partitions of the lane's values (by accumulator slot, by tile) with v_max3 / v_med3 at 1.25 VALU per
+//      value; the intersection of the best slot and the best tile IS the point, and the runners-up of both partitions bound every other
+//      candidate (a point within T of the best lies in a slot AND a tile whose maxima are within T of it).
+//   2. k_tex_refine: per (latent, rolled) pair the rows that can still reach the top 200 (S7) by their bounds c_i + 2 G +- Es_i, and for
+//      those rows the exact similarity of each candidate point — the table entries RECOMPUTED from the fp32 descriptor and the fp32
+//      codebook in LDS with lut_entry(), summed in the reference's four chains.  Every other row gets -inf (it cannot be among the 200).
+// The rolled points' fp16 reconstructions never exist in memory: a workgroup decodes 128 points at a time from their 16 code bytes through
+// the fp16 codebook in LDS (64 KB) straight into MFMA operand layout (another 48 KB of LDS, double buffered); HBM carries 20 bytes per point.
+#include "afis_device.h"
+#include <algorithm>
+
+namespace afis {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMfThreads = 512;             // 8 waves: two per SIMD, <= 256 VGPRs each
+constexpr int kMfRowBlocks = 16;            // row blocks (32 latent rows) per workgroup, two per wave
+constexpr int kMfStageTiles = 4;            // tiles (32 points) per LDS stage = 2 pairs
+constexpr float kMfNeg = -1.0e30f;          // "no point": the accumulator start of padding points
+
+__device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __uint_as_float(x); }
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32
+__device__ __forceinline__ float med3f(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Codebook in fp16, one 16-byte entry per (m, c): 6 halves (round to nearest) + 4 bytes of padding; and |cw_mc|^2 per entry.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mf_codebook(const float* __restrict__ cw, uint4* __restrict__ cw16, float* __restrict__ cwn)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const float* w = cw + (size_t)e * kDsub;
+    uint32_t h[6];
+    double n2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < kDsub; ++d) {
+        const _Float16 x = (_Float16)w[d];
+        h[d] = (uint32_t)__builtin_bit_cast(unsigned short, x);
+        n2 += (double)w[d] * (double)w[d];
+    }
+    cw16[e] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), 0u);
+    cwn[e] = (float)n2;
+}
+
+// Pair-aligned copy of the gallery's texture codes: template t owns ceil(n/64) pairs of tiles (64 entries of 16 code bytes, zero beyond
+// the template's points) starting at pair q_blk[t]; per entry also G's point term -|b_j|^2 / 2 (kMfNeg beyond the points), and per pair
+// (template, pair index in the template | 256 on the template's last pair).  grid = G, block = 64.
+__global__ __launch_bounds__(64) void k_mf_pairs(GalleryDev g, const int32_t* __restrict__ q_blk, const float* __restrict__ cwn,
+                                                 uint4* __restrict__ codes_p, float* __restrict__ nrm_p, int2* __restrict__ pair_meta)
+{
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int p0 = g.tex_off[t], n = g.tex_off[t + 1] - p0;
+    const int nb = (n + 63) >> 6;
+    for (int k = 0; k < nb; ++k) {
+        const int p = k * 64 + lane;
+        uint4 c = make_uint4(0, 0, 0, 0);
+        float nrm = kMfNeg;
+        if (p < n) {
+            c = g.tex_codes[p0 + p];
+            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+            float s = 0.0f;
+#pragma unroll
+            for (int m = 0; m < kM; ++m) s += cwn[m * kK + ((w[m >> 2] >> (8 * (m & 3))) & 255u)];
+            nrm = -0.5f * s;
+        }
+        const size_t e = ((size_t)q_blk[t] + k) * 64 + lane;
+        codes_p[e] = c; nrm_p[e] = nrm;
+        if (lane == 0) pair_meta[q_blk[t] + k] = make_int2(t, k | (k == nb - 1 ? 256 : 0));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Per latent texture row (grid = padded rows, block = 256 = codeword index): the row in fp16 as MFMA B-operand fragments, and its constants
+//   rowk[i] = (c_i, Es_i, Tg_i, force)
+// With a~ = fp16(a), b~ = fp16(cw), da = a - a~, db = cw - b~ (exact differences) and G = fl(a~ . b~) + n_j, n_j = fl(-|b_j|^2 / 2):
+//   |G - (a . b_j - |b_j|^2 / 2)| <= Eg = sum_m max_c |da_m . cw_mc| + sum_m max_c |a~_m . db_mc| + accumulation + n_j rounding
+// (per sub-quantizer the codeword of point j is ONE of the 256, so the per-m maxima bound every point), and
+//   delta = the reference's own fp32 rounding of 6 - sum lut (19 roundings of intermediates <= 6 + sum_m max_c lut, as in adc.hip::k_lutq_build),
+//   pert  = what replacing the low 5 mantissa bits of a tracked value by an index can move it.
+//   Tg (units of G)   = 2 Eg + delta + 2 pert : a point whose REFERENCE similarity equals the row maximum has G >= G_best - Tg
+//   Es (units of sim) = 2 Eg + delta + 2 pert + rounding of c_i : the reference's row maximum lies in c_i + 2 G_best +- Es.
+// force = 1 (and Tg = Es = inf) for rows whose descriptors fp16 cannot carry (|a| > 1000, non-finite bounds): every cell is then evaluated exactly.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_des, int n_rows, const float* __restrict__ cw, const float* __restrict__ cwn,
+                                                 _Float16* __restrict__ bfrag, float4* __restrict__ rowk)
+{
+    __shared__ float s_a[kDes], s_ah[kDes];
+    __shared__ float s_red[4][5];
+    const int row = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+    const bool real = row < n_rows;
+    if (c < kDes) {
+        const float a = real ? lt_des[(size_t)row * kDes + c] : 0.0f;
+        const bool fits = fabsf(a) <= 1000.0f;                          // (false for NaN as well)
+        const _Float16 ah = (_Float16)(fits ? a : 0.0f);
+        s_a[c] = a; s_ah[c] = (float)ah;
+        const int kk = c >> 4, half = (c >> 3) & 1, e = c & 7, r = row & 31, rb = row >> 5;
+        bfrag[(((size_t)rb * 6 + kk) * 64 + r + 32 * half) * 8 + e] = ah;
+    }
+    __syncthreads();
+    if (!real) return;
+    double P = 0.0, Q = 0.0, L = 0.0, S = 0.0, N = 0.0;
+    for (int m = 0; m < kM; ++m) {
+        const float* w = cw + ((size_t)m * kK + c) * kDsub;
+        float p = 0.f, q = 0.f, sabs = 0.f, a6[kDsub], w6[kDsub];
+#pragma unroll
+        for (int d = 0; d < kDsub; ++d) {
+            const float wf = w[d], wh = (float)(_Float16)wf, a = s_a[m * kDsub + d], ah = s_ah[m * kDsub + d];
+            p = __builtin_fmaf(a - ah, wf, p); q = __builtin_fmaf(ah, wf - wh, q); sabs = __builtin_fmaf(fabsf(ah), fabsf(wh), sabs);
+            a6[d] = a; w6[d] = wf;
+        }
+        float v[5] = {fabsf(p), fabsf(q), lut_entry(a6, w6), sabs, cwn[m * kK + c]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float x = v[k];
+            if (!(x == x)) x = INFINITY;                                // NaN input: unbounded
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
+            v[k] = x;
+        }
+        __syncthreads();
+        if (lane == 0) { for (int k = 0; k < 5; ++k) s_red[wave][k] = v[k]; }
+        __syncthreads();
+        if (c == 0) {
+            float r[5];
+            for (int k = 0; k < 5; ++k) r[k] = fmaxf(fmaxf(s_red[0][k], s_red[1][k]), fmaxf(s_red[2][k], s_red[3][k]));
+            P += r[0]; Q += r[1]; L += r[2]; S += r[3]; N += 0.5 * r[4];
+        }
+    }
+    if (c == 0) {
+        double A2 = 0.0; bool fits = true;
+        for (int k = 0; k < kDes; ++k) { A2 += (double)s_a[k] * (double)s_a[k]; fits = fits && fabsf(s_a[k]) <= 1000.0f; }
+        const double u = 5.9604644775390625e-8;                          // 2^-24
+        const double mag = S + N;                                        // no partial sum of the accumulation is larger
+        const double Eg = 1.001 * (P + Q) + 100.0 * u * mag + 32.0 * u * N + 1e-9;
+        const double pert = 64.0 * u * mag;
+        const double delta = 24.0 * u * (6.0 + 1.0001 * L);
+        double Tg = 2.0 * Eg + delta + 2.0 * pert;
+        double Es = 2.0 * Eg + 2.0 * pert + delta + 4.0 * u * fmax(8.0, 6.0 + A2);
+        const bool force = !fits || !(Tg < 1e20) || !(Es < 1e20);
+        if (force) { Tg = INFINITY; Es = INFINITY; }
+        rowk[row] = make_float4((float)(6.0 - A2), (float)(Es * 1.000001), (float)(Tg * 1.000001), force ? 1.0f : 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The bound pass.  grid = row groups (512 latent rows) x gallery chunks, block = 512.
+//   LDS: fp16 codebook (64 KB) + two stages of 4 tiles: per tile 12 operand groups x 32 points x 16 B (group gidx = halves 8 gidx .. 8 gidx + 7
+//   of the point's 96, i.e. exactly what lane (point, k half) of MFMA step gidx / 2 wants: reads and writes are conflict free) + 32 point terms.
+//   Every thread decodes one (point, 4 sub-quantizers) item per stage: 4 codebook reads (12 bytes used of 16), 3 operand-group writes — three
+//   groups are exactly four codewords' 24 halves, so no repacking arithmetic at all.
+//   Wave w keeps the B fragments of row blocks 2w, 2w + 1 in 48 registers for its whole life and runs every tile through both.
+//   D[point][row]: lane = (row = lane & 31, h = lane >> 5), register r = point (r & 3) + 8 (r >> 2) + 4 h of the tile; the C operand of the first
+//   MFMA of a tile is the points' term n_j, so a finished accumulator IS G.
+// Records: rec[(template * 2 + h) * R_pad + row] = (value of the lane's best point, descriptor):
+//   bits 0-4 / 5-9 best / second tile, 10-13 / 14-17 best / second slot, 18 second tile within T, 19 second slot within T, 20 "many" (a third
+//   tile or slot within T, or a forced row): candidates = {tiles} x {slots}; point = 32 tile + (slot & 3) + 8 (slot >> 2) + 4 h.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct __align__(16) MfStage {
+    uint4 a[kMfStageTiles][12][32];
+    float nrm[kMfStageTiles][32];
+};
+
+__global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
+                                                          const int2* __restrict__ pair_meta, const int32_t* __restrict__ pair0, const uint4* __restrict__ cw16,
+                                                          const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
+                                                          int n_rg, int chunk, uint2* __restrict__ rec)
+{
+    __shared__ uint4 s_cw[kM * kK];                                     // 64 KB
+    __shared__ MfStage s_st[2];                                         // 2 x 25 088 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
+    const int t_lo = chunk_id * chunk, t_hi = min(g.G, t_lo + chunk);
+    if (t_lo >= t_hi) return;
+    const int pair_lo = pair0[t_lo], pair_hi = pair0[t_hi];
+    const int n_pairs = pair_hi - pair_lo;
+    if (n_pairs <= 0) return;
+    const int n_stages = (n_pairs + 1) >> 1;
+    for (int i = tid; i < kM * kK; i += kMfThreads) s_cw[i] = cw16[i];
+
+    const int h = lane >> 5, col = lane & 31;
+    const int rb0 = rg * kMfRowBlocks + wave * 2;
+    const bool wave_ok = rb0 < n_rb;                                   // a wave whose row blocks lie beyond the group only decodes
+    half8 bf[2][6];
+    float Tg[2]; bool row_ok[2], force[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int rb = rb0 + blk;
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+            const uint4 v = rb < n_rb ? bfrag[((size_t)rb * 6 + kk) * 64 + lane] : make_uint4(0, 0, 0, 0);
+            bf[blk][kk] = __builtin_bit_cast(half8, v);
+        }
+        const int row = rb * 32 + col;
+        row_ok[blk] = row < n_rows;
+        const float4 rk = row_ok[blk] ? rowk[row] : make_float4(0.f, 0.f, 0.f, 0.f);
+        Tg[blk] = rk.z; force[blk] = rk.w != 0.0f;
+    }
+
+    // producer identity: point pp of tile pj of the stage, sub-quantizers 4 pQ .. 4 pQ + 3
+    const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;
+    auto fetch = [&](int s, uint32_t& code, float& nrm) {
+        const int pair = pair_lo + 2 * s + (pj >> 1);
+        code = 0u; nrm = kMfNeg;
+        if (pair < pair_hi) {
+            const size_t e = (size_t)pair * 64 + (pj & 1) * 32 + pp;
+            code = reinterpret_cast<const uint32_t*>(codes_p)[e * 4 + pQ];
+            if (pQ == 0) nrm = nrm_p[e];
+        }
+    };
+    auto decode = [&](int buf, uint32_t code, float nrm) {
+        uint4 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = s_cw[(4 * pQ + i) * kK + ((code >> (8 * i)) & 255u)];
+        MfStage& st = s_st[buf];
+        st.a[pj][3 * pQ + 0][pp] = make_uint4(w[0].x, w[0].y, w[0].z, w[1].x);
+        st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
+        st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
+        if (pQ == 0) st.nrm[pj][pp] = nrm;
+    };
+    uint32_t code_cur, code_nxt = 0u; float nrm_cur, nrm_nxt = kMfNeg;
+    fetch(0, code_cur, nrm_cur);
+    __syncthreads();                                                    // the codebook is in LDS
+    decode(0, code_cur, nrm_cur);
+    fetch(1, code_cur, nrm_cur);                                        // (beyond the chunk: zeros)
+    __syncthreads();
+
+    // tracking state per row block: slot maxima over the template's tiles, top three tile maxima (low 5 bits = tile index)
+    float m[2][16], tb[2], ts[2], tu[2];
+    auto reset = [&]() {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m[blk][k] = kMfNeg;
+            tb[blk] = ts[blk] = tu[blk] = kMfNeg;
+        }
+    };
+    reset();
+
+    for (int s = 0; s < n_stages; ++s) {
+        fetch(s + 2, code_nxt, nrm_nxt);                                // two stages ahead: its latency hides under this stage's MFMAs
+        const MfStage& st = s_st[s & 1];
+        if (wave_ok) {
+#pragma unroll
+            for (int u = 0; u < kMfStageTiles / 2; ++u) {
+                const int pair = pair_lo + 2 * s + u;
+                if (pair >= pair_hi) break;
+                const int2 meta = pair_meta[pair];                      // wave-uniform: scalar load
+                const int tX = 2 * u, tY = 2 * u + 1;
+                floatx16 nX, nY;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 vx = *reinterpret_cast<const float4*>(&st.nrm[tX][8 * q4 + 4 * h]);
+                    const float4 vy = *reinterpret_cast<const float4*>(&st.nrm[tY][8 * q4 + 4 * h]);
+                    nX[4 * q4] = vx.x; nX[4 * q4 + 1] = vx.y; nX[4 * q4 + 2] = vx.z; nX[4 * q4 + 3] = vx.w;
+                    nY[4 * q4] = vy.x; nY[4 * q4 + 1] = vy.y; nY[4 * q4 + 2] = vy.z; nY[4 * q4 + 3] = vy.w;
+                }
+                floatx16 X0 = nX, X1 = nX, Y0 = nY, Y1 = nY;
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) {
+                    const half8 aX = __builtin_bit_cast(half8, st.a[tX][2 * kk + h][col]);
+                    const half8 aY = __builtin_bit_cast(half8, st.a[tY][2 * kk + h][col]);
+                    X0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX, bf[0][kk], X0, 0, 0, 0);
+                    X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX, bf[1][kk], X1, 0, 0, 0);
+                    Y0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aY, bf[0][kk], Y0, 0, 0, 0);
+                    Y1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aY, bf[1][kk], Y1, 0, 0, 0);
+                }
+                const uint32_t tiX = (uint32_t)(2 * (meta.y & 255)), tiY = tiX + 1u;
+                auto track = [&](int blk, const floatx16& X, const floatx16& Y) {
+                    float x = max3f(X[0], X[1], X[2]), y = max3f(Y[0], Y[1], Y[2]);
+#pragma unroll
+                    for (int k = 3; k < 15; k += 2) { x = max3f(x, X[k], X[k + 1]); y = max3f(y, Y[k], Y[k + 1]); }
+                    x = fmaxf(x, X[15]); y = fmaxf(y, Y[15]);
+                    const float ex = u2f((f2u(x) & ~31u) | tiX), ey = u2f((f2u(y) & ~31u) | tiY);
+                    tu[blk] = med3f(ts[blk], ex, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], ex); tb[blk] = fmaxf(tb[blk], ex);
+                    tu[blk] = med3f(ts[blk], ey, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], ey); tb[blk] = fmaxf(tb[blk], ey);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) m[blk][k] = max3f(m[blk][k], X[k], Y[k]);
+                };
+                track(0, X0, Y0);
+                track(1, X1, Y1);
+                if (meta.y & 256) {                                     // the template's last pair: its records, then a fresh state
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const float e = u2f((f2u(m[blk][k]) & ~15u) | (uint32_t)k);
+                            u3 = med3f(s3, e, u3); s3 = med3f(b3, s3, e); b3 = fmaxf(b3, e);
+                        }
+                        const float thr = fminf(tb[blk], b3) - Tg[blk];
+                        const bool many = (tu[blk] >= thr) | (u3 >= thr) | force[blk];
+                        const uint32_t desc = (f2u(tb[blk]) & 31u) | ((f2u(ts[blk]) & 31u) << 5) | ((f2u(b3) & 15u) << 10) | ((f2u(s3) & 15u) << 14) |
+                                              ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
+                        if (row_ok[blk]) rec[((size_t)meta.x * 2 + h) * R_pad + (size_t)(rb0 + blk) * 32 + col] = make_uint2(f2u(b3), desc);
+                    }
+                    reset();
+                }
+            }
+        }
+        if (s + 1 < n_stages) decode((s + 1) & 1, code_cur, nrm_cur);
+        code_cur = code_nxt; nrm_cur = nrm_nxt;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Selection by bounds + exact evaluation.  Persistent workgroups of 8 waves (the fp32 codebook, 96 KB, in LDS); each wave draws
+// (latent, rolled) pairs from a counter and owns a 4 KB item list.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int kRfWaves = 8, kRfItems = 512;
+struct __align__(16) RfWave { unsigned short row[kRfItems]; unsigned short pt[kRfItems]; float val[kRfItems]; };
+
+__device__ __forceinline__ uint32_t ord_f32(float v) { const uint32_t b = f2u(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+// this wave's own LDS traffic in program order (the waves of the workgroup work on different pairs: no workgroup barrier may be used)
+#define RF_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+__device__ __forceinline__ int rf_next_task(int32_t* ctr)               // one atomic by lane 0 (see graph.hip::next_task for why it is asm)
+{
+    int t;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(t), "=&s"(saved) : "v"(0), "v"(1), "s"(ctr) : "memory");
+    return __builtin_amdgcn_readfirstlane(t);
+}
+
+__device__ __forceinline__ void rf_argmax(float& v, int& i)             // value descending, point ascending: the FIRST maximum
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(i, off);
+        const bool take = (ov > v) | ((ov == v) & (oi < i));
+        v = take ? ov : v; i = take ? oi : i;
+    }
+}
+
+// stats (optional): [0] pairs, [1] rows, [2] active rows, [3] items evaluated, [4] rows evaluated in full, [5] rows whose exact maximum fell outside its bounds (must stay 0)
+__global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, GalleryDev g, const float* __restrict__ cw32, const uint2* __restrict__ rec,
+                                                               const float4* __restrict__ rowk, int R_pad, int all_rows, float* __restrict__ rm_val,
+                                                               int32_t* __restrict__ rm_arg, int32_t* __restrict__ task_ctr, unsigned long long* __restrict__ stats)
+{
+    __shared__ float s_cw[kM * kK * kDsub];                             // 96 KB
+    __shared__ RfWave s_w[kRfWaves];                                    // 32 KB
+    for (int i = threadIdx.x; i < kM * kK * kDsub; i += kRfWaves * 64) s_cw[i] = cw32[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    RfWave& W = s_w[threadIdx.x >> 6];
+    const int n_tasks = q.nq * g.G;
+    for (;;) {
+        const int task = rf_next_task(task_ctr);
+        if (task >= n_tasks) break;
+        const int qi = task / g.G, gi = task - qi * g.G;
+        const int l0 = q.lt_off[qi], n_lt = q.lt_off[qi + 1] - l0;
+        const int r0 = g.tex_off[gi], n_rt = g.tex_off[gi + 1] - r0;
+        if (n_lt <= 0 || n_rt <= 0) continue;                           // no texture on one side: the scorer is not called (matcher.cpp:411)
+        const size_t o = (size_t)task * q.lt_pad;
+        const uint2* rec0 = rec + ((size_t)gi * 2 + 0) * R_pad + l0;
+        const uint2* rec1 = rec + ((size_t)gi * 2 + 1) * R_pad + l0;
+        const float* des = q.lt_des + (size_t)l0 * kDes;
+
+        // exact similarity of latent row e and rolled point p: table entries recomputed (include.h:327-359), the four chains of matcher.cpp:571-592
+        auto exact_sim = [&](int e, int p) -> float {
+            const uint4 cd = g.tex_codes[r0 + p];
+            const uint32_t w4[4] = {cd.x, cd.y, cd.z, cd.w};
+            const float4* a4 = reinterpret_cast<const float4*>(des + (size_t)e * kDes);
+            float d[4] = {6.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+                float a[24];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { const float4 v = a4[mg * 6 + k]; a[4 * k] = v.x; a[4 * k + 1] = v.y; a[4 * k + 2] = v.z; a[4 * k + 3] = v.w; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int mm = 4 * mg + c;
+                    const float2* wv = reinterpret_cast<const float2*>(s_cw + ((size_t)mm * kK + ((w4[mg] >> (8 * c)) & 255u)) * kDsub);
+                    const float2 w0 = wv[0], w1 = wv[1], w2 = wv[2];
+                    const float w6[kDsub] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                    d[c] -= lut_entry(a + 6 * c, w6);
+                }
+            }
+            return (d[0] + d[1]) + (d[2] + d[3]);
+        };
+
+        // ---- A: bounds of every row's maximum -------------------------------------------------------------------------------
+        constexpr int kRegs = (kTexMax + 63) / 64;
+        const int n_regs = (n_lt + 63) >> 6;
+        uint32_t klo[kRegs], khi[kRegs];
+#pragma unroll
+        for (int u = 0; u < kRegs; ++u) {
+            const int e = u * 64 + lane;
+            klo[u] = 0u; khi[u] = 0u;
+            if (u < n_regs && e < n_lt) {
+                const uint2 a = rec0[e], b = rec1[e];
+                const float4 rk = rowk[l0 + e];
+                const float mid = rk.x + 2.0f * fmaxf(u2f(a.x), u2f(b.x));
+                // rounding of mid itself (|mid| <= a few units): two more ulps on either side
+                klo[u] = ord_f32(mid - rk.y - 4e-6f * fmaxf(1.0f, fabsf(mid))); khi[u] = ord_f32(mid + rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid)));
+            }
+        }
+        // ---- B: the 200th largest LOWER bound; a row whose UPPER bound is below it cannot be among the 200 (matcher.cpp:736-747) ----
+        uint32_t C = 0u;
+        if (!all_rows && n_lt > kTopTex) {
+            for (int bit = 31; bit >= 0; --bit) {
+                const uint32_t cand = C | (1u << bit);
+                int cnt = 0;
+#pragma unroll
+                for (int u = 0; u < kRegs; ++u) if (u < n_regs) cnt += __popcll(__ballot(klo[u] >= cand));
+                if (cnt >= kTopTex) C = cand;
+            }
+        }
+        // ---- C: candidate items of the active rows ------------------------------------------------------------------------
+        int n_items = 0;
+        unsigned long long st_active = 0, st_items = 0, st_full = 0;
+        auto flush = [&]() {
+            RF_WSYNC();
+            for (int it = lane; it < n_items; it += 64) W.val[it] = exact_sim(W.row[it], W.pt[it]);
+            RF_WSYNC();
+            for (int it = lane; it < n_items; it += 64) {
+                const int row = W.row[it];
+                if (it == 0 || W.row[it - 1] != row) {                  // the first item of its row: reduce the row's run
+                    float bv = W.val[it]; int bp = W.pt[it];
+                    for (int j = it + 1; j < n_items && W.row[j] == row; ++j) {
+                        const float v = W.val[j]; const int p = W.pt[j];
+                        if (v > bv || (v == bv && p < bp)) { bv = v; bp = p; }
+                    }
+                    rm_val[o + row] = bv; rm_arg[o + row] = bp;
+                    if (stats) {                                        // self-check of the bounds: the exact row maximum must lie inside them
+                        const float4 rk = rowk[l0 + row];
+                        const float mid = rk.x + 2.0f * fmaxf(u2f(rec0[row].x), u2f(rec1[row].x));
+                        const float sl = rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid));
+                        if (!(bv >= mid - sl && bv <= mid + sl)) atomicAdd(stats + 5, 1ull);
+                    }
+                }
+            }
+            st_items += (unsigned long long)n_items;
+            n_items = 0;
+            RF_WSYNC();
+        };
+        for (int u = 0; u < n_regs; ++u) {
+            const int e = u * 64 + lane;
+            const bool in = e < n_lt;
+            uint32_t lo_k = 0u, hi_k = 0u;
+#pragma unroll
+            for (int k = 0; k < kRegs; ++k) if (k == u) { lo_k = klo[k]; hi_k = khi[k]; }
+            (void)lo_k;
+            const bool active = in && hi_k >= C;
+            if (in && !active) { rm_val[o + e] = -INFINITY; rm_arg[o + e] = 0; }
+            uint32_t pts[8]; int cnt = 0; bool full = false;
+            if (active) {
+                const uint2 ra = rec0[e], rb = rec1[e];
+                const float tg = rowk[l0 + e].z;
+                const float V = fmaxf(u2f(ra.x), u2f(rb.x));
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const uint2 r = hh ? rb : ra;
+                    if (!(u2f(r.x) >= V - tg)) continue;                // this half's best is out of reach
+                    const uint32_t dsc = r.y;
+                    full = full || ((dsc >> 20) & 1u);
+                    const uint32_t tt[2] = {dsc & 31u, (dsc >> 5) & 31u}, kk[2] = {(dsc >> 10) & 15u, (dsc >> 14) & 15u};
+                    const int nt = 1 + (int)((dsc >> 18) & 1u), nk = 1 + (int)((dsc >> 19) & 1u);
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const uint32_t p = 32u * tt[a] + (kk[b] & 3u) + 8u * (kk[b] >> 2) + 4u * (uint32_t)hh;
+                            if (a < nt && b < nk && p < (uint32_t)n_rt) {
+#pragma unroll
+                                for (int z = 0; z < 8; ++z) if (z == cnt) pts[z] = p;
+                                ++cnt;
+                            }
+                        }
+                }
+                if (full) cnt = 0;
+            }
+            st_active += (unsigned long long)__popcll(__ballot(active));
+            // rows whose candidates the bound pass could not pin down (or forced rows): every point, exactly — the whole wave per row
+            unsigned long long fm = __ballot(active && full);
+            while (fm) {
+                const int src = (int)__ffsll((long long)fm) - 1;
+                fm &= fm - 1;
+                const int row = u * 64 + src;
+                float bv = -INFINITY; int bp = 0x7fffffff;
+                for (int p = lane; p < n_rt; p += 64) { const float v = exact_sim(row, p); if (v > bv) { bv = v; bp = p; } }
+                rf_argmax(bv, bp);
+                if (lane == 0) { rm_val[o + row] = bv; rm_arg[o + row] = bp; }
+                ++st_full;
+            }
+            // append this round's items, rows in ascending order (a row's items stay adjacent)
+            int incl = cnt;                                             // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+            const int total = __shfl(incl, 63);
+            if (n_items + total > kRfItems) flush();
+            const int base = n_items + incl - cnt;
+#pragma unroll
+            for (int z = 0; z < 8; ++z) if (z < cnt) { W.row[base + z] = (unsigned short)e; W.pt[base + z] = (unsigned short)pts[z]; }
+            n_items += total;
+        }
+        flush();
+        if (stats && lane == 0) {
+            atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)n_lt); atomicAdd(stats + 2, st_active);
+            atomicAdd(stats + 3, st_items); atomicAdd(stats + 4, st_full);
+        }
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------
+hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_mf_codebook, dim3(kM), dim3(kK), 0, stream, codewords, (uint4*)cw16, cwn);
+    return hipGetLastError();
+}
+
+hipError_t launch_mf_pairs(const GalleryDev& g, const int32_t* q_blk, const float* cwn, void* codes_p, float* nrm_p, void* pair_meta, hipStream_t stream)
+{
+    if (g.G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mf_pairs, dim3(g.G), dim3(64), 0, stream, g, q_blk, cwn, (uint4*)codes_p, nrm_p, (int2*)pair_meta);
+    return hipGetLastError();
+}
+
+hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream)
+{
+    if (n_rb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mf_rows, dim3(n_rb * 32), dim3(256), 0, stream, lt_des, n_rows, codewords, cwn, (_Float16*)bfrag, (float4*)rowk);
+    return hipGetLastError();
+}
+
+hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* pair_meta, const int32_t* pair0, const void* cw16,
+                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream)
+{
+    if (n_rb <= 0 || g.G <= 0) return hipSuccess;
+    const int n_rg = (n_rb + kMfRowBlocks - 1) / kMfRowBlocks;
+    const int n_chunks = (g.G + chunk - 1) / chunk;
+    const long long blocks = (long long)n_rg * n_chunks;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kMfThreads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)pair_meta, pair0,
+                       (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
+    return hipGetLastError();
+}
+
+hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
+                             float* rm_val, int32_t* rm_arg, unsigned long long* stats, hipStream_t stream)
+{
+    const long long n_tasks = (long long)q.nq * g.G;
+    if (n_tasks <= 0) return hipSuccess;
+    if (n_tasks > 0x7ffffff0LL || !g.task_ctr) return hipErrorInvalidValue;
+    hipError_t e0 = hipMemsetAsync(g.task_ctr + 2, 0, 4, stream);
+    if (e0 != hipSuccess) return e0;
+    const int grid = (int)std::min<long long>(256, (n_tasks + kRfWaves - 1) / kRfWaves);
+    hipLaunchKernelGGL(k_tex_refine, dim3(grid), dim3(kRfWaves * 64), 0, stream, q, g, codewords, (const uint2*)rec, (const float4*)rowk, R_pad, all_rows,
+                       rm_val, rm_arg, g.task_ctr + 2, stats);
+    return hipGetLastError();
+}
+
+}  // namespace afis

@@ -68,10 +68,15 @@ struct afis_ctx {
     int64_t q_blocks = 0;
     int max_nR = 0;
     int64_t total_tex_points = 0;
+    // adc_variant 9: fp16 codebook + |cw|^2 (once), pair-aligned gallery codes / point terms / pair directory (first use), per group B fragments,
+    // row constants and the bound pass's records
+    DevBuf mf_cw16, mf_cwn, g_codes_p, g_nrm_p, g_pair_meta, mf_bfrag, mf_rowk, mf_rec, mf_stats;
+    bool mf_cb_built = false, mf_gal_built = false;
+    int mf_collect_stats = 0;
     DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // lut_dtype 16: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step)
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
-    int adc_variant = 8;                 // 8: 16-bit bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
+    int adc_variant = 8;                 // 9: fp16 matrix-core bound pass + exact recomputation; 8: 16-bit LDS-table bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD; 0 = 4 with the exact refine (its fp32 table stays in L2), 1 without
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
@@ -187,6 +192,7 @@ void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
     c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_empty.release(); c->g_task_ctr.release();
+    c->g_codes_p.release(); c->g_nrm_p.release(); c->g_pair_meta.release(); c->mf_gal_built = false;
 }
 
 }  // namespace
@@ -240,6 +246,7 @@ void afis_destroy(afis_ctx* c)
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
     c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
+    c->mf_cw16.release(); c->mf_cwn.release(); c->mf_bfrag.release(); c->mf_rowk.release(); c->mf_rec.release(); c->mf_stats.release();
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -643,6 +650,46 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
     return AFIS_OK;
 }
 
+// S4-S6 (+ the row selection of S7) of adc_variant 9 for one query group: row constants, matrix-core bound pass, selection by bounds and exact
+// recomputation.  all_rows: every row is evaluated exactly (parity taps); otherwise rows that cannot reach the pair's top 200 get -inf.
+static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr)
+{
+    const QueryDev& d = grp.dev;
+    hipStream_t s = ctx->stream;
+    const GalleryDev& g = ctx->gal;
+    if (grp.n_lt_rows <= 0 || g.G <= 0) { if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s)); return AFIS_OK; }
+    if (!ctx->mf_cb_built) {
+        HIPCHK(ctx, ctx->mf_cw16.ensure((size_t)kM * kK * 16));
+        HIPCHK(ctx, ctx->mf_cwn.ensure((size_t)kM * kK * 4));
+        HIPCHK(ctx, launch_mf_codebook(ctx->codewords.as<float>(), ctx->mf_cw16.p, ctx->mf_cwn.as<float>(), s));
+        ctx->mf_cb_built = true;
+    }
+    if (!ctx->mf_gal_built) {
+        const size_t n_ent = std::max<size_t>((size_t)ctx->q_blocks * 64, 1);
+        HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
+        HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
+        HIPCHK(ctx, ctx->g_pair_meta.ensure(std::max<size_t>((size_t)ctx->q_blocks * 8, 16)));
+        HIPCHK(ctx, launch_mf_pairs(g, ctx->g_tex_q_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, s));
+        ctx->mf_gal_built = true;
+    }
+    const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
+    HIPCHK(ctx, ctx->mf_bfrag.ensure((size_t)n_rb * 6 * 64 * 16));
+    HIPCHK(ctx, ctx->mf_rowk.ensure((size_t)R_pad * 16));
+    HIPCHK(ctx, ctx->mf_rec.ensure((size_t)g.G * 2 * R_pad * 8));
+    if (ctx->mf_collect_stats && !ctx->mf_stats.p) { HIPCHK(ctx, ctx->mf_stats.ensure(64)); HIPCHK(ctx, hipMemsetAsync(ctx->mf_stats.p, 0, 64, s)); }
+    HIPCHK(ctx, launch_mf_rows(d.lt_des, n_rows, n_rb, ctx->codewords.as<float>(), ctx->mf_cwn.as<float>(), ctx->mf_bfrag.p, ctx->mf_rowk.p, s));
+    if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
+    // workgroups = row groups x gallery chunks: about eight per CU, a chunk never below 8 templates
+    const int n_rg = (n_rb + 15) / 16;
+    const long long want_chunks = std::max<long long>(1, (2048 + n_rg - 1) / n_rg);
+    const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
+    HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->mf_cw16.p,
+                                ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_rec.p, s));
+    HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
+                                  ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr, s));
+    return AFIS_OK;
+}
+
 // Rank lists are made on the device for k <= kDeviceTopK (k passes of a workgroup-wide maximum per query); larger k sorts on the host.
 static const int kDeviceTopK = 64;
 
@@ -696,7 +743,10 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const long long n_chunks_auto = ((G + 639) / 640 + cmul - 1) / cmul * cmul;
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
-            if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {           // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
+            if (ctx->adc_variant == 9 && ctx->lut_dtype != 16) {           // fp16 matrix-core bound pass + exact recomputation
+                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1]);
+                if (rc9 != AFIS_OK) return rc9;
+            } else if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {    // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
                 int rc16 = adc_stage_q(ctx, grp, chunk, ctx->lut_dtype != 16, ev[1]);
                 if (rc16 != AFIS_OK) return rc16;
             } else {
@@ -922,12 +972,13 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
-    if (n == "adc_variant") { if (value < 0 || value > 8 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7 or 8"); ctx->adc_variant = (int)value; }
+    if (n == "adc_variant") { if (value < 0 || value > 9 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7, 8 or 9"); ctx->adc_variant = (int)value; }
     else if (n == "lut_dtype") { if (value != 16 && value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype must be 32 (exact, default) or 16 (16-bit fixed-point LUT, tolerance path)"); ctx->lut_dtype = (int)value; }
     else if (n == "tile_share") { if (value < 0 || value > 32) return fail(ctx, AFIS_EINVAL, "tile_share must be 0 (auto) or 1..32"); ctx->tile_share = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
+    else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
     return AFIS_OK;
@@ -942,6 +993,21 @@ int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset)
     unsigned long long gph[16];                          // graph.hip phases (only in PHASE_TIMING builds) reported in slots 0..15 + 32.. is not
     HIPCHK(ctx, read_graph_phase_cycles(gph, reset != 0)); // possible with a 32-slot array: they overlay the unused slots 5..15 and 21..25
     for (int i = 0; i < 8; ++i) { out32[5 + i] = gph[i]; out32[21 + i] = gph[8 + i]; }
+    return AFIS_OK;
+}
+
+// adc_variant 9, after afis_set_option("mf_stats", 1): counters of the selection / recomputation kernel accumulated since the last reset:
+// out[0] pairs, [1] latent rows, [2] rows evaluated (may reach the top 200), [3] candidate cells evaluated, [4] rows evaluated over every point,
+// [5] rows whose exact maximum lay outside its bounds (self-check, must be 0)
+int afis_debug_refine_stats(afis_ctx* ctx, unsigned long long* out8, int reset)
+{
+    if (!ctx || !out8) return fail(ctx, AFIS_EINVAL, "afis_debug_refine_stats: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!ctx->mf_stats.p) return AFIS_OK;
+    HIPCHK(ctx, hipMemcpy(out8, ctx->mf_stats.p, 64, hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(ctx, hipMemset(ctx->mf_stats.p, 0, 64));
     return AFIS_OK;
 }
 
@@ -1012,7 +1078,8 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
         HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * d.lt_pad * 4));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_val.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_arg.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
-        if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32, ctx->lut_dtype != 16); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
+        if (ctx->adc_variant == 9 && ctx->lut_dtype != 16) { int rc9 = adc_stage_mfma(ctx, grp, true); if (rc9 != AFIS_OK) { grp.release(); return rc9; } }
+        else if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32, ctx->lut_dtype != 16); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
         else {
         HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, ctx->stream));
         HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk > 0 ? ctx->chunk : 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
@@ -1055,7 +1122,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             if (d.n_tiles <= 0) return AFIS_OK;
             HIPCHK(ctx, ctx->lut.ensure((size_t)d.n_tiles * kTileFloats * 4));
             HIPCHK(ctx, ctx->rm_val.ensure((size_t)d.lt_pad * 4)); HIPCHK(ctx, ctx->rm_arg.ensure((size_t)d.lt_pad * 4));
-            const int av = ctx->adc_variant == 8 ? 7 : ctx->adc_variant;     // the tap always uses a direct exact kernel (same bits)
+            const int av = ctx->adc_variant >= 8 ? 7 : ctx->adc_variant;     // the tap always uses a direct exact kernel (same bits)
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), av, s));
             HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, av, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(),

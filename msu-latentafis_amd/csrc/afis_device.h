@@ -36,7 +36,7 @@ struct GalleryDev {
                                             // lane class and half-period shifted for the conflict-free ADC kernel (adc.hip)
     const int32_t* tex_cf_blk = nullptr;    // [G+1] offset of each template's stream in tex_codes_cf, in 64-entry blocks
     const uint8_t* empty = nullptr;      // [G] 1 = rolled template has neither minutiae nor texture (score -1)
-    int32_t* task_ctr = nullptr;         // [2] next-task counters of the graph kernels (texture, minutiae): zeroed by their launchers
+    int32_t* task_ctr = nullptr;         // [3] next-task counters of the graph kernels (texture, minutiae) and the refine kernel: zeroed by their launchers
 };
 
 // A group of latents resident on the device (selected minutiae templates 26, 2, 11 + texture template 0).
@@ -80,6 +80,23 @@ __device__ __forceinline__ float sqrt_rn_pos(float x)
 }
 #endif
 
+#ifdef __HIPCC__
+// S4, one table entry: lut[i][m][k] = sum_{d<6} (des[i][6m+d] - cw[m][k][d])^2, d ascending, difference, product and sum rounded separately
+// (include.h:327-359; every translation unit is built with -ffp-contract=off).  Shared by the table builders (adc.hip), the PQ encoder and the
+// exact recomputation of adc_mfma.hip: one definition, one set of bits.
+__device__ __forceinline__ float lut_entry(const float* __restrict__ des6, const float* __restrict__ cw6)
+{
+    float dist = 0.0f;
+#pragma unroll
+    for (int d = 0; d < kDsub; ++d) {
+        float t = des6[d] - cw6[d];
+        float t2 = t * t;
+        dist += t2;
+    }
+    return dist;
+}
+#endif
+
 hipError_t launch_lut_build(const QueryDev& q, const float* codewords, float* lut_tiles, int variant, hipStream_t stream);
 // S5+S6: ADC similarity + per-row (max, first argmax) for queries [q0, q0+nq) against gallery templates.
 hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
@@ -92,6 +109,18 @@ hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, 
 // reference layout [row][16][256] (launch_lut_reference_layout over all latent texture rows of the group): exact results, bit for bit.
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
                                const float* lut32, int chunk, int share, float* rm_val, int32_t* rm_arg, hipStream_t stream);
+// adc_variant 9 (adc_mfma.hip): fp16 matrix-core bound pass + exact recomputation.  launch_mf_codebook: fp16 codebook (16-byte entries) and
+// |cw|^2 table, once per context.  launch_mf_pairs: pair-aligned codes / point terms / pair directory of the gallery (first use).
+// launch_mf_rows: per latent row of a query group the fp16 B fragments and (c, Es, Tg, force).  launch_adc_mfma: the bound pass ->
+// rec[(template * 2 + half) * R_pad + row].  launch_tex_refine: bounds -> the rows that can reach the top 200 -> exact (max, first arg-max)
+// into rm_val / rm_arg, -inf for the other rows (all_rows != 0: every row exactly; the parity taps use it).
+hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hipStream_t stream);
+hipError_t launch_mf_pairs(const GalleryDev& g, const int32_t* q_blk, const float* cwn, void* codes_p, float* nrm_p, void* pair_meta, hipStream_t stream);
+hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream);
+hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* pair_meta, const int32_t* pair0, const void* cw16,
+                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream);
+hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
+                             float* rm_val, int32_t* rm_arg, unsigned long long* stats, hipStream_t stream);
 // one correspondence of a minutiae-template list (S3 output), 8 bytes
 struct MinuCand { float sim; short li, ri; };
 // S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]

@@ -45,7 +45,7 @@ class Timing(C.Structure):
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles", "afis_debug_atan2_grid", "afis_debug_graph_arith"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles", "afis_debug_atan2_grid", "afis_debug_graph_arith", "afis_debug_refine_stats"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -85,6 +85,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_debug_atan2_grid.argtypes = [vp, C.c_int, fp]
     if hasattr(lib, "afis_debug_graph_arith"):                          # absent from older builds compared by tools/lib_ab.py; tests/test_host.py checks the exports
         lib.afis_debug_graph_arith.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+    if hasattr(lib, "afis_debug_refine_stats"):
+        lib.afis_debug_refine_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     return lib
 
 
@@ -308,6 +310,12 @@ class Matcher:
         out = (C.c_ulonglong * 8)()
         self._chk(self.lib.afis_debug_graph_arith(self.ctx, out))
         return list(out)
+
+    def refine_stats(self, reset: bool = True) -> dict:
+        """adc_variant 9 with set_option("mf_stats", 1): what the selection / recomputation kernel did since the last reset."""
+        out = (C.c_ulonglong * 8)()
+        self._chk(self.lib.afis_debug_refine_stats(self.ctx, out, 1 if reset else 0))
+        return dict(zip(("pairs", "rows", "rows_evaluated", "cells_evaluated", "rows_evaluated_in_full", "bound_violations"), list(out)[:6]))
 
     def debug_stage_list(self, latent: FPTemplate, g: int, which: int, stage: int):
         """(sim, li, ri) of the scorer's correspondence list after a stage (None when the scorer is not run)."""

@@ -69,7 +69,7 @@ def test_config1_one_latent_vs_10k(codebook_bytes, cb, oracle):
     m.gallery_add_packed(gal); m.gallery_commit(0)
     res = m.search(lats, k=24, want_parts=True)
     _check_properties(res, planted, G, 24)
-    for v in (1, 6, 7, 8):                                              # other ADC variants (8 = 16-bit bound pass + exact refine), same bits
+    for v in (1, 6, 7, 8, 9):                                           # other ADC variants (8 / 9 = bound pass + exact evaluation), same bits
         m.set_option("adc_variant", v)
         assert np.array_equal(m.search(lats, k=0)["scores"], res["scores"]), v
     m.close()
@@ -139,7 +139,7 @@ def test_config2_oracle_sample_bit_exact(headline, codebook_bytes, oracle):
 def test_config2_variants_same_bits_on_a_query_slice(headline):
     lats, gal, planted, m, res = headline
     sub = [3, 41, 77] if len(lats) > 77 else [1, 2, 3]
-    for v, gen in ((0, 0), (7, 1), (8, 0)):                             # plain-layout ADC kernel; generic minutiae candidate kernel; bound + refine
+    for v, gen in ((0, 0), (7, 1), (8, 0), (9, 0)):                     # plain-layout ADC kernel; generic minutiae candidate kernel; the two bound + refine forms
         m.set_option("adc_variant", v); m.set_option("minu_generic", gen)
         r = m.search([lats[i] for i in sub], k=24)
         assert np.array_equal(r["scores"], res["scores"][sub]) and np.array_equal(r["topk_idx"], res["topk_idx"][sub]), (v, gen)

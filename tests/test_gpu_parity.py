@@ -51,7 +51,7 @@ def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9])
 def test_rowmax_bit_exact(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -72,7 +72,7 @@ def _compare(res, orc_parts, tol=1e-3):
     return got, want, err
 
 
-@pytest.mark.parametrize("variant", [0, 1, 7])
+@pytest.mark.parametrize("variant", [0, 1, 7, 9])
 def test_scores_small(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
     m = _matcher(codebook_bytes, gal, variant)
@@ -888,8 +888,9 @@ def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes,
         gs = [g for g, _ in planted[qi]] + [int(x) for x in rng.integers(0, gal.G, 36)]
         for g in gs:
             m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lats[qi], g)
-            m.set_option("adc_variant", 8); v8, a8 = m.debug_texture_rowmax(lats[qi], g)
-            assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)) and np.array_equal(a7, a8), (qi, g, np.argwhere(a7 != a8)[:4])
+            for v in (8, 9):                                            # 8: 16-bit LDS-table bound pass; 9: fp16 matrix-core bound pass
+                m.set_option("adc_variant", v); v8, a8 = m.debug_texture_rowmax(lats[qi], g)
+                assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)) and np.array_equal(a7, a8), (v, qi, g, np.argwhere(a7 != a8)[:4])
             n += len(v7)
     m.close()
     assert n > 100000
@@ -922,14 +923,16 @@ def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
     m = _matcher(codebook_bytes, gal)
     for g in range(len(gal)):
         m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
-        m.set_option("adc_variant", 8); v8, a8 = m.debug_texture_rowmax(lat, g)
-        assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (g, np.argwhere(v7 != v8)[:4])
-        assert np.array_equal(a7, a8), (g, np.argwhere(a7 != a8)[:4], a7[:8], a8[:8])
+        for v in (8, 9):
+            m.set_option("adc_variant", v); v8, a8 = m.debug_texture_rowmax(lat, g)
+            assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (v, g, np.argwhere(v7 != v8)[:4])
+            assert np.array_equal(a7, a8), (v, g, np.argwhere(a7 != a8)[:4], a7[:8], a8[:8])
     assert (m.debug_texture_rowmax(lat, 0)[1] == 0).all()                                          # all points identical: the first one
     m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
-    m.set_option("adc_variant", 8); r8 = m.search([lat], k=0, want_parts=True)
+    for v in (8, 9):
+        m.set_option("adc_variant", v); r8 = m.search([lat], k=0, want_parts=True)
+        assert np.array_equal(r7["parts"].view(np.uint32), r8["parts"].view(np.uint32)), v
     m.close()
-    assert np.array_equal(r7["parts"].view(np.uint32), r8["parts"].view(np.uint32))
 
 
 def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_bytes, cb):
@@ -950,13 +953,42 @@ def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_b
     gal = [rolled(rng.integers(0, 256, (n, 16)).astype(np.uint8)), rolled(near), rolled(rng.integers(0, 256, (130, 16)).astype(np.uint8))]
     m = _matcher(codebook_bytes, gal)
     per_row = np.where(np.arange(lt.n)[:, None] % 3 == 0, 1.0, np.where(np.arange(lt.n)[:, None] % 3 == 1, 17.0, 0.01)).astype(np.float32)
-    for name, des in (("x8", lt.des * np.float32(8)), ("x40", lt.des * np.float32(40)), ("+3", lt.des + np.float32(3)), ("mixed", lt.des * per_row)):
+    huge = lt.des.copy(); huge[::5] *= np.float32(3000)                 # beyond what fp16 operands carry: variant 9 evaluates those rows over every point
+    for name, des in (("x8", lt.des * np.float32(8)), ("x40", lt.des * np.float32(40)), ("+3", lt.des + np.float32(3)), ("mixed", lt.des * per_row), ("huge", huge)):
         lat = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=np.ascontiguousarray(des, np.float32))])
         for g in range(len(gal)):
             m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
-            m.set_option("adc_variant", 8); v8, a8 = m.debug_texture_rowmax(lat, g)
-            assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (name, g, np.argwhere(v7 != v8)[:4], v7[:3], v8[:3])
-            assert np.array_equal(a7, a8), (name, g, np.argwhere(a7 != a8)[:4])
+            for v in (8, 9):
+                m.set_option("adc_variant", v); v8, a8 = m.debug_texture_rowmax(lat, g)
+                assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (v, name, g, np.argwhere(v7 != v8)[:4], v7[:3], v8[:3])
+                assert np.array_equal(a7, a8), (v, name, g, np.argwhere(a7 != a8)[:4])
+        m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
+        m.set_option("adc_variant", 9); r9 = m.search([lat], k=0, want_parts=True)
+        assert np.array_equal(r7["parts"].view(np.uint32), r9["parts"].view(np.uint32)), name
+    m.close()
+
+
+def test_matrix_core_bound_pass_selection_statistics(codebook_bytes, cb, medium):
+    """adc_variant 9 as the search runs it (rows that cannot reach a pair's top 200 are NOT evaluated): scores equal the direct exact kernel's
+    bit for bit on 6 latents x 3000 templates, and the kernel's own counters say what it did — every exact row maximum inside the bounds the
+    selection used, about a third of the rows evaluated, about one candidate cell per evaluated row, next to no row evaluated in full."""
+    lats, gal, planted = medium
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add_packed(gal); m.gallery_commit(0)
+    m.set_option("adc_variant", 7); r7 = m.search(lats, k=24, want_parts=True)
+    m.set_option("adc_variant", 9); m.set_option("mf_stats", 1)
+    r9 = m.search(lats, k=24, want_parts=True)
+    st = m.refine_stats()
+    assert np.array_equal(r7["parts"].view(np.uint32), r9["parts"].view(np.uint32)) and np.array_equal(r7["topk_idx"], r9["topk_idx"])
+    assert st["pairs"] == len(lats) * gal.G and st["bound_violations"] == 0, st
+    assert 200 * st["pairs"] <= st["rows_evaluated"] <= 0.6 * st["rows"], st
+    assert st["rows_evaluated"] <= st["cells_evaluated"] + 64 * st["rows_evaluated_in_full"] and st["cells_evaluated"] <= 1.3 * st["rows_evaluated"], st
+    assert st["rows_evaluated_in_full"] <= 0.01 * st["rows_evaluated"], st
+    # the parity tap evaluates every row: the bounds hold there too
+    for g in [planted[0][0][0], 5, 77]:
+        m.debug_texture_rowmax(lats[0], g)
+    st2 = m.refine_stats()
+    assert st2["bound_violations"] == 0 and st2["rows_evaluated"] == st2["rows"], st2
     m.close()
 
 
