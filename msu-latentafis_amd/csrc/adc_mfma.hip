@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_mf_pairs(GalleryDev g, const int32_t* __
 //   |G - (a . b_j - |b_j|^2 / 2)| <= Eg = sum_m max_c |da_m . cw_mc| + sum_m max_c |a~_m . db_mc| + accumulation + n_j rounding
 // (per sub-quantizer the codeword of point j is ONE of the 256, so the per-m maxima bound every point), and
 //   delta = the reference's own fp32 rounding of 6 - sum lut (19 roundings of intermediates <= 6 + sum_m max_c lut, as in adc.hip::k_lutq_build),
-//   pert  = what replacing the low 5 mantissa bits of a tracked value by an index can move it.
+//   pert  = what replacing the low 6 mantissa bits of a tracked value by an index can move it.
 //   Tg (units of G)   = 2 Eg + delta + 2 pert : a point whose REFERENCE similarity equals the row maximum has G >= G_best - Tg
 //   Es (units of sim) = 2 Eg + delta + 2 pert + rounding of c_i : the reference's row maximum lies in c_i + 2 G_best +- Es.
 // force = 1 (and Tg = Es = inf) for rows whose descriptors fp16 cannot carry (|a| > 1000, non-finite bounds): every cell is then evaluated exactly.
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
     const bool real = row < n_rows;
     if (c < kDes) {
         const float a = real ? lt_des[(size_t)row * kDes + c] : 0.0f;
-        const bool fits = fabsf(a) <= 1000.0f;                          // (false for NaN as well)
+        const bool fits = (f2u(a) & 0x7fffffffu) <= 0x447a0000u;        // |a| <= 1000 on the bits (false for NaN and inf)
         const _Float16 ah = (_Float16)(fits ? a : 0.0f);
         s_a[c] = a; s_ah[c] = (float)ah;
         const int kk = c >> 4, half = (c >> 3) & 1, e = c & 7, r = row & 31, rb = row >> 5;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             float x = v[k];
-            if (!(x == x)) x = INFINITY;                                // NaN input: unbounded
+            if ((f2u(x) & 0x7fffffffu) > 0x7f800000u) x = INFINITY;     // NaN input (tested on the bits: this file is built with -fno-honor-nans): unbounded
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
             v[k] = x;
@@ -141,15 +141,15 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
     }
     if (c == 0) {
         double A2 = 0.0; bool fits = true;
-        for (int k = 0; k < kDes; ++k) { A2 += (double)s_a[k] * (double)s_a[k]; fits = fits && fabsf(s_a[k]) <= 1000.0f; }
+        for (int k = 0; k < kDes; ++k) { A2 += (double)s_a[k] * (double)s_a[k]; fits = fits && (f2u(s_a[k]) & 0x7fffffffu) <= 0x447a0000u; }
         const double u = 5.9604644775390625e-8;                          // 2^-24
         const double mag = S + N;                                        // no partial sum of the accumulation is larger
         const double Eg = 1.001 * (P + Q) + 100.0 * u * mag + 32.0 * u * N + 1e-9;
-        const double pert = 64.0 * u * mag;
+        const double pert = 128.0 * u * mag;                             // the low 6 mantissa bits of a tracked value carry an index
         const double delta = 24.0 * u * (6.0 + 1.0001 * L);
         double Tg = 2.0 * Eg + delta + 2.0 * pert;
         double Es = 2.0 * Eg + 2.0 * pert + delta + 4.0 * u * fmax(8.0, 6.0 + A2);
-        const bool force = !fits || !(Tg < 1e20) || !(Es < 1e20);
+        const bool force = !fits || !(Tg < 1e20) || !(Es < 1e20) || (f2u((float)Tg) & 0x7fffffffu) > 0x7f800000u || (f2u((float)Es) & 0x7fffffffu) > 0x7f800000u;
         if (force) { Tg = INFINITY; Es = INFINITY; }
         rowk[row] = make_float4((float)(6.0 - A2), (float)(Es * 1.000001), (float)(Tg * 1.000001), force ? 1.0f : 0.0f);
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The bound pass.  grid = row groups (512 latent rows) x gallery chunks, block = 512.
-//   LDS: fp16 codebook (64 KB) + two stages of 4 tiles: per tile 12 operand groups x 32 points x 16 B (group gidx = halves 8 gidx .. 8 gidx + 7
+//   LDS: fp16 codebook (64 KB) + a ring of three stages of 4 tiles: per tile 12 operand groups x 32 points x 16 B (group gidx = halves 8 gidx .. 8 gidx + 7
 //   of the point's 96, i.e. exactly what lane (point, k half) of MFMA step gidx / 2 wants: reads and writes are conflict free) + 32 point terms.
 //   Every thread decodes one (point, 4 sub-quantizers) item per stage: 4 codebook reads (12 bytes used of 16), 3 operand-group writes — three
 //   groups are exactly four codewords' 24 halves, so no repacking arithmetic at all.
@@ -165,12 +165,14 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 //   D[point][row]: lane = (row = lane & 31, h = lane >> 5), register r = point (r & 3) + 8 (r >> 2) + 4 h of the tile; the C operand of the first
 //   MFMA of a tile is the points' term n_j, so a finished accumulator IS G.
 // Records: rec[(template * 2 + h) * R_pad + row] = (value of the lane's best point, descriptor):
-//   bits 0-4 / 5-9 best / second tile, 10-13 / 14-17 best / second slot, 18 second tile within T, 19 second slot within T, 20 "many" (a third
-//   tile or slot within T, or a forced row): candidates = {tiles} x {slots}; point = 32 tile + (slot & 3) + 8 (slot >> 2) + 4 h.
+//   bits 0-5 / 6-11 best / second group (group = 2 * tile + register half), 12-14 / 15-17 best / second slot (slot k = registers k, k + 8),
+//   18 second group within T, 19 second slot within T, 20 "many" (a third group or slot within T, or a forced row):
+//   candidates = {groups} x {slots}; register r = slot + 8 * (group & 1), point = 32 * (group >> 1) + (r & 3) + 8 (r >> 2) + 4 h.
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct __align__(16) MfStage {
     uint4 a[kMfStageTiles][12][32];
     float nrm[kMfStageTiles][32];
+    int2 meta[kMfStageTiles / 2];      // (template, pair index | 256 on its last pair) of the stage's pairs; (0, 0) beyond the chunk
 };
 
 __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
                                                           int n_rg, int chunk, uint2* __restrict__ rec)
 {
     __shared__ uint4 s_cw[kM * kK];                                     // 64 KB
-    __shared__ MfStage s_st[2];                                         // 2 x 25 088 B
+    __shared__ MfStage s_st[3];                                         // 3 x 25 088 B: decoded two stages ahead, read one tile ahead
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
@@ -212,108 +214,145 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
 
     // producer identity: point pp of tile pj of the stage, sub-quantizers 4 pQ .. 4 pQ + 3
     const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;
-    auto fetch = [&](int s, uint32_t& code, float& nrm) {
+    // (the thread with pp == 0, pQ == 1 of a pair's first tile also carries the pair's directory entry: it travels through LDS with the tile,
+    // because a scalar load inside the tile loop would share — and so drain — the lgkmcnt counter of the operand reads in flight)
+    const bool meta_thread = pQ == 1 && pp == 0 && (pj & 1) == 0;
+    struct Pf { uint32_t code; float nrm; int2 meta; };
+    auto fetch = [&](int s, Pf& f) {
         const int pair = pair_lo + 2 * s + (pj >> 1);
-        code = 0u; nrm = kMfNeg;
+        f.code = 0u; f.nrm = kMfNeg; f.meta = make_int2(0, 0);
         if (pair < pair_hi) {
             const size_t e = (size_t)pair * 64 + (pj & 1) * 32 + pp;
-            code = reinterpret_cast<const uint32_t*>(codes_p)[e * 4 + pQ];
-            if (pQ == 0) nrm = nrm_p[e];
+            f.code = reinterpret_cast<const uint32_t*>(codes_p)[e * 4 + pQ];
+            if (pQ == 0) f.nrm = nrm_p[e];
+            if (meta_thread) f.meta = pair_meta[pair];
         }
     };
-    auto decode = [&](int buf, uint32_t code, float nrm) {
+    auto decode = [&](int buf, const Pf& f) {
         uint4 w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = s_cw[(4 * pQ + i) * kK + ((code >> (8 * i)) & 255u)];
+        for (int i = 0; i < 4; ++i) w[i] = s_cw[(4 * pQ + i) * kK + ((f.code >> (8 * i)) & 255u)];
         MfStage& st = s_st[buf];
         st.a[pj][3 * pQ + 0][pp] = make_uint4(w[0].x, w[0].y, w[0].z, w[1].x);
         st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
         st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
-        if (pQ == 0) st.nrm[pj][pp] = nrm;
+        if (pQ == 0) st.nrm[pj][pp] = f.nrm;
+        if (meta_thread) st.meta[pj >> 1] = f.meta;
     };
-    uint32_t code_cur, code_nxt = 0u; float nrm_cur, nrm_nxt = kMfNeg;
-    fetch(0, code_cur, nrm_cur);
+    Pf pf_cur, pf_nxt;
+    fetch(0, pf_cur);
     __syncthreads();                                                    // the codebook is in LDS
-    decode(0, code_cur, nrm_cur);
-    fetch(1, code_cur, nrm_cur);                                        // (beyond the chunk: zeros)
+    decode(0, pf_cur);
+    fetch(1, pf_cur);                                                   // (beyond the chunk: zeros)
+    decode(1, pf_cur);
+    fetch(2, pf_cur);
     __syncthreads();
 
-    // tracking state per row block: slot maxima over the template's tiles, top three tile maxima (low 5 bits = tile index)
-    float m[2][16], tb[2], ts[2], tu[2];
+    // Tracking state per row block.  A lane sees 16 values per tile (registers r = 0..15 of the accumulator).  Two partitions of all the
+    // values it sees over a template:  G: 8 slots, slot k = registers k and k + 8 of every tile (running maxima m[k]);  H: 2 groups per tile,
+    // registers 0..7 and 8..15 (top three group maxima tb >= ts >= tu, low 6 bits = group id = 2 * tile + register half).  A slot and a
+    // group meet in exactly one value.
+    float m[2][8], tb[2], ts[2], tu[2];
     auto reset = [&]() {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) m[blk][k] = kMfNeg;
+            for (int k = 0; k < 8; ++k) m[blk][k] = kMfNeg;
             tb[blk] = ts[blk] = tu[blk] = kMfNeg;
         }
     };
     reset();
+    auto track = [&](int blk, const floatx16& X, uint32_t gid) {        // 24 VALU per 16 values
+        float lo = max3f(X[0], X[1], X[2]), hi = max3f(X[8], X[9], X[10]);
+        lo = max3f(lo, X[3], X[4]); hi = max3f(hi, X[11], X[12]);
+        lo = max3f(lo, X[5], X[6]); hi = max3f(hi, X[13], X[14]);
+        lo = fmaxf(lo, X[7]); hi = fmaxf(hi, X[15]);
+        const float el = u2f((f2u(lo) & ~63u) | gid), eh = u2f((f2u(hi) & ~63u) | (gid + 1u));
+        tu[blk] = med3f(ts[blk], el, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], el); tb[blk] = fmaxf(tb[blk], el);
+        tu[blk] = med3f(ts[blk], eh, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], eh); tb[blk] = fmaxf(tb[blk], eh);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[blk][k] = max3f(m[blk][k], X[k], X[k + 8]);
+    };
+    auto finish_template = [&](int tmpl) {                             // the template's records, then a fresh state
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float e = u2f((f2u(m[blk][k]) & ~7u) | (uint32_t)k);
+                u3 = med3f(s3, e, u3); s3 = med3f(b3, s3, e); b3 = fmaxf(b3, e);
+            }
+            const float thr = fminf(tb[blk], b3) - Tg[blk];
+            const bool many = (tu[blk] >= thr) | (u3 >= thr) | force[blk];
+            const uint32_t desc = (f2u(tb[blk]) & 63u) | ((f2u(ts[blk]) & 63u) << 6) | ((f2u(b3) & 7u) << 12) | ((f2u(s3) & 7u) << 15) |
+                                  ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
+            if (row_ok[blk]) rec[((size_t)tmpl * 2 + h) * R_pad + (size_t)(rb0 + blk) * 32 + col] = make_uint2(f2u(b3), desc);
+        }
+        reset();
+    };
 
+    // The tile loop is software pipelined inside the wave: step i issues the 12 MFMAs of tile i into one accumulator set while the VALU tracks
+    // tile i - 1 in the other (the matrix pipe runs asynchronously; the two waves of a SIMD run the same instruction stream in step, so
+    // overlap BETWEEN waves cannot be relied on).  Four steps per stage, so the sets alternate with a fixed phase.
+    floatx16 acc[2][2];                                                  // [set][row block]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = kMfNeg; }   // "tracking" the tile before the first changes nothing
+    // operands of the tile about to be multiplied, fetched from LDS one step ahead (ping-pong by step parity: no register copies)
+    half8 afr[2][6]; floatx16 nrr[2]; int2 mtr[2];
+    auto load_tile = [&](int par, const MfStage& st, int j) {
+        mtr[par] = st.meta[j >> 1];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 v = *reinterpret_cast<const float4*>(&st.nrm[j][8 * q4 + 4 * h]);
+            nrr[par][4 * q4] = v.x; nrr[par][4 * q4 + 1] = v.y; nrr[par][4 * q4 + 2] = v.z; nrr[par][4 * q4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) afr[par][kk] = __builtin_bit_cast(half8, st.a[j][2 * kk + h][col]);
+    };
+    if (wave_ok) load_tile(0, s_st[0], 0);
+    int2 meta_prev = make_int2(0, 0);                                    // the pair of the tile waiting to be tracked
+    int buf = 0;                                                        // s % 3
     for (int s = 0; s < n_stages; ++s) {
-        fetch(s + 2, code_nxt, nrm_nxt);                                // two stages ahead: its latency hides under this stage's MFMAs
-        const MfStage& st = s_st[s & 1];
+        fetch(s + 3, pf_nxt);                                           // three stages ahead: its latency hides under this stage's MFMAs
+        const int buf_next = buf == 2 ? 0 : buf + 1;
         if (wave_ok) {
 #pragma unroll
-            for (int u = 0; u < kMfStageTiles / 2; ++u) {
-                const int pair = pair_lo + 2 * s + u;
-                if (pair >= pair_hi) break;
-                const int2 meta = pair_meta[pair];                      // wave-uniform: scalar load
-                const int tX = 2 * u, tY = 2 * u + 1;
-                floatx16 nX, nY;
+            for (int j = 0; j < kMfStageTiles; ++j) {
+                const int set = j & 1;
+                const int2 meta = make_int2(__builtin_amdgcn_readfirstlane(mtr[set].x), __builtin_amdgcn_readfirstlane(mtr[set].y));
+                // the NEXT tile's operands (the next stage's first tile was decoded a whole stage ago); beyond the last stage the reads stay
+                // inside the ring and are never used
+                if (j < kMfStageTiles - 1) load_tile(set ^ 1, s_st[buf], j + 1); else load_tile(set ^ 1, s_st[buf_next], 0);
+                acc[set][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][0], bf[0][0], nrr[set], 0, 0, 0);
+                acc[set][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][0], bf[1][0], nrr[set], 0, 0, 0);
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 vx = *reinterpret_cast<const float4*>(&st.nrm[tX][8 * q4 + 4 * h]);
-                    const float4 vy = *reinterpret_cast<const float4*>(&st.nrm[tY][8 * q4 + 4 * h]);
-                    nX[4 * q4] = vx.x; nX[4 * q4 + 1] = vx.y; nX[4 * q4 + 2] = vx.z; nX[4 * q4 + 3] = vx.w;
-                    nY[4 * q4] = vy.x; nY[4 * q4 + 1] = vy.y; nY[4 * q4 + 2] = vy.z; nY[4 * q4 + 3] = vy.w;
+                for (int kk = 1; kk < 6; ++kk) {
+                    acc[set][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][kk], bf[0][kk], acc[set][0], 0, 0, 0);
+                    acc[set][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][kk], bf[1][kk], acc[set][1], 0, 0, 0);
                 }
-                floatx16 X0 = nX, X1 = nX, Y0 = nY, Y1 = nY;
-#pragma unroll
-                for (int kk = 0; kk < 6; ++kk) {
-                    const half8 aX = __builtin_bit_cast(half8, st.a[tX][2 * kk + h][col]);
-                    const half8 aY = __builtin_bit_cast(half8, st.a[tY][2 * kk + h][col]);
-                    X0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX, bf[0][kk], X0, 0, 0, 0);
-                    X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aX, bf[1][kk], X1, 0, 0, 0);
-                    Y0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aY, bf[0][kk], Y0, 0, 0, 0);
-                    Y1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(aY, bf[1][kk], Y1, 0, 0, 0);
-                }
-                const uint32_t tiX = (uint32_t)(2 * (meta.y & 255)), tiY = tiX + 1u;
-                auto track = [&](int blk, const floatx16& X, const floatx16& Y) {
-                    float x = max3f(X[0], X[1], X[2]), y = max3f(Y[0], Y[1], Y[2]);
-#pragma unroll
-                    for (int k = 3; k < 15; k += 2) { x = max3f(x, X[k], X[k + 1]); y = max3f(y, Y[k], Y[k + 1]); }
-                    x = fmaxf(x, X[15]); y = fmaxf(y, Y[15]);
-                    const float ex = u2f((f2u(x) & ~31u) | tiX), ey = u2f((f2u(y) & ~31u) | tiY);
-                    tu[blk] = med3f(ts[blk], ex, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], ex); tb[blk] = fmaxf(tb[blk], ex);
-                    tu[blk] = med3f(ts[blk], ey, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], ey); tb[blk] = fmaxf(tb[blk], ey);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) m[blk][k] = max3f(m[blk][k], X[k], Y[k]);
-                };
-                track(0, X0, Y0);
-                track(1, X1, Y1);
-                if (meta.y & 256) {                                     // the template's last pair: its records, then a fresh state
-#pragma unroll
-                    for (int blk = 0; blk < 2; ++blk) {
-                        float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const float e = u2f((f2u(m[blk][k]) & ~15u) | (uint32_t)k);
-                            u3 = med3f(s3, e, u3); s3 = med3f(b3, s3, e); b3 = fmaxf(b3, e);
-                        }
-                        const float thr = fminf(tb[blk], b3) - Tg[blk];
-                        const bool many = (tu[blk] >= thr) | (u3 >= thr) | force[blk];
-                        const uint32_t desc = (f2u(tb[blk]) & 31u) | ((f2u(ts[blk]) & 31u) << 5) | ((f2u(b3) & 15u) << 10) | ((f2u(s3) & 15u) << 14) |
-                                              ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
-                        if (row_ok[blk]) rec[((size_t)meta.x * 2 + h) * R_pad + (size_t)(rb0 + blk) * 32 + col] = make_uint2(f2u(b3), desc);
-                    }
-                    reset();
-                }
+                // the previous tile, in the other set: its 48 VALU go between this tile's MFMAs
+                const uint32_t gid_prev = (uint32_t)(4 * (meta_prev.y & 255) + 2 * ((j & 1) ^ 1));     // previous tile: the other half of its pair
+                track(0, acc[set ^ 1][0], gid_prev);
+                track(1, acc[set ^ 1][1], gid_prev);
+                // order inside the step: the ten LDS reads of the next tile first, then one MFMA per four VALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 11, 0);
+#define MF_GRP(nv) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
+                MF_GRP(5) MF_GRP(5) MF_GRP(5) MF_GRP(5) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4)
+#undef MF_GRP
+                if ((j & 1) == 0 && (meta_prev.y & 256)) finish_template(meta_prev.x);   // the previous tile closed its template
+                meta_prev = meta;
             }
         }
-        if (s + 1 < n_stages) decode((s + 1) & 1, code_cur, nrm_cur);
-        code_cur = code_nxt; nrm_cur = nrm_nxt;
+        if (s + 2 < n_stages) decode(buf == 0 ? 2 : buf - 1, pf_cur);                   // stage s + 2 into the slot stage s - 1 has left
+        pf_cur = pf_nxt;
+        buf = buf_next;
         __syncthreads();
+    }
+    if (wave_ok) {                                                      // the chunk's last tile
+        const uint32_t gid_prev = (uint32_t)(4 * (meta_prev.y & 255) + 2);
+        track(0, acc[1][0], gid_prev);
+        track(1, acc[1][1], gid_prev);
+        if (meta_prev.y & 256) finish_template(meta_prev.x);
     }
 }
 
@@ -474,13 +513,14 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                     if (!(u2f(r.x) >= V - tg)) continue;                // this half's best is out of reach
                     const uint32_t dsc = r.y;
                     full = full || ((dsc >> 20) & 1u);
-                    const uint32_t tt[2] = {dsc & 31u, (dsc >> 5) & 31u}, kk[2] = {(dsc >> 10) & 15u, (dsc >> 14) & 15u};
+                    const uint32_t tt[2] = {dsc & 63u, (dsc >> 6) & 63u}, kk[2] = {(dsc >> 12) & 7u, (dsc >> 15) & 7u};
                     const int nt = 1 + (int)((dsc >> 18) & 1u), nk = 1 + (int)((dsc >> 19) & 1u);
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
 #pragma unroll
                         for (int b = 0; b < 2; ++b) {
-                            const uint32_t p = 32u * tt[a] + (kk[b] & 3u) + 8u * (kk[b] >> 2) + 4u * (uint32_t)hh;
+                            const uint32_t rr = kk[b] + 8u * (tt[a] & 1u);
+                            const uint32_t p = 32u * (tt[a] >> 1) + (rr & 3u) + 8u * (rr >> 2) + 4u * (uint32_t)hh;
                             if (a < nt && b < nk && p < (uint32_t)n_rt) {
 #pragma unroll
                                 for (int z = 0; z < 8; ++z) if (z == cnt) pts[z] = p;
