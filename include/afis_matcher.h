@@ -78,6 +78,8 @@ typedef struct afis_timing {
     int32_t adc_launches;  /* number of ADC kernel launches in the call                 */
     int64_t adc_lookups;   /* LUT look-ups performed by those launches                  */
     int64_t pairs;         /* (query, gallery template) pairs scored                    */
+    float   adc_bound_ms;  /* part of adc_ms: the bound pass over every cell (adc_variant 8: the whole kernel; 9: k_adc_mfma) */
+    float   adc_refine_ms; /* part of adc_ms: adc_variant 9's selection + exact recomputation kernel; 0 otherwise             */
 } afis_timing;
 
 /* Replaces PQ::Matcher::Matcher(code_file) (matcher.cpp:31-94).  codewords = [M][K][dsub] fp32 exactly as stored
@@ -183,14 +185,17 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
                          int32_t* counts /*[n][3]*/, int16_t* xy /*[n][3][120][4]*/);
 
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
-/* Tunables: "adc_variant" — every variant gives bit-identical results: 8 [default] = a 16-bit fixed-point pass over all points bounds the
- * candidates of every row maximum, which are then evaluated exactly (fp32, the reference's order) — 0.78 x the time of 7; 7 = direct
- * exact kernel, conflict-free lane classes, 1024-thread workgroups; 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad
- * rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
+/* Tunables: "adc_variant" — every variant gives bit-identical results: 9 [default] = an fp16 matrix-core pass over all (latent row, rolled
+ * point) cells bounds every row maximum and pins its candidate points; the rows that can reach a pair's top 200 then get the exact fp32
+ * value of their candidates, the table entries recomputed in the reference's arithmetic and order (adc_mfma.hip) — 0.62 x the time of 8;
+ * 8 = a 16-bit fixed-point LDS-table pass bounds the candidates, which are then evaluated exactly from an fp32 table in HBM/L2 (the
+ * north_star's LDS-LUT design; 0.55 x the time of 7); 7 = direct exact kernel, conflict-free lane classes, 1024-thread workgroups;
+ * 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as
+ * references (4 and 5 were earlier forms of 6/7 and are rejected).
  * "query_batch" (latents per launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae
- * candidate kernel), "rowmax_budget_mb", and "lut_dtype": 32 (default) = the exact fp32 look-up table, every result bit-identical to the reference
- * arithmetic; 16 = opt-in TOLERANCE path: the per-query table quantised to 16-bit fixed point (16 latent rows per 128 KB LDS tile,
- * integer sums; BASELINE.json configs[4]).  Its only error is the quantisation (|d sim| <= 16 steps / 2, about 4e-3), so row maxima
+ * candidate kernel), "rowmax_budget_mb", "mf_stats" (adc_variant 9: collect afis_debug_refine_stats), and "lut_dtype": 32 (default) = exact,
+ * every result bit-identical to the reference arithmetic; 16 = opt-in TOLERANCE path: the per-query table quantised to 16-bit fixed point (16 latent rows per 128 KB LDS tile,
+ * integer sums).  Its only error is the quantisation (|d sim| <= 16 steps / 2, about 4e-3), so row maxima
  * and arg-maxima can differ from the exact path where two candidates are closer than that; scores are NOT bit-exact.
  * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);

@@ -26,9 +26,6 @@ namespace afis {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int kMfThreads = 512;             // 8 waves: two per SIMD, <= 256 VGPRs each
-constexpr int kMfRowBlocks = 16;            // row blocks (32 latent rows) per workgroup, two per wave
-constexpr int kMfStageTiles = 4;            // tiles (32 points) per LDS stage = 2 pairs
 constexpr float kMfNeg = -1.0e30f;          // "no point": the accumulator start of padding points
 
 __device__ __forceinline__ uint32_t f2u(float x) { return __float_as_uint(x); }
@@ -156,32 +153,41 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The bound pass.  grid = row groups (512 latent rows) x gallery chunks, block = 512.
-//   LDS: fp16 codebook (64 KB) + a ring of three stages of 4 tiles: per tile 12 operand groups x 32 points x 16 B (group gidx = halves 8 gidx .. 8 gidx + 7
-//   of the point's 96, i.e. exactly what lane (point, k half) of MFMA step gidx / 2 wants: reads and writes are conflict free) + 32 point terms.
+// The bound pass.  grid = row groups (768 latent rows) x gallery chunks, block = 768 = 12 waves, three per SIMD (<= 168 VGPRs).
+//   LDS: fp16 codebook (64 KB) + two stages of 6 tiles: per tile 12 operand groups x 32 points x 16 B (group gidx = halves 8 gidx .. 8 gidx + 7
+//   of the point's 96, i.e. exactly what lane (point, k half) of MFMA step gidx / 2 wants: reads and writes are conflict free), 32 point terms
+//   and the pair's directory entry (it travels with the tile: a scalar load in the tile loop would share the operand reads' lgkmcnt).
 //   Every thread decodes one (point, 4 sub-quantizers) item per stage: 4 codebook reads (12 bytes used of 16), 3 operand-group writes — three
 //   groups are exactly four codewords' 24 halves, so no repacking arithmetic at all.
 //   Wave w keeps the B fragments of row blocks 2w, 2w + 1 in 48 registers for its whole life and runs every tile through both.
 //   D[point][row]: lane = (row = lane & 31, h = lane >> 5), register r = point (r & 3) + 8 (r >> 2) + 4 h of the tile; the C operand of the first
 //   MFMA of a tile is the points' term n_j, so a finished accumulator IS G.
+// Tracking: a lane sees 16 values per tile and row block.  Two partitions of all the values it sees over a template:  G: 8 slots, slot k =
+//   registers k and k + 8 of every tile (running maxima m[k]);  H: 2 groups per tile, registers 0..7 and 8..15 (top three group maxima
+//   tb >= ts >= tu, low 6 bits = group id = 2 * tile + register half).  A slot and a group meet in exactly one value.  24 VALU per 16 values.
 // Records: rec[(template * 2 + h) * R_pad + row] = (value of the lane's best point, descriptor):
 //   bits 0-5 / 6-11 best / second group (group = 2 * tile + register half), 12-14 / 15-17 best / second slot (slot k = registers k, k + 8),
 //   18 second group within T, 19 second slot within T, 20 "many" (a third group or slot within T, or a forced row):
 //   candidates = {groups} x {slots}; register r = slot + 8 * (group & 1), point = 32 * (group >> 1) + (r & 3) + 8 (r >> 2) + 4 h.
+// What was tried on this kernel and left out (all within 3 % of this form): two waves per SIMD with the tracking of tile
+// i - 1 interleaved between the MFMAs of tile i (two accumulator sets); the same with a three-stage LDS ring and operand reads one tile ahead;
+// the two waves of a SIMD half a period apart (one in its MFMA burst while the other tracks); the decode spread over the tile steps.
 // ---------------------------------------------------------------------------------------------------------------------------------
-struct __align__(16) MfStage {
-    uint4 a[kMfStageTiles][12][32];
-    float nrm[kMfStageTiles][32];
-    int2 meta[kMfStageTiles / 2];      // (template, pair index | 256 on its last pair) of the stage's pairs; (0, 0) beyond the chunk
+constexpr int kM12Threads = 768, kM12RowBlocks = 24, kM12StageTiles = 6;
+struct __align__(16) M12Stage {
+    uint4 a[kM12StageTiles][12][32];
+    float nrm[kM12StageTiles][32];
+    int2 meta[kM12StageTiles / 2];
+    int2 pad;
 };
 
-__global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
-                                                          const int2* __restrict__ pair_meta, const int32_t* __restrict__ pair0, const uint4* __restrict__ cw16,
-                                                          const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
-                                                          int n_rg, int chunk, uint2* __restrict__ rec)
+__global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
+                                                            const int2* __restrict__ pair_meta, const int32_t* __restrict__ pair0, const uint4* __restrict__ cw16,
+                                                            const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
+                                                            int n_rg, int chunk, uint2* __restrict__ rec)
 {
     __shared__ uint4 s_cw[kM * kK];                                     // 64 KB
-    __shared__ MfStage s_st[3];                                         // 3 x 25 088 B: decoded two stages ahead, read one tile ahead
+    __shared__ M12Stage s_st[2];                                        // 2 x 37.7 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
@@ -190,12 +196,12 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
     const int pair_lo = pair0[t_lo], pair_hi = pair0[t_hi];
     const int n_pairs = pair_hi - pair_lo;
     if (n_pairs <= 0) return;
-    const int n_stages = (n_pairs + 1) >> 1;
-    for (int i = tid; i < kM * kK; i += kMfThreads) s_cw[i] = cw16[i];
+    const int n_stages = (n_pairs + 2) / 3;
+    for (int i = tid; i < kM * kK; i += kM12Threads) s_cw[i] = cw16[i];
 
     const int h = lane >> 5, col = lane & 31;
-    const int rb0 = rg * kMfRowBlocks + wave * 2;
-    const bool wave_ok = rb0 < n_rb;                                   // a wave whose row blocks lie beyond the group only decodes
+    const int rb0 = rg * kM12RowBlocks + wave * 2;
+    const bool wave_ok = rb0 < n_rb;
     half8 bf[2][6];
     float Tg[2]; bool row_ok[2], force[2];
 #pragma unroll
@@ -211,15 +217,11 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
         const float4 rk = row_ok[blk] ? rowk[row] : make_float4(0.f, 0.f, 0.f, 0.f);
         Tg[blk] = rk.z; force[blk] = rk.w != 0.0f;
     }
-
-    // producer identity: point pp of tile pj of the stage, sub-quantizers 4 pQ .. 4 pQ + 3
-    const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;
-    // (the thread with pp == 0, pQ == 1 of a pair's first tile also carries the pair's directory entry: it travels through LDS with the tile,
-    // because a scalar load inside the tile loop would share — and so drain — the lgkmcnt counter of the operand reads in flight)
+    const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;       // point in tile, sub-quantizer quad, tile of the stage (0..5)
     const bool meta_thread = pQ == 1 && pp == 0 && (pj & 1) == 0;
     struct Pf { uint32_t code; float nrm; int2 meta; };
     auto fetch = [&](int s, Pf& f) {
-        const int pair = pair_lo + 2 * s + (pj >> 1);
+        const int pair = pair_lo + 3 * s + (pj >> 1);
         f.code = 0u; f.nrm = kMfNeg; f.meta = make_int2(0, 0);
         if (pair < pair_hi) {
             const size_t e = (size_t)pair * 64 + (pj & 1) * 32 + pp;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
         uint4 w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = s_cw[(4 * pQ + i) * kK + ((f.code >> (8 * i)) & 255u)];
-        MfStage& st = s_st[buf];
+        M12Stage& st = s_st[buf];
         st.a[pj][3 * pQ + 0][pp] = make_uint4(w[0].x, w[0].y, w[0].z, w[1].x);
         st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
         st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
@@ -241,17 +243,11 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
     };
     Pf pf_cur, pf_nxt;
     fetch(0, pf_cur);
-    __syncthreads();                                                    // the codebook is in LDS
+    __syncthreads();
     decode(0, pf_cur);
-    fetch(1, pf_cur);                                                   // (beyond the chunk: zeros)
-    decode(1, pf_cur);
-    fetch(2, pf_cur);
+    fetch(1, pf_cur);
     __syncthreads();
 
-    // Tracking state per row block.  A lane sees 16 values per tile (registers r = 0..15 of the accumulator).  Two partitions of all the
-    // values it sees over a template:  G: 8 slots, slot k = registers k and k + 8 of every tile (running maxima m[k]);  H: 2 groups per tile,
-    // registers 0..7 and 8..15 (top three group maxima tb >= ts >= tu, low 6 bits = group id = 2 * tile + register half).  A slot and a
-    // group meet in exactly one value.
     float m[2][8], tb[2], ts[2], tu[2];
     auto reset = [&]() {
 #pragma unroll
@@ -262,7 +258,7 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
         }
     };
     reset();
-    auto track = [&](int blk, const floatx16& X, uint32_t gid) {        // 24 VALU per 16 values
+    auto track = [&](int blk, const floatx16& X, uint32_t gid) {
         float lo = max3f(X[0], X[1], X[2]), hi = max3f(X[8], X[9], X[10]);
         lo = max3f(lo, X[3], X[4]); hi = max3f(hi, X[11], X[12]);
         lo = max3f(lo, X[5], X[6]); hi = max3f(hi, X[13], X[14]);
@@ -273,7 +269,7 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
 #pragma unroll
         for (int k = 0; k < 8; ++k) m[blk][k] = max3f(m[blk][k], X[k], X[k + 8]);
     };
-    auto finish_template = [&](int tmpl) {                             // the template's records, then a fresh state
+    auto finish_template = [&](int tmpl) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
@@ -291,68 +287,39 @@ __global__ __launch_bounds__(kMfThreads) void k_adc_mfma(GalleryDev g, const uin
         reset();
     };
 
-    // The tile loop is software pipelined inside the wave: step i issues the 12 MFMAs of tile i into one accumulator set while the VALU tracks
-    // tile i - 1 in the other (the matrix pipe runs asynchronously; the two waves of a SIMD run the same instruction stream in step, so
-    // overlap BETWEEN waves cannot be relied on).  Four steps per stage, so the sets alternate with a fixed phase.
-    floatx16 acc[2][2];                                                  // [set][row block]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][0][r] = acc[0][1][r] = acc[1][0][r] = acc[1][1][r] = kMfNeg; }   // "tracking" the tile before the first changes nothing
-    // operands of the tile about to be multiplied, fetched from LDS one step ahead (ping-pong by step parity: no register copies)
-    half8 afr[2][6]; floatx16 nrr[2]; int2 mtr[2];
-    auto load_tile = [&](int par, const MfStage& st, int j) {
-        mtr[par] = st.meta[j >> 1];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 v = *reinterpret_cast<const float4*>(&st.nrm[j][8 * q4 + 4 * h]);
-            nrr[par][4 * q4] = v.x; nrr[par][4 * q4 + 1] = v.y; nrr[par][4 * q4 + 2] = v.z; nrr[par][4 * q4 + 3] = v.w;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 6; ++kk) afr[par][kk] = __builtin_bit_cast(half8, st.a[j][2 * kk + h][col]);
-    };
-    if (wave_ok) load_tile(0, s_st[0], 0);
-    int2 meta_prev = make_int2(0, 0);                                    // the pair of the tile waiting to be tracked
-    int buf = 0;                                                        // s % 3
     for (int s = 0; s < n_stages; ++s) {
-        fetch(s + 3, pf_nxt);                                           // three stages ahead: its latency hides under this stage's MFMAs
-        const int buf_next = buf == 2 ? 0 : buf + 1;
+        fetch(s + 2, pf_nxt);
+        const M12Stage& st = s_st[s & 1];
         if (wave_ok) {
 #pragma unroll
-            for (int j = 0; j < kMfStageTiles; ++j) {
-                const int set = j & 1;
-                const int2 meta = make_int2(__builtin_amdgcn_readfirstlane(mtr[set].x), __builtin_amdgcn_readfirstlane(mtr[set].y));
-                // the NEXT tile's operands (the next stage's first tile was decoded a whole stage ago); beyond the last stage the reads stay
-                // inside the ring and are never used
-                if (j < kMfStageTiles - 1) load_tile(set ^ 1, s_st[buf], j + 1); else load_tile(set ^ 1, s_st[buf_next], 0);
-                acc[set][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][0], bf[0][0], nrr[set], 0, 0, 0);
-                acc[set][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][0], bf[1][0], nrr[set], 0, 0, 0);
+            for (int j = 0; j < kM12StageTiles; ++j) {
+                floatx16 nrm;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 v = *reinterpret_cast<const float4*>(&st.nrm[j][8 * q4 + 4 * h]);
+                    nrm[4 * q4] = v.x; nrm[4 * q4 + 1] = v.y; nrm[4 * q4 + 2] = v.z; nrm[4 * q4 + 3] = v.w;
+                }
+                const int2 mv = st.meta[j >> 1];
+                half8 af[6];
+#pragma unroll
+                for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[j][2 * kk + h][col]);
+                floatx16 X0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0][0], nrm, 0, 0, 0);
+                floatx16 X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1][0], nrm, 0, 0, 0);
 #pragma unroll
                 for (int kk = 1; kk < 6; ++kk) {
-                    acc[set][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][kk], bf[0][kk], acc[set][0], 0, 0, 0);
-                    acc[set][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[set][kk], bf[1][kk], acc[set][1], 0, 0, 0);
+                    X0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[0][kk], X0, 0, 0, 0);
+                    X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[1][kk], X1, 0, 0, 0);
                 }
-                // the previous tile, in the other set: its 48 VALU go between this tile's MFMAs
-                const uint32_t gid_prev = (uint32_t)(4 * (meta_prev.y & 255) + 2 * ((j & 1) ^ 1));     // previous tile: the other half of its pair
-                track(0, acc[set ^ 1][0], gid_prev);
-                track(1, acc[set ^ 1][1], gid_prev);
-                // order inside the step: the ten LDS reads of the next tile first, then one MFMA per four VALU
-                __builtin_amdgcn_sched_group_barrier(0x100, 11, 0);
-#define MF_GRP(nv) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);
-                MF_GRP(5) MF_GRP(5) MF_GRP(5) MF_GRP(5) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4) MF_GRP(4)
-#undef MF_GRP
-                if ((j & 1) == 0 && (meta_prev.y & 256)) finish_template(meta_prev.x);   // the previous tile closed its template
-                meta_prev = meta;
+                const int my = __builtin_amdgcn_readfirstlane(mv.y);
+                const uint32_t gid = (uint32_t)(4 * (my & 255) + 2 * (j & 1));
+                track(0, X0, gid);
+                track(1, X1, gid);
+                if ((j & 1) && (my & 256)) finish_template(__builtin_amdgcn_readfirstlane(mv.x));
             }
         }
-        if (s + 2 < n_stages) decode(buf == 0 ? 2 : buf - 1, pf_cur);                   // stage s + 2 into the slot stage s - 1 has left
+        if (s + 1 < n_stages) decode((s + 1) & 1, pf_cur);
         pf_cur = pf_nxt;
-        buf = buf_next;
         __syncthreads();
-    }
-    if (wave_ok) {                                                      // the chunk's last tile
-        const uint32_t gid_prev = (uint32_t)(4 * (meta_prev.y & 255) + 2);
-        track(0, acc[1][0], gid_prev);
-        track(1, acc[1][1], gid_prev);
-        if (meta_prev.y & 256) finish_template(meta_prev.x);
     }
 }
 
@@ -587,11 +554,11 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream)
 {
     if (n_rb <= 0 || g.G <= 0) return hipSuccess;
-    const int n_rg = (n_rb + kMfRowBlocks - 1) / kMfRowBlocks;
     const int n_chunks = (g.G + chunk - 1) / chunk;
+    const int n_rg = (n_rb + kM12RowBlocks - 1) / kM12RowBlocks;
     const long long blocks = (long long)n_rg * n_chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kMfThreads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)pair_meta, pair0,
+    hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kM12Threads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)pair_meta, pair0,
                        (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
     return hipGetLastError();
 }

@@ -56,7 +56,7 @@ struct afis_queries {
 struct afis_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> evpool;      // 6 per query group + 2: the groups of a search run back to back, timings are read at the end
+    std::vector<hipEvent_t> evpool;      // 7 per query group + 2: the groups of a search run back to back, timings are read at the end
     std::string err;
     DevBuf codewords, table;
     HostGallery hg;
@@ -76,7 +76,7 @@ struct afis_ctx {
     DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // lut_dtype 16: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step)
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
-    int adc_variant = 8;                 // 9: fp16 matrix-core bound pass + exact recomputation; 8: 16-bit LDS-table bound pass + exact refine (default); 7: direct exact kernel; 0-3, 6: earlier direct kernels
+    int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD; 0 = 4 with the exact refine (its fp32 table stays in L2), 1 without
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
     int query_batch = 8;
@@ -652,7 +652,7 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
 
 // S4-S6 (+ the row selection of S7) of adc_variant 9 for one query group: row constants, matrix-core bound pass, selection by bounds and exact
 // recomputation.  all_rows: every row is evaluated exactly (parity taps); otherwise rows that cannot reach the pair's top 200 get -inf.
-static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr)
+static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr)
 {
     const QueryDev& d = grp.dev;
     hipStream_t s = ctx->stream;
@@ -679,12 +679,14 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     if (ctx->mf_collect_stats && !ctx->mf_stats.p) { HIPCHK(ctx, ctx->mf_stats.ensure(64)); HIPCHK(ctx, hipMemsetAsync(ctx->mf_stats.p, 0, 64, s)); }
     HIPCHK(ctx, launch_mf_rows(d.lt_des, n_rows, n_rb, ctx->codewords.as<float>(), ctx->mf_cwn.as<float>(), ctx->mf_bfrag.p, ctx->mf_rowk.p, s));
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
-    // workgroups = row groups x gallery chunks: about eight per CU, a chunk never below 8 templates
-    const int n_rg = (n_rb + 15) / 16;
-    const long long want_chunks = std::max<long long>(1, (2048 + n_rg - 1) / n_rg);
+    // workgroups = row groups x gallery chunks: about 24 per CU (a CU runs one at a time: the end of the launch idles at most ~1/24 of it),
+    // a chunk never below 8 templates
+    const int n_rg = (n_rb + 23) / 24;                                 // 24 row blocks per workgroup (adc_mfma.hip)
+    const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
     HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->mf_cw16.p,
                                 ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_rec.p, s));
+    if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
     HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
                                   ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr, s));
     return AFIS_OK;
@@ -709,14 +711,14 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     // The groups run back to back on the stream: no host round trip between them.  Scores of ALL queries stay on the device
     // ([n_q][G]) for the rank-list kernel; they cross PCIe only when the caller asks for them.
     const size_t n_groups = q->groups.size();
-    while (ctx->evpool.size() < n_groups * 6 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
+    while (ctx->evpool.size() < n_groups * 7 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
     if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
     int q0 = 0;
     size_t gi = 0;
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
-        hipEvent_t* ev = &ctx->evpool[gi * 6];
+        hipEvent_t* ev = &ctx->evpool[gi * 7];
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
             HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));
@@ -744,7 +746,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
             if (ctx->adc_variant == 9 && ctx->lut_dtype != 16) {           // fp16 matrix-core bound pass + exact recomputation
-                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1]);
+                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6]);
                 if (rc9 != AFIS_OK) return rc9;
             } else if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {    // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
                 int rc16 = adc_stage_q(ctx, grp, chunk, ctx->lut_dtype != 16, ev[1]);
@@ -775,7 +777,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     }
     // ---- rank lists (matcher.cpp:306-309; ties by ascending index) ----
     const bool dev_topk = k > 0 && k <= kDeviceTopK && G > 0 && nq_all > 0;
-    hipEvent_t* evk = &ctx->evpool[n_groups * 6];
+    hipEvent_t* evk = &ctx->evpool[n_groups * 7];
     if (dev_topk) {
         HIPCHK(ctx, ctx->topk_idx.ensure((size_t)nq_all * k * 8));
         HIPCHK(ctx, ctx->topk_score.ensure((size_t)nq_all * k * 4));
@@ -794,10 +796,15 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (G > 0) {
         for (size_t i = 0; i < n_groups; ++i) {
-            hipEvent_t* ev = &ctx->evpool[i * 6];
+            hipEvent_t* ev = &ctx->evpool[i * 7];
             float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
             for (int j = 0; j < 5; ++j) HIPCHK(ctx, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
             HIPCHK(ctx, hipEventElapsedTime(&tot, ev[0], ev[5]));
+            if (ctx->adc_variant == 9 && ctx->lut_dtype != 16 && q->groups[i].n_lt_rows > 0) {
+                float tb_ = 0, tr_ = 0;
+                HIPCHK(ctx, hipEventElapsedTime(&tb_, ev[1], ev[6])); HIPCHK(ctx, hipEventElapsedTime(&tr_, ev[6], ev[2]));
+                tm.adc_bound_ms += tb_; tm.adc_refine_ms += tr_;
+            } else tm.adc_bound_ms += ms[1];
             tm.lut_ms += ms[0]; tm.adc_ms += ms[1]; tm.tex_tail_ms += ms[2]; tm.minu_ms += ms[3]; tm.fuse_ms += ms[4]; tm.total_ms += tot;
         }
         if (dev_topk) { float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, evk[0], evk[1])); tm.topk_ms = t; tm.total_ms += t; }

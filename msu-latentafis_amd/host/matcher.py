@@ -39,7 +39,7 @@ class TemplateView(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("lut_ms", C.c_float), ("adc_ms", C.c_float), ("tex_tail_ms", C.c_float), ("minu_ms", C.c_float), ("fuse_ms", C.c_float), ("topk_ms", C.c_float),
-                ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64)]
+                ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64), ("adc_bound_ms", C.c_float), ("adc_refine_ms", C.c_float)]
 
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",

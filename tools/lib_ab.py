@@ -13,7 +13,10 @@ lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb); S.plant_mate
 paths = [M.LIB_PATH] + sorted(args)
 ms = []
 for path in paths:
-    m = M.Matcher(cbb, lib_path=path); m.gallery_add_packed(gal); m.gallery_commit(0)
+    m = M.Matcher(cbb, lib_path=path)
+    for kv in filter(None, os.environ.get("AFIS_AB_OPTS", "").split(",")):       # e.g. AFIS_AB_OPTS=adc_variant=9,mf_kernel=12
+        m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    m.gallery_add_packed(gal); m.gallery_commit(0)
     ms.append((m, m.upload_queries(lats)))
 ref = None; best = [None] * len(paths)
 for rep in range(4):
