@@ -26,6 +26,7 @@ M = importlib.import_module("msu-latentafis_amd.host.matcher")
 SH = importlib.import_module("msu-latentafis_amd.host.sharding")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense (2065 TF measured with tools/ubench/mfma_layout.hip, one wave per SIMD)
 LDS_PEAK_BYTES = 256 * 256 * 2.4e9     # 256 CUs x 256 B/clk (ds_read_b128) x 2.4 GHz = 157 TB/s (MI355X_MICROARCH.md §LDS); 154.8 TB/s measured with
                                       # tools/ubench/lds_rate.hip (profiles/r01_lds_peak.json)
 BYTES_PER_TEX_POINT = 2 + 2 + 4 + 16  # x, y, ori, 16 PQ code bytes per rolled texture point
@@ -270,27 +271,51 @@ def main():
     if rank == 0 and a.dump_ranks:
         np.savez(a.dump_ranks, idx=np.asarray(idx), score=np.asarray(sc))
     if rank == 0:
-        # roofline of the dominant kernel (PQ-ADC row-max): algorithmic bytes per launch / average launch duration, where the
-        # duration comes from HIP events on the stream the kernel runs on (afis_get_timing).
+        # roofline of the dominant kernel.  Durations come from HIP events on the stream the kernels run on (afis_get_timing).
         launches = max(1, tm_acc["adc_launches"])
         adc_ms_avg = tm_acc["adc_ms"] / launches
         q_per_launch = Q * a.steps / launches
         shard_tex_points = int(nt_all[lo:hi].sum())
         alg_bytes_launch = q_per_launch * shard_tex_points * BYTES_PER_TEX_POINT
-        achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
-        lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
-        quantised = a.lut_dtype == 16 or a.variant in (-1, 8)              # the 16-bit pass (default variant 8 and the tolerance path): 2 LDS bytes per look-up
-        lds_bytes_per_lookup = 2 if quantised else 4
-        traffic = None; traffic_source = None
-        tp = os.path.join(ROOT, "profiles", "adc_hbm_traffic.json")
-        if os.path.exists(tp) and world == 1 and G == 100000 and Q == 100:      # measured for the default workload only
+        hbm_achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
+        variant = 9 if a.variant < 0 else a.variant
+        carried = None
+        cp = os.path.join(ROOT, "profiles", "r03_adc_counters.json")
+        if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9 and a.lut_dtype == 32:   # measured for the default workload only
             try:
-                tj = json.load(open(tp))
-                traffic = tj.get("traffic_bytes_per_launch")
-                traffic_source = "profiles/adc_hbm_traffic.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, %s; PMC counters cannot be read inside this run)" % tj.get("round", "round 1")
-                if a.variant not in (-1, 8) or a.lut_dtype != 32: traffic = None; traffic_source = None
+                carried = json.load(open(cp))
             except Exception:
-                traffic = None
+                carried = None
+        if variant == 9 and a.lut_dtype == 32:
+            # k_adc_mfma: every (latent texture row, rolled texture point) cell is a 96-long fp16 dot product on the matrix cores: 192 flop
+            rows_per_step = sum(min(L.tex[0].n, 1000) if L.tex else 0 for L in lats)
+            alg_flops_launch = rows_per_step * a.steps / launches * shard_tex_points * 192.0
+            bound_ms_avg = tm_acc["adc_bound_ms"] / launches
+            tflops = alg_flops_launch / (bound_ms_avg * 1e-3) / 1e12 if bound_ms_avg > 0 else 0.0
+            roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": MFMA_F16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
+                        "traffic": carried.get("traffic_bytes_per_launch") if carried else None,
+                        "traffic_source": ("profiles/r03_adc_counters.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
+                                           "calibrated in profiles/r03_fetch_calibration.json; PMC counters cannot be read inside this run)") if carried else None,
+                        "achieved_is": "ALGORITHMIC flops (latent texture rows of the launch x rolled texture points of the shard x 192) / average kernel duration; padding rows / points and the "
+                                       "recomputation kernel's work are not counted",
+                        "alg_flops_per_launch": alg_flops_launch, "avg_launch_ms": round(bound_ms_avg, 3),
+                        "refine_kernel_avg_launch_ms": round(tm_acc["adc_refine_ms"] / launches, 3),
+                        "hbm_view": {"what": "the same stage (bound pass + recomputation) priced as north_star prices it: 24 algorithmic bytes per rolled texture point per query / stage time", "alg_bytes_per_launch": alg_bytes_launch,
+                                     "achieved_GBps": round(hbm_achieved, 2), "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_achieved / HBM_PEAK_GBS, 6)},
+                        "unit_fractions_from_counters": carried.get("fractions") if carried else None,
+                        "limiting_resource": "matrix pipe and vector issue in turn: the waves of a SIMD run the tile loop in step (MFMA bursts together, then tracking together), see DESIGN section 4"}
+        else:
+            lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
+            quantised = a.lut_dtype == 16 or variant == 8                       # the 16-bit pass (variant 8 and the tolerance path): 2 LDS bytes per look-up
+            lds_bytes_per_lookup = 2 if quantised else 4
+            roofline = {"bound": "hbm", "kernel": ("k_adc_rowmin_q<1024,true> (16-bit LDS-table bound pass + exact refine)" if variant == 8 else "k_adc_rowmax (direct exact kernel)") if a.lut_dtype == 32 else "k_adc_rowmin_q<1024,false> (tolerance path)",
+                        "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "traffic": None, "traffic_source": None,
+                        "achieved_is": "ALGORITHMIC bytes (24 B per rolled texture point per query of the launch) / kernel time; by construction not the binding resource: see lds_frac and limiting_resource",
+                        "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),
+                        "lds_lookups_per_s": lookups_per_s, "lds_bytes_per_lookup": lds_bytes_per_lookup, "lds_peak_bytes_per_s": LDS_PEAK_BYTES,
+                        "lds_frac": round(lookups_per_s * lds_bytes_per_lookup / LDS_PEAK_BYTES, 4),
+                        "limiting_resource": "vector instruction issue (profiles/r02_pmc_sq_summary.txt: 8.27e10 VALU instructions per launch at 3.5 cycles each, profiles/r03_valu_peak.json, = 0.78 of the SIMD-cycles); LDS array 0.55 busy"}
         pipeline_bytes = Q * (int(nt_all.sum()) * BYTES_PER_TEX_POINT + int(nm_all.sum()) * BYTES_PER_MINUTIA)
         out = {
             "metric": "latent queries/sec vs 100k rolled gallery", "value": round(value, 4), "unit": "queries/s",
@@ -301,17 +326,10 @@ def main():
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
-                       "adc_variant": a.variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
+                       "adc_variant": variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
-            "roofline": {"bound": "hbm", "kernel": ("k_adc_rowmin_q<1024,true> (16-bit bound pass + exact refine)" if a.variant in (-1, 8) else "k_adc_rowmax (direct exact kernel)") if a.lut_dtype == 32 else "k_adc_rowmin_q<1024,false> (tolerance path)", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
-                         "achieved_is": "ALGORITHMIC bytes (24 B per rolled texture point per query of the launch) / kernel time; the kernel reads each code byte from HBM once per launch and is bound by LDS/VALU issue, see lds_frac",
-                         "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),
-                         "lds_lookups_per_s": lookups_per_s, "lds_bytes_per_lookup": lds_bytes_per_lookup, "lds_peak_bytes_per_s": LDS_PEAK_BYTES,
-                         "lds_frac": round(lookups_per_s * lds_bytes_per_lookup / LDS_PEAK_BYTES, 4),
-                         "limiting_resource": "VALU issue (about one VALU instruction per 4.4 cycles per SIMD, profiles/r02_pmc_sq_summary.txt); LDS array about half busy",
-                         "pipeline_achieved_GBps": round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9 / 1.0, 3)},
-            "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
+            "roofline": dict(roofline, pipeline_achieved_GBps=round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 3)),
+            "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
             "refine_stats": m.refine_stats() if a.refine_stats else None,
             "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},
         }

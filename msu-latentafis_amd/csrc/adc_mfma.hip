@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
 // Selection by bounds + exact evaluation.  Persistent workgroups of 8 waves (the fp32 codebook, 96 KB, in LDS); each wave draws
 // (latent, rolled) pairs from a counter and owns a 4 KB item list.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kRfWaves = 8, kRfItems = 512;
+constexpr int kRfWaves = 16, kRfItems = 384;        // 96 KB codebook + 16 x 3 KB item lists = 144 KB of LDS; <= 128 VGPRs
 struct __align__(16) RfWave { unsigned short row[kRfItems]; unsigned short pt[kRfItems]; float val[kRfItems]; };
 
 __device__ __forceinline__ uint32_t ord_f32(float v) { const uint32_t b = f2u(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -390,6 +390,7 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             float d[4] = {6.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int mg = 0; mg < 4; ++mg) {
+                __builtin_amdgcn_sched_barrier(0);                      // one quarter of the descriptor (24 floats) in registers at a time
                 float a[24];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) { const float4 v = a4[mg * 6 + k]; a[4 * k] = v.x; a[4 * k + 1] = v.y; a[4 * k + 2] = v.z; a[4 * k + 3] = v.w; }
@@ -405,26 +406,38 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             return (d[0] + d[1]) + (d[2] + d[3]);
         };
 
-        // ---- A: bounds of every row's maximum -------------------------------------------------------------------------------
+        // ---- A: lower bounds of every row's maximum (ordered keys, 16 registers) ------------------------------------------------------------
         constexpr int kRegs = (kTexMax + 63) / 64;
         const int n_regs = (n_lt + 63) >> 6;
-        uint32_t klo[kRegs], khi[kRegs];
-#pragma unroll
-        for (int u = 0; u < kRegs; ++u) {
-            const int e = u * 64 + lane;
-            klo[u] = 0u; khi[u] = 0u;
-            if (u < n_regs && e < n_lt) {
-                const uint2 a = rec0[e], b = rec1[e];
-                const float4 rk = rowk[l0 + e];
-                const float mid = rk.x + 2.0f * fmaxf(u2f(a.x), u2f(b.x));
-                // rounding of mid itself (|mid| <= a few units): two more ulps on either side
-                klo[u] = ord_f32(mid - rk.y - 4e-6f * fmaxf(1.0f, fabsf(mid))); khi[u] = ord_f32(mid + rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid)));
-            }
-        }
-        // ---- B: the 200th largest LOWER bound; a row whose UPPER bound is below it cannot be among the 200 (matcher.cpp:736-747) ----
-        uint32_t C = 0u;
+        auto bounds = [&](int e, const uint2& a, const uint2& b, float& lo, float& hi) {
+            const float4 rk = rowk[l0 + e];
+            const float mid = rk.x + 2.0f * fmaxf(u2f(a.x), u2f(b.x));
+            const float sl = rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid));    // rounding of mid itself (|mid| <= a few units): two more ulps on either side
+            lo = mid - sl; hi = mid + sl;
+        };
+        uint32_t C = 0u;                                                // rows whose UPPER bound's key is below C cannot be among the pair's top 200
         if (!all_rows && n_lt > kTopTex) {
-            for (int bit = 31; bit >= 0; --bit) {
+            uint32_t klo[kRegs];
+            uint32_t kmax = 0u, kmin = 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < kRegs; ++u) {
+                const int e = u * 64 + lane;
+                klo[u] = 0u;
+                if (u < n_regs && e < n_lt) {
+                    float lo, hi; bounds(e, rec0[e], rec1[e], lo, hi);
+                    klo[u] = ord_f32(lo);
+                    kmax = max(kmax, klo[u]); kmin = min(kmin, klo[u]);
+                }
+            }
+            // ---- B: (a lower bound of) the 200th largest lower bound (matcher.cpp:736-747), bit by bit.  Any C at or below the true value is safe
+            // (it only lets a few more rows through), so the search starts at the first bit in which the keys differ at all and stops 14 bits
+            // further down: a resolution of 2^-14 of the keys' spread, far below the width of the bounds themselves.
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off)); kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off)); }
+            const uint32_t diff = kmax ^ kmin;
+            const int top = diff ? 31 - __clz((int)diff) : -1;           // highest differing bit (wave-uniform)
+            C = top >= 0 ? (kmax & ~((2u << top) - 1u)) : kmax;          // the common prefix
+            for (int bit = top; bit >= max(top - 14, 0); --bit) {
                 const uint32_t cand = C | (1u << bit);
                 int cnt = 0;
 #pragma unroll
@@ -463,15 +476,16 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         for (int u = 0; u < n_regs; ++u) {
             const int e = u * 64 + lane;
             const bool in = e < n_lt;
-            uint32_t lo_k = 0u, hi_k = 0u;
-#pragma unroll
-            for (int k = 0; k < kRegs; ++k) if (k == u) { lo_k = klo[k]; hi_k = khi[k]; }
-            (void)lo_k;
-            const bool active = in && hi_k >= C;
+            uint2 ra = make_uint2(0u, 0u), rb = make_uint2(0u, 0u);
+            bool active = false;
+            if (in) {
+                ra = rec0[e]; rb = rec1[e];
+                float lo, hi; bounds(e, ra, rb, lo, hi);
+                active = ord_f32(hi) >= C;
+            }
             if (in && !active) { rm_val[o + e] = -INFINITY; rm_arg[o + e] = 0; }
-            uint32_t pts[8]; int cnt = 0; bool full = false;
+            uint32_t pts[4]; int cnt = 0; bool full = false;
             if (active) {
-                const uint2 ra = rec0[e], rb = rec1[e];
                 const float tg = rowk[l0 + e].z;
                 const float V = fmaxf(u2f(ra.x), u2f(rb.x));
 #pragma unroll
@@ -490,11 +504,12 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                             const uint32_t p = 32u * (tt[a] >> 1) + (rr & 3u) + 8u * (rr >> 2) + 4u * (uint32_t)hh;
                             if (a < nt && b < nk && p < (uint32_t)n_rt) {
 #pragma unroll
-                                for (int z = 0; z < 8; ++z) if (z == cnt) pts[z] = p;
+                                for (int z = 0; z < 4; ++z) if (z == cnt) pts[z] = p;
                                 ++cnt;
                             }
                         }
                 }
+                full = full || cnt > 4;                                 // more than four candidate cells (both halves with runners-up): every point instead
                 if (full) cnt = 0;
             }
             st_active += (unsigned long long)__popcll(__ballot(active));
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             if (n_items + total > kRfItems) flush();
             const int base = n_items + incl - cnt;
 #pragma unroll
-            for (int z = 0; z < 8; ++z) if (z < cnt) { W.row[base + z] = (unsigned short)e; W.pt[base + z] = (unsigned short)pts[z]; }
+            for (int z = 0; z < 4; ++z) if (z < cnt) { W.row[base + z] = (unsigned short)e; W.pt[base + z] = (unsigned short)pts[z]; }
             n_items += total;
         }
         flush();

@@ -79,7 +79,7 @@ struct afis_ctx {
     int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD; 0 = 4 with the exact refine (its fp32 table stays in L2), 1 without
     int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
-    int query_batch = 8;
+    int query_batch = 10;                // latents per launch group at most (adc_variant 9 places the cuts by latent texture rows: see afis_queries_upload)
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     int64_t rowmax_budget_bytes = 24ll << 30;
@@ -604,10 +604,37 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch, by_mem));
     afis_queries* q = new afis_queries();
     q->n_q = n_q;
-    for (int i = 0; i < n_q; i += per) {
+    // Launch groups are contiguous runs of at most `per` queries.  The matrix-core bound pass (adc_variant 9) works in row groups of 768 latent
+    // texture rows: a run whose rows fill its last row group only partly pays for the whole of it, so the cuts are placed where the total
+    // number of row groups is smallest (dynamic programme over the cut positions; ties: fewer launches).  Results do not depend on the cuts.
+    std::vector<int> cuts;                                                  // group ends (exclusive)
+    if (ctx->adc_variant == 9 && ctx->lut_dtype != 16 && n_q > 1) {
+        std::vector<long long> rows((size_t)n_q + 1, 0);
+        for (int i = 0; i < n_q; ++i) {
+            const afis_template_view& t = queries[i];
+            const bool has = t.n_tex > 0 && t.tex && !(t.n_minu <= kSelected[0] && t.n_tex <= 0);
+            rows[(size_t)i + 1] = rows[(size_t)i] + (has ? std::min(std::max(t.tex[0].n, 0), kTexMax) : 0);
+        }
+        const long long kInf = 1ll << 60;
+        std::vector<long long> best((size_t)n_q + 1, kInf); std::vector<int> from((size_t)n_q + 1, 0), cnt((size_t)n_q + 1, 0);
+        best[0] = 0;
+        for (int i = 1; i <= n_q; ++i)
+            for (int j = std::max(0, i - per); j < i; ++j) {
+                const long long c = best[(size_t)j] + (rows[(size_t)i] - rows[(size_t)j] + 767) / 768;
+                if (c < best[(size_t)i] || (c == best[(size_t)i] && cnt[(size_t)j] + 1 < cnt[(size_t)i])) { best[(size_t)i] = c; from[(size_t)i] = j; cnt[(size_t)i] = cnt[(size_t)j] + 1; }
+            }
+        for (int i = n_q; i > 0; i = from[(size_t)i]) cuts.push_back(i);
+        std::reverse(cuts.begin(), cuts.end());
+    } else {
+        for (int i = per; i < n_q; i += per) cuts.push_back(i);
+        if (n_q > 0) cuts.push_back(n_q);
+    }
+    int g0 = 0;
+    for (int end : cuts) {
         q->groups.emplace_back();
-        int rc = build_group(ctx, queries + i, std::min(per, n_q - i), q->groups.back(), q->status);
+        int rc = build_group(ctx, queries + g0, end - g0, q->groups.back(), q->status);
         if (rc != AFIS_OK) { afis_queries_free(ctx, q); return rc; }
+        g0 = end;
     }
     *out = q;
     return AFIS_OK;
