@@ -165,7 +165,6 @@ def main():
     ap.add_argument("--query-batch", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tile-share", type=int, default=0)
-    ap.add_argument("--lut-dtype", type=int, default=32, help="32 = exact fp32 LUT (the headline path); 16 = opt-in 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (a few atomics per pair; not for timed runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
@@ -222,7 +221,6 @@ def main():
     if a.variant >= 0: m.set_option("adc_variant", a.variant)
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)
-    if a.lut_dtype != 32: m.set_option("lut_dtype", a.lut_dtype)
     if a.tile_share > 0: m.set_option("tile_share", a.tile_share)
     if a.refine_stats: m.set_option("mf_stats", 1)
     t_up = time.perf_counter()
@@ -281,12 +279,12 @@ def main():
         variant = 9 if a.variant < 0 else a.variant
         carried = None
         cp = os.path.join(ROOT, "profiles", "r03_adc_counters.json")
-        if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9 and a.lut_dtype == 32:   # measured for the default workload only
+        if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only
             try:
                 carried = json.load(open(cp))
             except Exception:
                 carried = None
-        if variant == 9 and a.lut_dtype == 32:
+        if variant == 9:
             # k_adc_mfma: every (latent texture row, rolled texture point) cell is a 96-long fp16 dot product on the matrix cores: 192 flop
             rows_per_step = sum(min(L.tex[0].n, 1000) if L.tex else 0 for L in lats)
             alg_flops_launch = rows_per_step * a.steps / launches * shard_tex_points * 192.0
@@ -307,9 +305,9 @@ def main():
                         "limiting_resource": "matrix pipe and vector issue in turn: the waves of a SIMD run the tile loop in step (MFMA bursts together, then tracking together), see DESIGN section 4"}
         else:
             lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
-            quantised = a.lut_dtype == 16 or variant == 8                       # the 16-bit pass (variant 8 and the tolerance path): 2 LDS bytes per look-up
+            quantised = variant == 8                                            # the 16-bit pass: 2 LDS bytes per look-up
             lds_bytes_per_lookup = 2 if quantised else 4
-            roofline = {"bound": "hbm", "kernel": ("k_adc_rowmin_q<1024,true> (16-bit LDS-table bound pass + exact refine)" if variant == 8 else "k_adc_rowmax (direct exact kernel)") if a.lut_dtype == 32 else "k_adc_rowmin_q<1024,false> (tolerance path)",
+            roofline = {"bound": "hbm", "kernel": "k_adc_rowmin_q<1024,true> (16-bit LDS-table bound pass + exact refine)" if variant == 8 else "k_adc_rowmax (direct exact kernel)",
                         "achieved": round(hbm_achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_achieved / HBM_PEAK_GBS, 6), "traffic": None, "traffic_source": None,
                         "achieved_is": "ALGORITHMIC bytes (24 B per rolled texture point per query of the launch) / kernel time; by construction not the binding resource: see lds_frac and limiting_resource",
                         "alg_bytes_per_launch": alg_bytes_launch, "avg_launch_ms": round(adc_ms_avg, 3),
@@ -320,9 +318,9 @@ def main():
         out = {
             "metric": "latent queries/sec vs 100k rolled gallery", "value": round(value, 4), "unit": "queries/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32" if a.lut_dtype == 32 else "u16 fixed-point LUT + f32 (tolerance path, NOT the bit-exact headline configuration)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch {Q} latents vs {G}-template synthetic rolled gallery "
-                                   f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists" + ("" if a.lut_dtype == 32 else "; 16-bit fixed-point LUT tolerance path (BASELINE.json configs[4] kernel on one GPU)"), "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
+                                   f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists", "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),

@@ -193,10 +193,8 @@ int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
  * 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as
  * references (4 and 5 were earlier forms of 6/7 and are rejected).
  * "query_batch" (latents per launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae
- * candidate kernel), "rowmax_budget_mb", "mf_stats" (adc_variant 9: collect afis_debug_refine_stats), and "lut_dtype": 32 (default) = exact,
- * every result bit-identical to the reference arithmetic; 16 = opt-in TOLERANCE path: the per-query table quantised to 16-bit fixed point (16 latent rows per 128 KB LDS tile,
- * integer sums).  Its only error is the quantisation (|d sim| <= 16 steps / 2, about 4e-3), so row maxima
- * and arg-maxima can differ from the exact path where two candidates are closer than that; scores are NOT bit-exact.
+ * candidate kernel), "rowmax_budget_mb", "mf_stats" (adc_variant 9: collect afis_debug_refine_stats).  ("lut_dtype" accepts only 32: the opt-in 16-bit
+ * tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
 

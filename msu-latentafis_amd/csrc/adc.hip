@@ -474,16 +474,14 @@ hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float
 }
 
 // ===============================================================================================================
-// Opt-in tolerance path (BASELINE.json configs[4], "fp16 LUT path"): the LUT quantised to 16-bit fixed point.
+// adc_variant 8: the LUT quantised to 16-bit fixed point as a BOUND pass, exact values from the fp32 table (k_adc_rowmin_q below).
 //   lut'[i][m][c] = lut[i][m][c] - min_c lut[i][m][.]  >= 0,   Q = round(lut' / q_i) in [0, 2047],   q_i = max_m range(i, m) / 2047
-//   sim(i, j) ~= (6 - sum_m min_m) - q_i * sum_m Q[i][m][code_jm]
+//   sim(i, j) ~= (6 - sum_m min_m) - q_i * sum_m Q[i][m][code_jm],   |error| <= 16 q_i / 2
 // Sixteen rows fit a 128 KB tile (two 16-byte reads return one (m, code) entry of all 16 rows), the 16 sub-quantizer terms are
-// added EXACTLY as packed 15-bit integers (16 x 2047 < 2^15: v_pk_add_u16, no rounding, any order), and the per-row minimum of
-// the integer sum — i.e. the maximum similarity — and its first point are tracked with packed 16-bit min / sign-mask / bfi.  Per
-// look-up this halves the LDS bytes and takes 0.7 x the VALU work of the fp32 kernel.  The ONLY error is the quantisation:
-// |sim_q - sim| <= 16 * q_i / 2 (about 4e-3; 6e-4 rms), so (max, argmax) can differ from the exact kernel's where the two best
-// points of a row are closer than that.  NOT bit-exact: afis_set_option("lut_dtype", 16) selects it, the default stays fp32.
-// Fixed-point rather than fp16 because an fp16 accumulation would add its own rounding at every one of the 16 steps.
+// added EXACTLY as packed 15-bit integers (16 x 2047 < 2^15, any order), and the per-row minimum of the integer sum — i.e. the maximum
+// similarity — its block and the lane's second smallest sum are tracked with packed 16-bit min / sign-mask / bfi.
+// (Rounds 1-2 also shipped this pass WITHOUT the exact refine as an opt-in "lut_dtype 16" tolerance path; it met SURVEY 8d's 1e-3 tolerance on
+// 98.2 % of the pairs instead of the required 99.9 % and was removed in round 3.)
 //   Tile layout (bytes): (m >> 3) << 16 | code << 8 | (m & 7) << 5 | half << 4, 16 bytes = rows 8*half .. 8*half+7 as u16.
 //   Conflict-free by construction, as k_adc_rowmax_cf: the 16 lanes a ds_read_b128 services together are 16 classes
 //   a = lane & 15 -> (pc = a >> 1, pr = a & 1); at step s a lane reads m = 8*mhi + ((s + pc) & 7), half pr first then pr ^ 1, so
@@ -582,13 +580,48 @@ __global__ __launch_bounds__(64) void k_codes_q(GalleryDev g, const int32_t* __r
     }
 }
 
+// Lane-ordered code stream of the direct conflict-free kernel (k_adc_rowmax_cf, variants 6 / 7), laid out on first use: template t owns
+// (blocks + 1) x 64 entries of 16 bytes starting at block cf_blk[t]; entry (block k, lane l) belongs to lane class a = l & 15
+// (pc = (a >> 1) & 3, pm = a >> 3).  Dword d carries sub-quantizer group mg = (d + 2 pm) & 3, byte c of it chain perm[(c + pc) & 3]; lanes
+// with pm = 1 run half a period late, so their dwords 0, 1 (mg 2, 3) come from point (k - 1) * 64 + l and their dwords 2, 3 (mg 0, 1) from point
+// k * 64 + l.  Entries without a point are zero.  grid = G, block = 64.
+__global__ __launch_bounds__(64) void k_codes_cf(GalleryDev g, uint4* __restrict__ out)
+{
+    const int t = blockIdx.x, l = threadIdx.x;
+    const int p0 = g.tex_off[t], n = g.tex_off[t + 1] - p0;
+    if (n <= 0) return;
+    const int blocks = (n + 63) >> 6;
+    const int a = l & 15, pc = (a >> 1) & 3, pm = a >> 3;
+    const int perm[4] = {0, 2, 1, 3};
+    for (int k = 0; k <= blocks; ++k) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int mg = (d + 2 * pm) & 3;
+            const int pt = (pm && d < 2 ? k - 1 : k) * 64 + l;
+            if (pt < 0 || pt >= n) continue;
+            const uint4 c = g.tex_codes[p0 + pt];
+            const uint32_t src = mg == 0 ? c.x : mg == 1 ? c.y : mg == 2 ? c.z : c.w;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) w[d] |= ((src >> (8 * perm[(cc + pc) & 3])) & 255u) << (8 * cc);
+        }
+        out[((size_t)g.tex_cf_blk[t] + k) * 64 + l] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+hipError_t launch_codes_cf(const GalleryDev& g, void* out, hipStream_t stream)
+{
+    if (g.G <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_codes_cf, dim3(g.G), dim3(64), 0, stream, g, (uint4*)out);
+    return hipGetLastError();
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(uint32_t x) { return __builtin_bit_cast(u16x2, x); }
 __device__ __forceinline__ uint32_t as_u32(u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
 
-// kExact = false: the tolerance path described above.
-// kExact = true (adc_variant 8): the quantised pass is only a BOUND, the results are the exact fp32 ones, bit for bit.  With
+// kExact = true (adc_variant 8; the only instantiation): the quantised pass is only a BOUND, the results are the exact fp32 ones, bit for bit.  With
 // e = 8 q_i + a few 1e-6 the bound on |q_i * S_j - exact part of sim(i, j)|, every point whose exact similarity equals the row's
 // exact maximum has an integer sum S_j <= S* + T_i, T_i = 16 + ceil(2 delta_i / q_i) + 2 (S* = the smallest sum; delta_i from the row's own table, see k_lutq_build).  Each lane also tracks
 // its SECOND smallest sum per row; if no lane's second sum is <= S* + T_i, the lanes whose smallest sum is <= S* + T_i hold every
@@ -739,48 +772,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
         block(n_blocks - 1, std::true_type{});
         constexpr int kXor1 = 0xB1, kXor2 = 0x4E, kRor4 = 0x124, kRor8 = 0x128;   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
         const bool row_ok = lane < kQRows && row0 + lane < n_lt;
-        if constexpr (!kExact) {
-            // ---- minimum over the 64 lanes: 32-bit keys (sum << 16 | point index) make "smallest sum, then first point" one v_min_u32 ----
-            // physical slots: A[j] (j < 8) = rows 8*pr + j, B[j] = rows 8*(pr^1) + j
-            uint32_t A[8], B[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t ba = as_u32(best[k]), bb = as_u32(best[k + 4]);
-                A[2 * k] = (ba << 16) | ((bidx[k] & 0xffffu) * 64u + (uint32_t)lane);
-                A[2 * k + 1] = (ba & 0xffff0000u) | ((bidx[k] >> 16) * 64u + (uint32_t)lane);
-                B[2 * k] = (bb << 16) | ((bidx[k + 4] & 0xffffu) * 64u + (uint32_t)lane);
-                B[2 * k + 1] = (bb & 0xffff0000u) | ((bidx[k + 4] >> 16) * 64u + (uint32_t)lane);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {                      // lane ^ 1 holds the same rows in its OTHER slot set
-                const uint32_t oa = (uint32_t)dpp_i<kXor1>((int)B[j]), ob = (uint32_t)dpp_i<kXor1>((int)A[j]);
-                A[j] = min(A[j], oa); B[j] = min(B[j], ob);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                A[j] = min(A[j], (uint32_t)dpp_i<kXor2>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kXor2>((int)B[j]));
-                A[j] = min(A[j], (uint32_t)dpp_i<kRor4>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor4>((int)B[j]));
-                A[j] = min(A[j], (uint32_t)dpp_i<kRor8>((int)A[j])); B[j] = min(B[j], (uint32_t)dpp_i<kRor8>((int)B[j]));
-                // across the four rows of 16 lanes: row_bcast:15 / row_bcast:31 leave the minimum over all 64 lanes in lane 63 — an ODD
-                // lane (pr = 1: its A slots are rows 8..15, its B slots rows 0..7); only odd lanes feed it
-                A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x142, 0xa, 0xf, false));
-                B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x142, 0xa, 0xf, false));
-                A[j] = min(A[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)A[j], 0x143, 0xc, 0xf, false));
-                B[j] = min(B[j], (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)B[j], 0x143, 0xc, 0xf, false));
-            }
-            uint32_t mine = 0;                                 // lane r < 16 ends up with row r's key
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)(r < 8 ? B[r] : A[r - 8]), 63);
-                if (lane == r) mine = sk;
-            }
-            if (row_ok) {
-                const float4 rc = rowc[lt0 + row0 + lane];
-                const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
-                rm_val[o] = rc.x - rc.y * (float)(mine >> 16);
-                rm_arg[o] = (int32_t)(mine & 0xffffu);
-            }
-        } else {
+        {
             // ---- exact tail.  (1) the packed minimum S* of the 16 row sums over the wave (no indices: 8 registers instead of 16 keys) ----
             auto pkmin = [](uint32_t x, uint32_t y) { return as_u32(__builtin_elementwise_min(as_u16x2(x), as_u16x2(y))); };
             uint32_t Mn[8];
@@ -928,10 +920,9 @@ hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const voi
     if (share < 1) share = 1;
     const long long blocks = (long long)((n_chunks + 8 * share - 1) / (8 * share)) * 8 * share * q.n_tiles16;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (lut32) hipLaunchKernelGGL((k_adc_rowmin_q<1024, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                                  (const float4*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
-    else hipLaunchKernelGGL((k_adc_rowmin_q<1024, false>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
-                            (const float4*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
+    if (!lut32) return hipErrorInvalidValue;                              // (the table-less tolerance form of rounds 1-2 is gone)
+    hipLaunchKernelGGL((k_adc_rowmin_q<1024, true>), dim3((unsigned)blocks), dim3(1024), 0, stream, q, g, (const uint4*)codes_q, q_blk, (const uint4*)lutq_tiles,
+                       (const float4*)rowc, lut32, chunk, n_chunks, share, rm_val, rm_arg);
     return hipGetLastError();
 }
 

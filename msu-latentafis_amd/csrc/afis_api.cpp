@@ -64,7 +64,9 @@ struct afis_ctx {
     int64_t index_base = 0;
     GalleryDev gal;
     DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_tex_codes_q, g_tex_q_blk, g_empty, g_task_ctr;
-    bool codes_q_built = false;          // the quantised path's code stream is laid out on first use (lut_dtype 16)
+    bool codes_cf_built = false;         // variants 6 / 7: their lane-ordered code stream, laid out on first use
+    int64_t cf_blocks = 0;
+    bool codes_q_built = false;          // adc_variant 8's lane-ordered code stream is laid out on first use
     int64_t q_blocks = 0;
     int max_nR = 0;
     int64_t total_tex_points = 0;
@@ -73,12 +75,11 @@ struct afis_ctx {
     DevBuf mf_cw16, mf_cwn, g_codes_p, g_nrm_p, g_pair_meta, mf_bfrag, mf_rowk, mf_rec, mf_stats;
     bool mf_cb_built = false, mf_gal_built = false;
     int mf_collect_stats = 0;
-    DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // lut_dtype 16: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step)
+    DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // adc_variant 8: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step, margin), fp32 table
     DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
-    int tile_share = 0;                  // variant 8 / lut_dtype 16: consecutive chunks per tile on an XCD; 0 = 4 with the exact refine (its fp32 table stays in L2), 1 without
-    int lut_dtype = 32;                  // 32: exact fp32 LUT (default, bit-exact); 16: 16-bit fixed-point LUT (opt-in tolerance path)
+    int tile_share = 0;                  // adc_variant 8: consecutive chunks per tile on an XCD; 0 = 4 (the refine's fp32 table stays in L2)
     int query_batch = 10;                // latents per launch group at most (adc_variant 9 places the cuts by latent texture rows: see afis_queries_upload)
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
@@ -324,7 +325,9 @@ int afis_gallery_add_dat(afis_ctx* ctx, const void* bytes, size_t len, int* load
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add_dat: gallery already committed");
     HostTemplate t;
     int rc = parse_rolled_dat(bytes, len, t);
-    if (rc < 0) { t.minu.clear(); t.tex.clear(); }                          // matcher.cpp:173-177
+    // matcher.cpp:173-177: a negative code discards the template.  Code 8 (a descriptor length outside 1..192, where the reference overruns a
+    // stack buffer) is this parser's own: the cursor is misaligned from there on, so the partial template is discarded too (score -1).
+    if (rc < 0 || rc == 8) { t.minu.clear(); t.tex.clear(); }
     if (load_rc) *load_rc = rc;
     std::vector<afis_minutiae_view> mv; std::vector<afis_texture_view> tv; afis_template_view v;
     views_of(t, mv, tv, v);
@@ -460,37 +463,15 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_codes, hg.tcodes, ctx->stream));
-    {   // conflict-free ADC stream (adc.hip): template t owns (blocks + 1) x 64 entries of 16 bytes; entry (block k, lane l)
-        // belongs to lane class a = l & 15 (pc = (a>>1)&3, pm = a>>3).  Dword d carries sub-quantizer group mg = (d + 2*pm) & 3,
-        // byte c of it chain perm[(c + pc) & 3]; lanes with pm = 1 run half a period late, so their dwords 0,1 (mg 2,3) come from
-        // point (k-1)*64 + l and their dwords 2,3 (mg 0,1) from point k*64 + l.  Entries without a point are zero.
+    {   // block offsets of the direct conflict-free kernel's code stream (variants 6 / 7): (blocks + 1) x 64 entries per template.  The stream
+        // itself — a full copy of the PQ codes — is laid out on the device at the first use of those variants (k_codes_cf); the default path
+        // never builds it.
         std::vector<int32_t> cfb(G + 1);
         int64_t nblk = 0;
         for (int64_t t = 0; t < G; ++t) { cfb[t] = (int32_t)nblk; const int64_t n = hg.tex_off[t + 1] - hg.tex_off[t]; nblk += n > 0 ? (n + 63) / 64 + 1 : 0; }
         cfb[G] = (int32_t)nblk;
         if (nblk > 0x7fffffff / 64) return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for the ADC code stream; split the gallery into more shards");
-        std::vector<uint8_t> cf((size_t)nblk * 64 * kM, 0);
-        static const int perm[4] = {0, 2, 1, 3};
-        parallel_for(G, [&](int64_t t_lo, int64_t t_hi) {
-        for (int64_t t = t_lo; t < t_hi; ++t) {
-            const int64_t n = hg.tex_off[t + 1] - hg.tex_off[t];
-            if (n <= 0) continue;
-            const int64_t blocks = (n + 63) / 64;
-            for (int64_t k = 0; k <= blocks; ++k)
-                for (int l = 0; l < 64; ++l) {
-                    const int a = l & 15, pc = (a >> 1) & 3, pm = a >> 3;
-                    uint8_t* dst = &cf[((size_t)(cfb[t] + k) * 64 + l) * kM];
-                    for (int d = 0; d < 4; ++d) {
-                        const int mg = (d + 2 * pm) & 3;
-                        const int64_t pt = (pm && d < 2 ? k - 1 : k) * 64 + l;       // the point this dword belongs to
-                        if (pt < 0 || pt >= n) continue;
-                        const uint8_t* src = &hg.tcodes[(size_t)(hg.tex_off[t] + pt) * kM];
-                        for (int c = 0; c < 4; ++c) dst[d * 4 + c] = src[4 * mg + perm[(c + pc) & 3]];
-                    }
-                }
-        }
-        });
-        HIPCHK(ctx, upload(ctx->g_tex_codes_cf, cf, ctx->stream));
+        ctx->cf_blocks = nblk; ctx->codes_cf_built = false;
         HIPCHK(ctx, upload(ctx->g_tex_cf_blk, cfb, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -509,7 +490,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     g.G = (int32_t)G;
     g.minu_off = ctx->g_minu_off.as<int32_t>(); g.minu_xy = ctx->g_minu_xy.as<short2>(); g.minu_ori = ctx->g_minu_ori.as<float>();
     g.minu_des = ctx->g_minu_des.as<float>(); g.minu_frag = ctx->g_minu_frag.as<float4>(); g.minu_tile_off = ctx->g_minu_tile_off.as<int32_t>(); g.tex_off = ctx->g_tex_off.as<int32_t>(); g.tex_xy = ctx->g_tex_xy.as<short2>();
-    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>(); g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
+    g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = nullptr; g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
     g.task_ctr = ctx->g_task_ctr.as<int32_t>();
     ctx->max_nR = max_nR;
     ctx->total_tex_points = (int64_t)hg.tx.size();
@@ -608,7 +589,7 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     // texture rows: a run whose rows fill its last row group only partly pays for the whole of it, so the cuts are placed where the total
     // number of row groups is smallest (dynamic programme over the cut positions; ties: fewer launches).  Results do not depend on the cuts.
     std::vector<int> cuts;                                                  // group ends (exclusive)
-    if (ctx->adc_variant == 9 && ctx->lut_dtype != 16 && n_q > 1) {
+    if (ctx->adc_variant == 9 && n_q > 1) {
         std::vector<long long> rows((size_t)n_q + 1, 0);
         for (int i = 0; i < n_q; ++i) {
             const afis_template_view& t = queries[i];
@@ -648,10 +629,21 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q)
     delete q;
 }
 
-static int tile_share_of(const afis_ctx* ctx) { return ctx->tile_share > 0 ? ctx->tile_share : (ctx->lut_dtype == 16 ? 1 : 4); }
+// variants 6 / 7 read the gallery's codes from their own lane-ordered stream: lay it out now if this is their first use
+static int ensure_codes_cf(afis_ctx* ctx, int variant)
+{
+    if ((variant != 6 && variant != 7) || ctx->codes_cf_built) return AFIS_OK;
+    HIPCHK(ctx, ctx->g_tex_codes_cf.ensure(std::max<size_t>((size_t)ctx->cf_blocks * 64 * 16, 16)));
+    ctx->gal.tex_codes_cf = ctx->g_tex_codes_cf.as<uint4>();
+    HIPCHK(ctx, launch_codes_cf(ctx->gal, ctx->g_tex_codes_cf.p, ctx->stream));
+    ctx->codes_cf_built = true;
+    return AFIS_OK;
+}
 
-// S4 + S5 + S6 of the opt-in quantised path for one query group (rm_val / rm_arg sized by the caller)
-// exact == true (adc_variant 8): the quantised pass bounds the candidates, the fp32 table (reference layout, all rows of the group) settles them
+static int tile_share_of(const afis_ctx* ctx) { return ctx->tile_share > 0 ? ctx->tile_share : 4; }
+
+// S4 + S5 + S6 of adc_variant 8 for one query group (rm_val / rm_arg sized by the caller): the quantised pass bounds the candidates, the fp32
+// table (reference layout, all rows of the group) settles them
 static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hipEvent_t after_lut = nullptr)
 {
     const QueryDev& d = grp.dev;
@@ -748,7 +740,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         hipEvent_t* ev = &ctx->evpool[gi * 7];
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
-            HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));
+            if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
             HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
             HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
             HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
@@ -768,17 +760,18 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             // tiles' fp32 tables — the refine's gathers — compete for an XCD's L2 at s = 4), so the count is a multiple of 8 s: -4.5 % ADC time
             // at 100k, -3 % at 12.5k.  (Round-2's first measurement of tile_share, with 196 chunks of 512, had shown a loss: the unbalanced
             // chunk count hid the gain.)
-            const long long cmul = 8ll * ((ctx->lut_dtype == 16 || ctx->adc_variant == 8) ? tile_share_of(ctx) : 1);
+            const long long cmul = 8ll * (ctx->adc_variant == 8 ? tile_share_of(ctx) : 1);
             const long long n_chunks_auto = ((G + 639) / 640 + cmul - 1) / cmul * cmul;
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
-            if (ctx->adc_variant == 9 && ctx->lut_dtype != 16) {           // fp16 matrix-core bound pass + exact recomputation
+            if (ctx->adc_variant == 9) {                                    // fp16 matrix-core bound pass + exact recomputation
                 int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6]);
                 if (rc9 != AFIS_OK) return rc9;
-            } else if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) {    // 16-bit fixed-point pass: tolerance path, or bound + exact refine (variant 8)
-                int rc16 = adc_stage_q(ctx, grp, chunk, ctx->lut_dtype != 16, ev[1]);
+            } else if (ctx->adc_variant == 8) {                             // 16-bit fixed-point LDS-table bound pass + exact refine
+                int rc16 = adc_stage_q(ctx, grp, chunk, true, ev[1]);
                 if (rc16 != AFIS_OK) return rc16;
             } else {
+                { int rcf = ensure_codes_cf(ctx, ctx->adc_variant); if (rcf != AFIS_OK) return rcf; }
                 HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, s));
                 HIPCHK(ctx, hipEventRecord(ev[1], s));
                 HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
@@ -827,7 +820,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
             for (int j = 0; j < 5; ++j) HIPCHK(ctx, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
             HIPCHK(ctx, hipEventElapsedTime(&tot, ev[0], ev[5]));
-            if (ctx->adc_variant == 9 && ctx->lut_dtype != 16 && q->groups[i].n_lt_rows > 0) {
+            if (ctx->adc_variant == 9 && q->groups[i].n_lt_rows > 0) {
                 float tb_ = 0, tr_ = 0;
                 HIPCHK(ctx, hipEventElapsedTime(&tb_, ev[1], ev[6])); HIPCHK(ctx, hipEventElapsedTime(&tr_, ev[6], ev[2]));
                 tm.adc_bound_ms += tb_; tm.adc_refine_ms += tr_;
@@ -1007,7 +1000,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     if (!ctx || !name) return AFIS_EINVAL;
     const std::string n(name);
     if (n == "adc_variant") { if (value < 0 || value > 9 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7, 8 or 9"); ctx->adc_variant = (int)value; }
-    else if (n == "lut_dtype") { if (value != 16 && value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype must be 32 (exact, default) or 16 (16-bit fixed-point LUT, tolerance path)"); ctx->lut_dtype = (int)value; }
+    else if (n == "lut_dtype") { if (value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype: only 32 (exact) exists; the 16-bit tolerance path of rounds 1-2 missed its stated tolerance and was removed (the reduced-precision pass of BASELINE.json configs[4] is adc_variant 9 / 8: a bound, followed by exact values)"); }
     else if (n == "tile_share") { if (value < 0 || value > 32) return fail(ctx, AFIS_EINVAL, "tile_share must be 0 (auto) or 1..32"); ctx->tile_share = (int)value; }
     else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
@@ -1112,9 +1105,10 @@ int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, in
         HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * d.lt_pad * 4));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_val.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(ctx->rm_arg.p, 0, n_pairs * d.lt_pad * 4, ctx->stream));
-        if (ctx->adc_variant == 9 && ctx->lut_dtype != 16) { int rc9 = adc_stage_mfma(ctx, grp, true); if (rc9 != AFIS_OK) { grp.release(); return rc9; } }
-        else if (ctx->lut_dtype == 16 || ctx->adc_variant == 8) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32, ctx->lut_dtype != 16); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
+        if (ctx->adc_variant == 9) { int rc9 = adc_stage_mfma(ctx, grp, true); if (rc9 != AFIS_OK) { grp.release(); return rc9; } }
+        else if (ctx->adc_variant == 8) { int rc16 = adc_stage_q(ctx, grp, ctx->chunk > 0 ? ctx->chunk : 32, true); if (rc16 != AFIS_OK) { grp.release(); return rc16; } }
         else {
+        { int rcf = ensure_codes_cf(ctx, ctx->adc_variant); if (rcf != AFIS_OK) { grp.release(); return rcf; } }
         HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), ctx->adc_variant, ctx->stream));
         HIPCHK(ctx, launch_adc_rowmax(d, ctx->gal, ctx->lut.as<float>(), ctx->chunk > 0 ? ctx->chunk : 32, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->stream));
         }
@@ -1156,7 +1150,9 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             if (d.n_tiles <= 0) return AFIS_OK;
             HIPCHK(ctx, ctx->lut.ensure((size_t)d.n_tiles * kTileFloats * 4));
             HIPCHK(ctx, ctx->rm_val.ensure((size_t)d.lt_pad * 4)); HIPCHK(ctx, ctx->rm_arg.ensure((size_t)d.lt_pad * 4));
-            const int av = ctx->adc_variant >= 8 ? 7 : ctx->adc_variant;     // the tap always uses a direct exact kernel (same bits)
+            const int av = ctx->adc_variant >= 8 ? 0 : ctx->adc_variant;     // the tap always uses a direct exact kernel (same bits); for the
+            { int rcf = ensure_codes_cf(ctx, av); if (rcf != AFIS_OK) return rcf; }  // bound + refine variants the plain one, which needs no extra code stream
+            one.tex_codes_cf = ctx->gal.tex_codes_cf;
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), av, s));
             HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, av, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(),

@@ -53,7 +53,7 @@ struct QueryDev {
     const float*   lt_ori = nullptr;
     const float*   lt_des = nullptr;     // [NLT][96]
     const int32_t* tile_off = nullptr;   // [nq+1] LUT tiles (8 rows each) per query
-    const int32_t* tile16_off = nullptr; // [nq+1] 16-row tiles of the quantised (lut_dtype 16) path
+    const int32_t* tile16_off = nullptr; // [nq+1] 16-row tiles of adc_variant 8's quantised table
     int32_t n_tiles16 = 0;
     const int32_t* tex_slot = nullptr;   // [nq] index of the texture score in the reference's score vector (= #latent minutiae templates), -1 = no texture
     const int32_t* status = nullptr;     // [nq] AFIS_QUERY_*
@@ -101,10 +101,12 @@ hipError_t launch_lut_build(const QueryDev& q, const float* codewords, float* lu
 // S5+S6: ADC similarity + per-row (max, first argmax) for queries [q0, q0+nq) against gallery templates.
 hipError_t launch_adc_rowmax(const QueryDev& q, const GalleryDev& g, const float* lut_tiles, int chunk, int variant,
                              float* rm_val, int32_t* rm_arg, hipStream_t stream);
-// Opt-in quantised path (lut_dtype 16, adc.hip): 16-bit fixed-point LUT tiles of 16 rows + per-row (offset, step); the lane-ordered code
-// stream it reads (ceil(n/64) blocks per template, first block q_blk[t]); S5+S6 with integer sums.  NOT bit-exact (quantisation error only).
+// adc_variant 8 (adc.hip): 16-bit fixed-point LUT tiles of 16 rows + per-row (offset, step, margin); the lane-ordered code stream it reads
+// (ceil(n/64) blocks per template, first block q_blk[t]); S5+S6 with integer sums as a bound pass.
 hipError_t launch_lutq_build(const QueryDev& q, int n_rows_total, const float* codewords, float* row_min, float* row_rng, void* tiles, void* rowc, hipStream_t stream);
 hipError_t launch_codes_q(const GalleryDev& g, const int32_t* q_blk, void* out, hipStream_t stream);
+// the direct conflict-free kernel's lane-ordered code stream (variants 6 / 7), laid out on the device at first use (g.tex_cf_blk = its block offsets)
+hipError_t launch_codes_cf(const GalleryDev& g, void* out, hipStream_t stream);
 // lut32 != NULL (adc_variant 8): the quantised pass only bounds the candidates, which are then evaluated exactly from the fp32 table in the
 // reference layout [row][16][256] (launch_lut_reference_layout over all latent texture rows of the group): exact results, bit for bit.
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,

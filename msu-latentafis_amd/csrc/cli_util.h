@@ -27,7 +27,7 @@ struct ArgParser {
 };
 
 // afis.config is a flat JSON object of string values (afis.config:1-17); this reads exactly that.
-std::map<std::string, std::string> read_flat_json(const std::string& path)
+inline std::map<std::string, std::string> read_flat_json(const std::string& path)
 {
     std::map<std::string, std::string> kv;
     std::ifstream in(path);

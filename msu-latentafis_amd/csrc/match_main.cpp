@@ -99,6 +99,7 @@ int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path
             read_file(files[(size_t)i].string(), b);
             int load_rc = 0;
             CHECK(ctx, afis_gallery_add_dat(ctx, b.data(), b.size(), &load_rc));
+            if (load_rc == 8) fprintf(stderr, "warning: %s: descriptor length outside 1..192, template discarded (scores -1)\n", files[(size_t)i].string().c_str());
         }
     }
     if (!pack_to.empty()) {

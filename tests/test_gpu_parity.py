@@ -824,56 +824,15 @@ def test_rank_lists_device_kernel_equals_host_sort(codebook_bytes, cb, medium, s
     m.close()
 
 
-# ---- opt-in tolerance path: 16-bit fixed-point LUT (afis_set_option("lut_dtype", 16); BASELINE.json configs[4]) -------------------------
-def test_quantised_lut_path_rowmax_within_its_bound(codebook_bytes, cb, oracle, small):
-    """S5+S6 of the quantised kernel against the exact one: every row maximum within the quantisation bound 16 * q_i / 2 (q_i = largest
-    per-sub-quantizer range of the row's table / 2047), and wherever the arg-max differs the chosen point's EXACT similarity is within
-    twice that bound of the exact maximum (i.e. the two points were closer than the path can resolve)."""
+def test_the_tolerance_path_is_gone(codebook_bytes, cb, small):
+    """Rounds 1-2 shipped an opt-in 16-bit LUT path that was NOT bit-exact and missed SURVEY 8d's tolerance (98.2 % of pairs within 1e-3 instead of
+    99.9 %).  It was removed: lut_dtype accepts only 32, every ADC variant left is bit-identical to the reference arithmetic."""
     lats, gal = small
     m = _matcher(codebook_bytes, gal)
-    ocb = oracle.codebook(codebook_bytes)
-    n_rows = n_same = 0
-    for qi in range(len(lats)):
-        lut = oracle.build_lut(ocb, lats[qi].tex[0].des).astype(np.float64)           # [rows][16][256], the exact table
-        qstep = (lut.max(axis=2) - lut.min(axis=2)).max(axis=1) / 2047.0
-        bound = 8.0 * qstep + 1e-5
-        for g in (0, 1, 5, 17, len(gal) - 1):
-            m.set_option("lut_dtype", 32)
-            val, arg = m.debug_texture_rowmax(lats[qi], g)
-            m.set_option("lut_dtype", 16)
-            qval, qarg = m.debug_texture_rowmax(lats[qi], g)
-            assert np.all(np.abs(qval.astype(np.float64) - val) <= bound), (qi, g, np.abs(qval - val).max(), bound.max())
-            codes = gal[g].tex[0].codes[:1000]
-            rows = np.arange(len(val))
-            exact_at_q = 6.0 - lut[rows[:, None], np.arange(16)[None, :], codes[qarg]].sum(axis=1)
-            assert np.all(exact_at_q >= val - 2 * bound), (qi, g)
-            n_rows += len(val); n_same += int((qarg == arg).sum())
     m.set_option("lut_dtype", 32)
+    with pytest.raises(M.AfisError):
+        m.set_option("lut_dtype", 16)
     m.close()
-    assert n_same >= 0.97 * n_rows, (n_same, n_rows)
-
-
-def test_quantised_lut_path_scores_within_tolerance(codebook_bytes, cb, medium):
-    """Fused scores of the quantised path against the exact path on 6 x 3000 pairs: the stated tolerance |d| <= 1e-3 * max(1, |s|) must
-    hold for the planted mates and for the bulk of all pairs; the mates' rank lists must be identical.  (Pairs outside the tolerance
-    are correspondences whose two best rolled points the 16-bit table cannot tell apart.)"""
-    lats, gal, planted = medium
-    m = M.Matcher(codebook_bytes)
-    m.gallery_add_packed(gal); m.gallery_commit(0)
-    exact = m.search(lats, k=24)
-    m.set_option("lut_dtype", 16)
-    quant = m.search(lats, k=24)
-    m.close()
-    e, q = exact["scores"], quant["scores"]
-    far = np.abs(q - e) > 1e-3 * np.maximum(1.0, np.abs(e))
-    pos = (e > 0) | (q > 0)
-    print("quantised LUT path: pairs beyond 1e-3: %d of %d (%.3f %% of all, %.3f %% of the %d positive-scoring pairs); max |d| %.4f"
-          % (far.sum(), far.size, 100.0 * far.mean(), 100.0 * far[pos].mean(), pos.sum(), np.abs(q - e).max()))
-    assert far.mean() <= 0.02, far.mean()
-    for qi in range(len(lats)):
-        mates = [g for g, _ in planted[qi]]
-        assert list(quant["topk_idx"][qi][:len(mates)]) == mates
-        assert not far[qi, mates].any(), (qi, e[qi, mates], q[qi, mates])
 
 
 def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes, cb, medium):
