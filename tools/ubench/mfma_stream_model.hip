@@ -9,6 +9,9 @@
 //   6  + every 26 units a "template end": ~80 VALU, one 8-byte store per lane, state reset (a uniform branch in the stream)
 //   7  as 6, but the decode's LDS operations are spread between the MFMAs of the 4 units and the barrier sits in the middle of a unit's MFMA stream
 //      (three-slot ring: the data decoded in stage s is read from stage s + 2 on, so any one barrier per stage orders everything)
+//   8  no LDS operands at all: every wave loads the tile's operand groups (6 KB per tile, the same addresses for the 8 waves of a workgroup, a
+//      fresh tile every unit: L1 / L2 traffic) straight from global memory one unit ahead; point terms through a wave-private LDS slice; no decode,
+//      no workgroup barrier; template-end branch as in 6
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -27,11 +30,12 @@ __device__ __forceinline__ void track_part(Trk& t, int blk, const floatx16& X, u
     if (part == 5) { const float eh = __uint_as_float((__float_as_uint(t.ts[blk]) & ~63u) | gid); t.tb[blk] = __builtin_amdgcn_fmed3f(t.tb[blk], eh, t.m[blk][2]); t.m[blk][3] = fmaxf(t.m[blk][3], eh); }
 }
 template <int LVL>
-__global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters)
+__global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, int iters, const uint4* __restrict__ gsrc)
 {
     __shared__ uint4 s_l[16][64];
     __shared__ uint4 s_cw[4096];
     __shared__ uint4 s_ring[2][48][32];
+    __shared__ float s_priv[8][2][32];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 16 * 64; i += 512) (&s_l[0][0])[i] = make_uint4(0x3c003c00u, 0x38003800u + i, 0x34003400u, 0x30003000u);
     for (int i = tid; i < 4096; i += 512) s_cw[i] = make_uint4(i, i * 3, i * 5, 0);
@@ -51,7 +55,14 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
 #pragma unroll
         for (int par = 0; par < 2; ++par) {                          // two units per iteration: static set indices
             const unsigned gid = (unsigned)((2 * it + par) & 31) * 2u;
-            if (LVL >= 3) {
+            if (LVL == 8) {
+                const uint4* tsrc = gsrc + ((size_t)blockIdx.x * 4096 + (size_t)((2 * it + par) & 4095)) * 448;     // this workgroup's tile stream: 7 x 64 x 16 B per tile
+#pragma unroll
+                for (int q = 0; q < 6; ++q) aq[par ^ 1][q] = __builtin_bit_cast(half8, tsrc[q * 64 + lane]);
+                if (lane < 32) s_priv[tid >> 6][par][lane] = reinterpret_cast<const float*>(tsrc + 6 * 64)[lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float4 w = *reinterpret_cast<const float4*>(&s_priv[tid >> 6][par ^ 1][8 * q + 4 * (lane >> 5)]); nrm[4 * q] = w.x; nrm[4 * q + 1] = w.y; nrm[4 * q + 2] = w.z; nrm[4 * q + 3] = w.w; }
+            } else if (LVL >= 3) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) aq[par ^ 1][q] = __builtin_bit_cast(half8, s_l[q][(lane + it) & 63]);
                 if (LVL >= 4) {
@@ -68,7 +79,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
                     floatx16& D = LVL >= 2 ? acc[par][blk] : acc[0][blk];
                     D = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, (LVL >= 4 && kk == 0) ? nrm : D, 0, 0, 0);
                     if (LVL >= 2) track_part(t, blk, acc[par ^ 1][blk], gid, kk);
-                    if (LVL >= 7) {
+                    if (LVL == 7) {
                         const int unit = (it & 1) * 2 + par;             // unit of the stage (0..3)
                         uint4 (&dst)[48][32] = s_ring[(it >> 1) & 1];
                         if (blk == 0 && kk == 1 && unit < 2) { dw[2 * unit] = s_cw[((2 * unit) * 1024 + ((code >> (16 * unit)) & 255u) * 4 + (tid & 3)) & 4095]; dw[2 * unit + 1] = s_cw[((2 * unit + 1) * 1024 + ((code >> (16 * unit + 8)) & 255u) * 4 + (tid & 3)) & 4095]; }
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
                     }
                 }
             }
-            if (LVL >= 6) {
+            if (LVL == 6 || LVL == 7 || LVL == 8) {
                 if (((2 * it + par) % 26) == 25) {                  // uniform
 #pragma unroll
                     for (int blk = 0; blk < 2; ++blk) {
@@ -100,7 +111,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
                 }
             }
         }
-        if (LVL >= 5 && LVL < 7 && (it & 1)) {                       // every 4 units
+        if ((LVL == 5 || LVL == 6) && (it & 1)) {                       // every 4 units
             code = code * 1664525u + 1013904223u;
             uint4 w[4];
 #pragma unroll
@@ -125,8 +136,10 @@ template <int LVL> double run()
     float* d; unsigned long long* dc;
     (void)hipMalloc(&d, (2 + 256 * 512) * 4 + 256 * 2 * 512 * 8); (void)hipMalloc(&dc, 256 * 8 * 8); (void)hipMemset(d, 0, 8);
     const int iters = 1500;
-    hipLaunchKernelGGL((k<LVL>), dim3(256), dim3(512), 0, 0, d, dc, 30);
-    hipLaunchKernelGGL((k<LVL>), dim3(256), dim3(512), 0, 0, d, dc, iters);
+    static uint4* gsrc = nullptr;
+    if (!gsrc) { (void)hipMalloc(&gsrc, (size_t)256 * 4096 * 448 * 16); (void)hipMemset(gsrc, 0x3c, (size_t)256 * 4096 * 448 * 16); }
+    hipLaunchKernelGGL((k<LVL>), dim3(256), dim3(512), 0, 0, d, dc, 30, gsrc);
+    hipLaunchKernelGGL((k<LVL>), dim3(256), dim3(512), 0, 0, d, dc, iters, gsrc);
     (void)hipDeviceSynchronize();
     std::vector<unsigned long long> h(256 * 8);
     (void)hipMemcpy(h.data(), dc, h.size() * 8, hipMemcpyDeviceToHost);
@@ -137,7 +150,7 @@ template <int LVL> double run()
 int main()
 {
     printf("{\"benchmark\": \"tools/ubench/mfma_stream_model.hip\", \"unit\": \"12 v_mfma_f32_32x32x16_f16 + 48 VALU per wave, two waves per SIMD; 768 cycles = the matrix pipe's share\", \"cycles_per_unit_per_wave\": {"
-           "\"0_constant_operands_private_valu\": %.0f, \"1_rotating_operands\": %.0f, \"2_valu_tracks_other_accumulator_set\": %.0f, \"3_operands_from_lds_one_unit_ahead\": %.0f, \"4_c_operand_from_lds\": %.0f, \"5_decode_phase_and_barrier_every_4_units\": %.0f, \"6_template_end_branch\": %.0f, \"7_decode_between_the_mfmas_barrier_mid_stream\": %.0f}}\n",
-           run<0>(), run<1>(), run<2>(), run<3>(), run<4>(), run<5>(), run<6>(), run<7>());
+           "\"0_constant_operands_private_valu\": %.0f, \"1_rotating_operands\": %.0f, \"2_valu_tracks_other_accumulator_set\": %.0f, \"3_operands_from_lds_one_unit_ahead\": %.0f, \"4_c_operand_from_lds\": %.0f, \"5_decode_phase_and_barrier_every_4_units\": %.0f, \"6_template_end_branch\": %.0f, \"7_decode_between_the_mfmas_barrier_mid_stream\": %.0f, \"8_operands_from_global_memory_no_lds_no_barrier\": %.0f}}\n",
+           run<0>(), run<1>(), run<2>(), run<3>(), run<4>(), run<5>(), run<6>(), run<7>(), run<8>());
     return 0;
 }
