@@ -951,6 +951,42 @@ def test_matrix_core_bound_pass_selection_statistics(codebook_bytes, cb, medium)
     m.close()
 
 
+def test_matrix_core_bound_pass_tile_stage_and_chunk_edges(codebook_bytes, cb):
+    """k_adc_mfma's bookkeeping at its edges: rolled texture templates of 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000 and 1900 (clamped) points and none
+    at all (tiles, pairs of tiles, padding tiles, the last-pair flag), latents of 1, 31, 33, 767, 769 and 1000 texture rows plus one without texture (row blocks,
+    row groups of 768, launch-group cuts), and workgroup chunks of 1, 2, 3, 7 templates (stages that end inside a pair, chunks of empty templates).
+    Row maxima / arg-maxima through the parity tap and per-part scores through the search equal the direct exact kernel bit for bit."""
+    rng = np.random.default_rng(909)
+    sizes = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 1900, 0, 700, 0, 5]
+    gal = []
+    for n in sizes:
+        r = S.make_rolled(rng, cb, n_tex=max(n, 1))
+        if n == 0:
+            r.tex = []
+        gal.append(r)
+    base = S.make_latent(rng, n_tex_lo=1000, n_tex_hi=1000)
+    lt = base.tex[0]
+    def latent(n):
+        tex = [] if n == 0 else [T.TextureTemplate(lt.x[:n].copy(), lt.y[:n].copy(), lt.ori[:n].copy(), des=lt.des[:n].copy())]
+        return T.FPTemplate(minu=list(base.minu), tex=tex)
+    lats = [latent(n) for n in (1, 31, 33, 767, 0, 769, 1000)]
+    gal[13] = S.make_mate(rng, cb, base, frac=0.6, n_tex=700)       # one real mate so that the texture scorer has something to find
+    m = _matcher(codebook_bytes, gal)
+    m.set_option("adc_variant", 7)
+    want = m.search(lats, k=0, want_parts=True)
+    taps = {(qi, g): m.debug_texture_rowmax(lats[qi], g) for qi in (0, 2, 3, 5, 6) for g in (0, 3, 6, 9, 10, 11, 13, 15)}
+    m.set_option("adc_variant", 9)
+    for chunk in (0, 1, 2, 3, 7):
+        m.set_option("chunk", chunk)
+        got = m.search(lats, k=0, want_parts=True)
+        assert np.array_equal(got["parts"].view(np.uint32), want["parts"].view(np.uint32)), (chunk, np.argwhere(got["parts"] != want["parts"])[:5])
+        for (qi, g), (v7, a7) in taps.items():
+            v9, a9 = m.debug_texture_rowmax(lats[qi], g)
+            assert np.array_equal(v7.view(np.uint32), v9.view(np.uint32)) and np.array_equal(a7, a9), (chunk, qi, g)
+    assert want["parts"][6, 13, 3] > 20
+    m.close()
+
+
 def test_minutiae_coordinates_beyond_the_packed_path(codebook_bytes, cb, oracle):
     """S8a arithmetic paths: pixel coordinates within [0, 2047] take the packed 16-bit predicate (v_pk_sub_i16 + v_dot2), anything larger
     — here offsets of 2040 (straddling the limit), 5000 and 30000 — the generic float arithmetic, where dx*dx + dy*dy is no longer exact.
