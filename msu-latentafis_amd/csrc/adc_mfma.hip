@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 // i - 1 interleaved between the MFMAs of tile i (two accumulator sets); the same with a three-stage LDS ring and operand reads one tile ahead;
 // the two waves of a SIMD half a period apart (one in its MFMA burst while the other tracks); the decode spread over the tile steps;
 // s_setprio 3 around the MFMA burst; one pipelined stream per wave after tools/ubench/mfma_stream_model.hip with the decode between the MFMAs and the
-// stage barrier in the middle of a step (3 % faster, 256 registers with spills: not kept).
+// stage barrier in the middle of a step (3 % faster, 256 registers with spills: not kept); an s_sleep of 0 / 200 / 400 cycles by wave class after each
+// stage barrier, so that the three waves of a SIMD start their stages staggered (no change).
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int kM12Threads = 768, kM12RowBlocks = 24, kM12StageTiles = 6;
 struct __align__(16) M12Stage {

@@ -30,7 +30,7 @@ valu = json.load(open("profiles/r03_valu_peak.json"))
 vop3_3w = None
 for r in valu["results"]:
     if r["instruction"].startswith("v_max3_f32"):
-        c = r["cycles_per_wave64_instruction_per_simd"]; vop3_3w = (c["2_waves"] + c["4_waves"]) / 2            # three waves per SIMD: between the 2- and 4-wave figures
+        vop3_3w = r["cycles_per_wave64_instruction_per_simd"]["3_waves"]                                       # the kernel runs three waves per SIMD
 xcd_cycles = sq["GRBM_GUI_ACTIVE"] / 8                                      # the counter is summed over the 8 XCDs
 simd_cycles = 1024 * xcd_cycles; cu_cycles = 256 * xcd_cycles
 n_valu = sq["SQ_INSTS_VALU"] - sq["SQ_INSTS_MFMA"]                          # SQ_INSTS_VALU counts the MFMAs too

@@ -1,4 +1,4 @@
-// Micro-benchmark: VALU issue cost per wave64 instruction on MI355X (gfx950), by encoding / opcode class, at 1, 2, 4 and 8 waves per SIMD.
+// Micro-benchmark: VALU issue cost per wave64 instruction on MI355X (gfx950), by encoding / opcode class, at 1, 2, 3, 4, 6 and 8 waves per SIMD.
 // Cycles are SHADER cycles read in the kernel (s_memtime), not wall time divided by an assumed clock; the effective clock (cycles / wall) is
 // printed beside them.  One workgroup per CU (256 blocks x 256*w threads: w waves on each of the 4 SIMDs; w = 8 uses two 1024-thread blocks per CU).
 // Every instruction group is 8 independent instructions on 8 different registers, so dependent-issue latency does not enter.
@@ -73,7 +73,7 @@ __global__ void k(unsigned* out, unsigned long long* cyc, int iters)
 struct Res { double cyc_per_instr_simd, wall_cyc_24, clock_ghz; };
 template <int KIND> Res run(int wps)
 {
-    const int iters = 20000, threads = wps <= 4 ? 256 * wps : 1024, blocks = wps <= 4 ? 256 : 256 * (wps / 4);
+    const int iters = 20000, threads = wps <= 4 ? 256 * wps : (wps == 6 ? 768 : 1024), blocks = wps <= 4 ? 256 : (wps == 6 ? 512 : 256 * (wps / 4));
     unsigned* d; unsigned long long* dc;
     hipMalloc(&d, (size_t)blocks * threads * 4); hipMalloc(&dc, (size_t)blocks * threads / 64 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -94,9 +94,9 @@ template <int KIND> Res run(int wps)
 template <int KIND> void all(bool last)
 {
     printf("  {\"instruction\": \"%s\", \"cycles_per_wave64_instruction_per_simd\": {", kNames[KIND]);
-    const int ws[4] = {1, 2, 4, 8};
+    const int ws[6] = {1, 2, 3, 4, 6, 8};
     double clk = 0;
-    for (int i = 0; i < 4; ++i) { Res r = run<KIND>(ws[i]); clk = r.clock_ghz; printf("\"%d_waves\": %.3f%s", ws[i], r.cyc_per_instr_simd, i < 3 ? ", " : ""); }
+    for (int i = 0; i < 6; ++i) { Res r = run<KIND>(ws[i]); clk = r.clock_ghz; printf("\"%d_waves\": %.3f%s", ws[i], r.cyc_per_instr_simd, i < 5 ? ", " : ""); }
     printf("}, \"effective_clock_ghz_at_8_waves\": %.3f}%s\n", clk, last ? "" : ",");
 }
 int main()
