@@ -324,7 +324,8 @@ def main():
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
-                       "adc_variant": variant, "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
+                       "adc_variant": variant, "bound_pass_dtype": ("f16 operands, f32 accumulation on the matrix cores: used for BOUNDS only, every score is the reference's f32 arithmetic" if variant == 9 else
+                                                                   "u16 fixed point in LDS: used for BOUNDS only" if variant == 8 else "none"), "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
             "roofline": dict(roofline, pipeline_achieved_GBps=round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 3)),
             "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
