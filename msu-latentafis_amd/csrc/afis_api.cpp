@@ -80,7 +80,7 @@ struct afis_ctx {
     std::vector<float> h_scores, h_parts;
     int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // adc_variant 8: consecutive chunks per tile on an XCD; 0 = 4 (the refine's fp32 table stays in L2)
-    int query_batch = 10;                // latents per launch group at most (adc_variant 9 places the cuts by latent texture rows: see afis_queries_upload)
+    int query_batch = 0;                 // latents per launch group at most; 0 = by shard size (afis_queries_upload); adc_variant 9 places the cuts by latent texture rows
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     int64_t rowmax_budget_bytes = 24ll << 30;
@@ -582,7 +582,11 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     // group size: bounded by the option and by the rowmax buffer budget (nq * G * 1000 rows * 8 B)
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
     int64_t by_mem = ctx->rowmax_budget_bytes / (G * kTexMax * 8);
-    int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch, by_mem));
+    // latents per launch group: the option, or (0 = auto) as many as keep about a million (latent, rolled) pairs in a launch — 10 at a 100k-template
+    // shard, 64 at 12.5k: the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
+    // each cost 1.2 x their share of a 100k-template step; 2 launches do not)
+    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : std::min<int64_t>(64, std::max<int64_t>(10, (1000000 + G / 2) / G));
+    int per = (int)std::max<int64_t>(1, std::min<int64_t>(want, by_mem));
     afis_queries* q = new afis_queries();
     q->n_q = n_q;
     // Launch groups are contiguous runs of at most `per` queries.  The matrix-core bound pass (adc_variant 9) works in row groups of 768 latent
@@ -931,7 +935,7 @@ int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, flo
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int n_pq = std::max((n_minu + 2) / 3, n_tex);
     const int64_t by_mem = std::max<int64_t>(1, ctx->rowmax_budget_bytes / (std::max<int64_t>(1, G) * kTexMax * 8));
-    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch, by_mem));
+    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch > 0 ? ctx->query_batch : 10, by_mem));
     std::vector<float> parts;
     for (int j0 = 0; j0 < n_pq; j0 += per) {
         const int nq = std::min(per, n_pq - j0);
@@ -1002,7 +1006,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     if (n == "adc_variant") { if (value < 0 || value > 9 || value == 4 || value == 5) return fail(ctx, AFIS_EINVAL, "adc_variant must be 0..3, 6, 7, 8 or 9"); ctx->adc_variant = (int)value; }
     else if (n == "lut_dtype") { if (value != 32) return fail(ctx, AFIS_EINVAL, "lut_dtype: only 32 (exact) exists; the 16-bit tolerance path of rounds 1-2 missed its stated tolerance and was removed (the reduced-precision pass of BASELINE.json configs[4] is adc_variant 9 / 8: a bound, followed by exact values)"); }
     else if (n == "tile_share") { if (value < 0 || value > 32) return fail(ctx, AFIS_EINVAL, "tile_share must be 0 (auto) or 1..32"); ctx->tile_share = (int)value; }
-    else if (n == "query_batch") { if (value < 1 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 1..256"); ctx->query_batch = (int)value; }
+    else if (n == "query_batch") { if (value < 0 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 0 (auto) or 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
