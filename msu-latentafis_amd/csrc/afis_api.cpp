@@ -792,7 +792,8 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             if (parts) HIPCHK(ctx, hipMemcpyAsync(parts + (size_t)q0 * G * 4, ctx->parts.p, n_pairs * 16, hipMemcpyDeviceToHost, s));
             if (d.n_tiles > 0) {
                 tm.adc_launches += 1;
-                int64_t rows = 0; for (int n : grp.h_lt_n) rows += (n + kTileRows - 1) / kTileRows * kTileRows;
+                const int tile_rows = ctx->adc_variant == 8 ? 16 : kTileRows;   // rows the launched kernel pads a latent to (variant 9 does no table look-ups: the count is nominal there)
+                int64_t rows = 0; for (int n : grp.h_lt_n) rows += (n + tile_rows - 1) / tile_rows * tile_rows;
                 tm.adc_lookups += rows * ctx->total_tex_points * kM;
             }
             tm.pairs += (int64_t)n_pairs;
