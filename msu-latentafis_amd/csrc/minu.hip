@@ -293,7 +293,7 @@ struct RtSmem {
     u64 cand[kCandCap];                              // exact composite keys of the candidates
     uint32_t cand_e[kCandCap];                       // their (row << 8 | column)
     int wave_tot[kWaves];
-    int thr_bin, n_cand;
+    int thr_bin, pad_;
 };
 
 __device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 store_tile(it, jt, mfma_tile(af, bf));
             }
             sm.hist[tid] = 0u;
-            if (tid == 0) { sm.n_cand = 0; sm.thr_bin = -1; }
+            if (tid == 0) sm.thr_bin = -1;
             __syncthreads();
             PHASE(16);
             // ---- S2 (:455-456): index-ascending sums; odd row stride: both walks are conflict free.  Eight reads are issued before
@@ -488,6 +488,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) if (w > wave) above += sm.wave_tot[w];
                 if (above < kTopMinu && above + own >= kTopMinu) sm.thr_bin = tid;
+                sm.hist[tid] = (uint32_t)above;                                      // from here on: where the next candidate of this bin goes
             }
             __syncthreads();
             PHASE(30);
@@ -499,37 +500,44 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 uint32_t hits = 0;
 #pragma unroll
                 for (int t = 0; t < 32; ++t) hits |= (rk[t] + kKeySlack >= edge ? 1u : 0u) << t;   // unused slots hold 0 (bounding the loop by n_rows was measured: 2 % slower)
-                if (hits) {
-                    int p = atomicAdd(&sm.n_cand, __popc(hits));
-                    while (hits) {
-                        const int t = __ffs(hits) - 1;
-                        hits &= hits - 1;
-                        if (p < kCandCap) sm.cand_e[p] = (uint32_t)(((cr + R * t) << 8) | cj);
-                        ++p;
-                    }
+                // The candidates are appended GROUPED BY BIN, highest bin first (every key of a bin above B is a candidate, so the suffix
+                // counts of the scan are the groups' start positions; keys of bin B - 1 within the slack join group B, the last one).
+                // The bin of a hit is recomputed from LDS: indexing rk[] with a runtime t would put the 32 keys into scratch.
+                const float cs = sm.colsum[cj];
+                while (hits) {
+                    const int t = __ffs(hits) - 1;
+                    hits &= hits - 1;
+                    const int i = cr + R * t;
+                    const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs);
+                    const int bin = max(min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1), B);
+                    const uint32_t p = atomicAdd(&sm.hist[bin], 1u);
+                    if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 16) | (i << 8) | cj);
                 }
             }
             __syncthreads();
             PHASE(31);
-            const int n_c = sm.n_cand;                                               // >= 120
+            const int n_c = (int)sm.hist[B];                                         // >= 120: group B ends the list
             if (n_c > kCandCap) { if (tid == 0) to_fallback(task); __syncthreads(); continue; }
-            int ci = 0, cj2 = 0;
+            int ci = 0, cj2 = 0, cbin = 0;
             if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
                 const uint32_t pe = sm.cand_e[tid];
-                ci = (int)(pe >> 8); cj2 = (int)(pe & 255u);
+                cbin = (int)(pe >> 16); ci = (int)((pe >> 8) & 255u); cj2 = (int)(pe & 255u);
                 sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 13) | (u64)(8191 - (ci * nR + cj2));
-            }
+            } else if (tid == n_c) sm.cand[tid & (kCandCap - 1)] = 0ull;             // pad of an odd list (n_c == kCandCap is even: nothing is overwritten)
             __syncthreads();
             PHASE(18);
-            // ---- rank the candidates by counting (composites are unique); ranks < 120 are the list, in the reference's order ----
+            // ---- rank the candidates by counting (composites are unique); ranks < 120 are the list, in the reference's order.
+            // Approximate and exact key differ by at most E = 8 << a bin's width (2^19), so a candidate of bin g can only be out of order
+            // with candidates of bins g - 1 .. g + 1: it counts the larger composites among THOSE (a contiguous range of the grouped list)
+            // and adds the number of candidates in higher bins, which all beat it.  sm.hist[b] now holds the END of group b (= the start
+            // of group b - 1).  The range is widened to even positions: the extra element in front is larger, the one behind smaller or the pad.
             if (tid < n_c) {
                 const u64 mine = sm.cand[tid];
-                int r = 0;
+                const int lo = cbin + 2 < kSelBins ? (int)sm.hist[cbin + 2] & ~1 : 0;
+                const int hi = cbin - 1 > B ? (int)sm.hist[cbin - 1] : n_c;
+                int r = lo;
                 const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(sm.cand);
-                const int n2 = n_c >> 1;
-#pragma unroll 4
-                for (int k = 0; k < n2; ++k) { const ulonglong2 kk = c2[k]; r += kk.x > mine; r += kk.y > mine; }
-                if (n_c & 1) r += sm.cand[n_c - 1] > mine;
+                for (int k = lo; k < hi; k += 2) { const ulonglong2 kk = c2[k >> 1]; r += kk.x > mine; r += kk.y > mine; }
                 if (r < kTopMinu) {
                     MinuCand cd; cd.sim = sm.simi[ci * ld + cj2]; cd.li = (short)ci; cd.ri = (short)cj2;
                     cands[(size_t)task * kTopMinu + r] = cd;
