@@ -711,6 +711,15 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
     else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table, ext);
     else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table, ext);
     n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
+    if (mode >= 1) {                                                       // the survivors' points back to 16-bit integers: what S9 and the correspondence export read
+        for (int t = threadIdx.x; t < num; t += 64) {
+            const int2 v = sm.xy[t];
+            int lx, ly, rx, ry;
+            unpack_h2(v.x, lx, ly); unpack_h2(v.y, rx, ry);
+            sm.xy[t] = pack_xy(lx, ly, rx, ry);
+        }
+        WSYNC();
+    }
     if (stop_after == 1) return 0.0f;
     n_survivors = 0;
     if (num < 2) return 0.0f;
@@ -837,15 +846,24 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             for (int t = lane; t < num; t += 64) { sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
         }
         WSYNC();
-        int out_of_range = 0, not_small = 0;                             // any block coordinate outside [0, 8191]: generic arithmetic for this list;
-        for (int t = lane; t < num; t += 64) {                           // all inside [0, 49] (always, for real templates): no |d| < 50 test needed
-            const int a = sm.li[t], b = sm.ri[t];
-            const short2 lp = q.lt_xy[l0 + a], rp = g.tex_xy[r0 + b];
-            sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
-            out_of_range |= (lp.x | lp.y | rp.x | rp.y) & ~8191;
-            not_small |= ((unsigned)lp.x > 49u) | ((unsigned)lp.y > 49u) | ((unsigned)rp.x > 49u) | ((unsigned)rp.y > 49u);
+        int out_of_range = 0, not_small = 0;                             // any block coordinate outside [0, 2047]: generic arithmetic for this list;
+        short2 lp4[TexSmem::U], rp4[TexSmem::U];                         // all inside [0, 49] (always, for real templates): no |d| < 50 test needed
+#pragma unroll
+        for (int u = 0; u < TexSmem::U; ++u) {
+            const int t = lane + 64 * u;
+            lp4[u] = make_short2(0, 0); rp4[u] = make_short2(0, 0);
+            if (t < num) {
+                lp4[u] = q.lt_xy[l0 + sm.li[t]]; rp4[u] = g.tex_xy[r0 + sm.ri[t]];
+                out_of_range |= (lp4[u].x | lp4[u].y | rp4[u].x | rp4[u].y) & ~2047;
+                not_small |= ((unsigned)lp4[u].x > 49u) | ((unsigned)lp4[u].y > 49u) | ((unsigned)rp4[u].x > 49u) | ((unsigned)rp4[u].y > 49u);
+            }
         }
         const int mode = __ballot(out_of_range != 0) != 0ull ? 0 : (__ballot(not_small != 0) == 0ull ? 2 : 1);
+#pragma unroll
+        for (int u = 0; u < TexSmem::U; ++u) {                           // packed paths: coordinates as fp16 pairs (graph_arith.h); generic: 16-bit integers
+            const int t = lane + 64 * u;
+            if (t < num) sm.xy[t] = mode ? make_int2(pack_h2(lp4[u].x, lp4[u].y), pack_h2(rp4[u].x, rp4[u].y)) : pack_xy(lp4[u].x, lp4[u].y, rp4[u].x, rp4[u].y);
+        }
         WSYNC();
         GPH_K(15);                                                       // S7 + list build
         int n_surv;
@@ -901,14 +919,24 @@ __global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g,
         const int l0 = q.lm_off[qs], r0 = g.minu_off[gi];
         const MinuCand* c = cands + (size_t)task * kTopMinu;
         int out_of_range = 0;                                            // any pixel coordinate outside [0, 2047]: generic float arithmetic
-        for (int t = lane; t < num; t += 64) {
-            const MinuCand cd = c[t];
-            sm.simv[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
-            const short2 lp = q.lm_xy[l0 + cd.li], rp = g.minu_xy[r0 + cd.ri];
-            sm.xy[t] = pack_xy(lp.x, lp.y, rp.x, rp.y);
-            out_of_range |= (lp.x | lp.y | rp.x | rp.y) & ~2047;
+        short2 lp2[MinuGraphSmem::U], rp2[MinuGraphSmem::U];
+#pragma unroll
+        for (int u = 0; u < MinuGraphSmem::U; ++u) {
+            const int t = lane + 64 * u;
+            lp2[u] = make_short2(0, 0); rp2[u] = make_short2(0, 0);
+            if (t < num) {
+                const MinuCand cd = c[t];
+                sm.simv[t] = cd.sim; sm.li[t] = cd.li; sm.ri[t] = cd.ri;
+                lp2[u] = q.lm_xy[l0 + cd.li]; rp2[u] = g.minu_xy[r0 + cd.ri];
+                out_of_range |= (lp2[u].x | lp2[u].y | rp2[u].x | rp2[u].y) & ~2047;
+            }
         }
         const int mode = __ballot(out_of_range != 0) == 0ull ? 1 : 0;
+#pragma unroll
+        for (int u = 0; u < MinuGraphSmem::U; ++u) {                     // packed path: coordinates as fp16 pairs (graph_arith.h); generic: 16-bit integers
+            const int t = lane + 64 * u;
+            if (t < num) sm.xy[t] = mode ? make_int2(pack_h2(lp2[u].x, lp2[u].y), pack_h2(rp2[u].x, rp2[u].y)) : pack_xy(lp2[u].x, lp2[u].y, rp2[u].x, rp2[u].y);
+        }
         WSYNC();
         GPH_K(7);                                                        // list load
         int n_surv;
@@ -960,6 +988,7 @@ hipError_t launch_debug_atan2_grid(int R, float* out, hipStream_t stream)
 //   part 0: sqrt_rn_int(n) vs sqrt_rn_pos(n), every integer n in [0, 2 * 2047^2]                      -> cnt[0] = mismatches
 //   part 1: texture "H != 0", every (n1, n2) in [0, 4802]^2                                            -> cnt[1..3] = pairs, inside the band, wrong outside it
 //   part 2: minutiae "H != 0", n1 over [0, 2 * 2047^2], n2 within +-12 of (sqrt n1 +- 30)^2            -> cnt[4..6]
+//   part 3: diff_n / pack_h2 / unpack_h2 on every coordinate difference of [-2047, 2047]^2                 -> cnt[7] = mismatches
 __device__ __forceinline__ void arith_check(bool tex, float f1, float f2, unsigned long long* cnt)
 {
     const float d = fabsf(sqrt_rn_pos(f1) - sqrt_rn_pos(f2));
@@ -976,6 +1005,13 @@ __global__ __launch_bounds__(256) void k_debug_graph_arith(int part, unsigned lo
     if (part == 0) {
         const unsigned n = blockIdx.x * 256u + threadIdx.x;
         if (n <= kMaxN && __float_as_uint(sqrt_rn_int((float)n)) != __float_as_uint(sqrt_rn_pos((float)n))) atomicAdd(cnt, 1ull);
+    } else if (part == 3) {                                               // diff_n on fp16-packed points vs the integer dx^2 + dy^2, every (dx, dy) of [-2047, 2047]^2
+        const int dx = (int)blockIdx.x - 2047, dy = (int)(blockIdx.y * 256u + threadIdx.x) - 2047;
+        if (dy > 2047) return;
+        const int ax = dx > 0 ? dx : 0, ox = dx > 0 ? 0 : -dx, ay = dy > 0 ? dy : 0, oy = dy > 0 ? 0 : -dy;
+        const float n = diff_n(pack_h2(ax, ay), pack_h2(ox, oy));
+        int bx, by; unpack_h2(pack_h2(ax, ay), bx, by);
+        if (__float_as_uint(n) != __float_as_uint((float)(dx * dx + dy * dy)) || bx != ax || by != ay) atomicAdd(cnt, 1ull);
     } else if (part == 1) {
         const unsigned n1 = blockIdx.x, n2 = blockIdx.y * 256u + threadIdx.x;
         if (n1 <= 4802u && n2 <= 4802u) arith_check(true, (float)n1, (float)n2, cnt + 1);
@@ -999,6 +1035,7 @@ hipError_t launch_debug_graph_arith(unsigned long long* cnt8, hipStream_t stream
     hipLaunchKernelGGL(k_debug_graph_arith, dim3((kMaxN + 256) / 256), dim3(256), 0, stream, 0, cnt8);
     hipLaunchKernelGGL(k_debug_graph_arith, dim3(4803, 19), dim3(256), 0, stream, 1, cnt8);
     hipLaunchKernelGGL(k_debug_graph_arith, dim3((kMaxN + 256) / 256), dim3(256), 0, stream, 2, cnt8);
+    hipLaunchKernelGGL(k_debug_graph_arith, dim3(4095, 16), dim3(256), 0, stream, 3, cnt8 + 7);
     return hipGetLastError();
 }
 

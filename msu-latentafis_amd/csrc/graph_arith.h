@@ -8,34 +8,39 @@ namespace afis {
 typedef short ga_v2s16 __attribute__((ext_vector_type(2)));
 typedef unsigned short ga_v2u16 __attribute__((ext_vector_type(2)));
 
-// n = dx^2 + dy^2 of the latent (n1) and of the rolled (n2) point pair from the packed (x | y << 16) words, as floats (exact
-// below 2^24).  v_dot2_i32_i16 with an inline 0 accumulator (the builtin selects the accumulate-in-place form and pays a v_mov per
-// call); a DOT result needs 3 wait states before a VALU reads it, which the compiler cannot know about inside an asm.
-__device__ __forceinline__ void pair_n(int2 a, int2 o, float& n1, float& n2)
+typedef _Float16 ga_v2h __attribute__((ext_vector_type(2)));
+
+// The packed paths keep a point as two half2 words (x, y as fp16: every integer of [0, 2047] is an fp16, and so is every difference of two).
+__device__ __forceinline__ int pack_h2(int x, int y) { const ga_v2h v = {(_Float16)(float)x, (_Float16)(float)y}; return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ void unpack_h2(int w, int& x, int& y) { const ga_v2h v = __builtin_bit_cast(ga_v2h, w); x = (int)(float)v.x; y = (int)(float)v.y; }
+
+// n = dx^2 + dy^2 of the latent (n1) and of the rolled (n2) point pair from the packed words, as floats: one v_pk_add_f16 (exact: the
+// differences are integers of [-2047, 2047]) and one v_dot2_f32_f16 per side (fp32 products and sum, exact below 2^24) — the fp32 value
+// arrives without the two v_cvt_f32_i32 the 16-bit integer form (v_pk_sub_i16 + v_dot2_i32_i16) needed.  Checked on the device against
+// the integer evaluation for every (dx, dy) of [-2047, 2047]^2 (afis_debug_graph_arith, part 3).
+__device__ __forceinline__ float diff_n(int a, int o)
 {
-    const ga_v2s16 dl = __builtin_bit_cast(ga_v2s16, a.x) - __builtin_bit_cast(ga_v2s16, o.x);
-    const ga_v2s16 dr = __builtin_bit_cast(ga_v2s16, a.y) - __builtin_bit_cast(ga_v2s16, o.y);
-    int i1, i2;
-    asm("v_dot2_i32_i16 %0, %2, %2, 0\n\tv_dot2_i32_i16 %1, %3, %3, 0\n\ts_nop 2" : "=&v"(i1), "=v"(i2) : "v"(dl), "v"(dr));
-    n1 = (float)i1; n2 = (float)i2;
+    const ga_v2h d = __builtin_bit_cast(ga_v2h, a) - __builtin_bit_cast(ga_v2h, o);
+    return __builtin_amdgcn_fdot2(d, d, 0.0f, false);
 }
-// |d| < 50 for all four coordinate differences (matcher.cpp:1257)  <=>  (d + 49) as u16 <= 98
+__device__ __forceinline__ void pair_n(int2 a, int2 o, float& n1, float& n2) { n1 = diff_n(a.x, o.x); n2 = diff_n(a.y, o.y); }
+// |d| < 50 for all four coordinate differences (matcher.cpp:1257); only lists with a block coordinate outside [0, 49] ask (never a real template)
 __device__ __forceinline__ bool tex_in_range(int2 a, int2 o)
 {
-    const ga_v2s16 dl = __builtin_bit_cast(ga_v2s16, a.x) - __builtin_bit_cast(ga_v2s16, o.x);
-    const ga_v2s16 dr = __builtin_bit_cast(ga_v2s16, a.y) - __builtin_bit_cast(ga_v2s16, o.y);
-    const ga_v2u16 bias = {49, 49};
-    const ga_v2u16 tl = __builtin_bit_cast(ga_v2u16, dl) + bias, tr = __builtin_bit_cast(ga_v2u16, dr) + bias;
-    const ga_v2u16 mx = __builtin_elementwise_max(tl, tr);
-    return max((unsigned)mx.x, (unsigned)mx.y) <= 98u;
+    const ga_v2h dl = __builtin_bit_cast(ga_v2h, a.x) - __builtin_bit_cast(ga_v2h, o.x);
+    const ga_v2h dr = __builtin_bit_cast(ga_v2h, a.y) - __builtin_bit_cast(ga_v2h, o.y);
+    const float m = fmaxf(fmaxf(fabsf((float)dl.x), fabsf((float)dl.y)), fmaxf(fabsf((float)dr.x), fabsf((float)dr.y)));
+    return m < 50.0f;
 }
 
 // RN(sqrt(x)) for an INTEGER-valued x in [0, 2 * 2047^2] (the packed paths' dx^2 + dy^2): v_rsq_f32 (1 ulp) and one fma
 // correction step.  Equal to sqrt_rn_pos for every such integer (exhaustive check).  x = 0: rsq = inf, clamped to 1 (rsq <= 1 for
-// x >= 1 anyway), and the chain gives 0.  One transcendental + 5 instructions; sqrt_rn_pos: one + 9.
+// x >= 1 anyway), and the chain gives 0.  One transcendental + 4 instructions; sqrt_rn_pos: one + 9.
 __device__ __forceinline__ float sqrt_rn_int(float x)
 {
-    const float y = fminf(__builtin_amdgcn_rsqf(x), 1.0f);
+    // min(rsq, 1) written as clamp(rsq, 0, 1) (rsq >= 0): the compiler folds it into the instruction's own clamp bit — one issue slot less than v_min_f32.
+    // (Not an asm: x comes out of a DOT instruction, whose wait states before a VALU read the compiler only inserts for instructions it can see.)
+    const float y = __builtin_fminf(__builtin_fmaxf(__builtin_amdgcn_rsqf(x), 0.0f), 1.0f);
     const float r0 = x * y;
     const float e = __builtin_fmaf(-r0, r0, x);
     return __builtin_fmaf(e, 0.5f * y, r0);
