@@ -460,7 +460,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     // Rows differ in their number of non-zeros, and a wave pays for the longest row of every pass.  So the rows are dealt to the
     // lanes in descending order of their non-zero count (16 buckets of 4, counting sort with ballots): the rows of one pass
     // then have nearly equal lengths.  Rows are independent, so the row -> lane assignment does not touch any result.
-    int myrow[U], trip[U];
+    int myrow[U], trip[U], rlen[U];
     const int Wn = (num + 31) / 32;
     {
         int cnt[U];
@@ -490,7 +490,8 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
         for (int u = 0; u < U; ++u) {
             const int p = lane + 64 * u;
             myrow[u] = p < num ? (int)sm.y.os.order[p] : -1;
-            trip[u] = g_wave_max(myrow[u] >= 0 ? (int)sm.y.os.sel[myrow[u]] : 0);        // longest row of this pass: the pass's trip count
+            rlen[u] = myrow[u] >= 0 ? (int)sm.y.os.sel[myrow[u]] : 0;
+            trip[u] = g_wave_max(rlen[u]);                                               // longest row of this pass: the pass's trip count
         }
         WSYNC();
         for (int t = num + lane; t < SM::N4; t += 64) sm.y.cc[t] = 0.0f;   // sel[] may have run over cc's zero padding (seq_sum reads it)
@@ -506,6 +507,11 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     // balanced by TOTAL count, their bits fall into different words).  Minutiae lists (4 denser words, everything stashed) are faster
     // with the plain word-by-word walk (measured: +4.5 % with the cursor loop), so they keep it.
     constexpr bool kFlat = NMAX > 128;
+    constexpr int kIdxN = kFlat ? (CACHE * 4) : 1;                            // neighbour indices per row in the stash space (texture lists)
+    unsigned char* const idx8 = reinterpret_cast<unsigned char*>(sm.x.stash);
+    [[maybe_unused]] int cur_w[U]; [[maybe_unused]] uint32_t cur_bits[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cur_w[u] = 0; cur_bits[u] = 0u; }
     auto value = [&](int2 own, int k) -> float {
         float dist;
         if (fast) dist = dist_fast(own, sm.xy[k]);
@@ -519,19 +525,47 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
             const uint32_t* hrow = sm.hb[t >= 0 ? t : 0];
             float acc = 0.0f;
             if (kFlat) {
-                int w = 0;
-                uint32_t bits = t >= 0 ? hrow[0] : 0u;
-                for (int n = 0; n < trip[u]; ++n) {                          // uniform
-                    while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }   // next non-empty word of this lane's row
-                    if (bits) {
-                        const int k = w * 32 + __ffs(bits) - 1;
-                        bits &= bits - 1;
-                        float h;
-                        if (it == 0 || n >= CACHE) h = value(mine[u], k);     // uniform condition
-                        else h = sm.x.stash[n * NMAX + t];
-                        if (it == 0 && n < CACHE) sm.x.stash[n * NMAX + t] = h;
-                        const float p = h * sm.b[k];
-                        acc += p;
+                // Iteration 0 walks the row's bit mask, computes every value and notes the first kIdxN neighbour indices of the row as bytes
+                // (idx[n][row], in the space a value stash would take: 16 indices instead of 4 values per row).  Iterations 1.. read the n-th
+                // neighbour from there — a byte load instead of the bit walk with its divergent "next non-empty word" loop — and recompute
+                // the value (20 instructions since the fp16 form); only rows longer than kIdxN go on with the bit walk, from the cursor
+                // (word, remaining bits) iteration 0 left at position kIdxN.
+                if (it == 0) {
+                    int w = 0;
+                    uint32_t bits = t >= 0 ? hrow[0] : 0u;
+                    for (int n = 0; n < trip[u]; ++n) {                      // uniform
+                        if (n == kIdxN) { cur_w[u] = w; cur_bits[u] = bits; }   // uniform condition
+                        while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }   // next non-empty word of this lane's row
+                        if (bits) {
+                            const int k = w * 32 + __ffs(bits) - 1;
+                            bits &= bits - 1;
+                            if (n < kIdxN) idx8[n * NMAX + t] = (unsigned char)k;
+                            const float p = value(mine[u], k) * sm.b[k];
+                            acc += p;
+                        }
+                    }
+                } else {
+                    const int nA = min(trip[u], kIdxN);
+                    const unsigned char* ip = idx8 + (t >= 0 ? t : 0);
+                    for (int n = 0; n < nA; ++n) {                           // uniform
+                        if (n < rlen[u]) {
+                            const int k = ip[n * NMAX];
+                            const float p = value(mine[u], k) * sm.b[k];
+                            acc += p;
+                        }
+                    }
+                    if (trip[u] > kIdxN) {
+                        int w = cur_w[u];
+                        uint32_t bits = cur_bits[u];
+                        for (int n = kIdxN; n < trip[u]; ++n) {
+                            while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }
+                            if (bits) {
+                                const int k = w * 32 + __ffs(bits) - 1;
+                                bits &= bits - 1;
+                                const float p = value(mine[u], k) * sm.b[k];
+                                acc += p;
+                            }
+                        }
                     }
                 }
             } else if (t >= 0) {
