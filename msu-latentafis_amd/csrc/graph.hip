@@ -370,7 +370,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     constexpr bool range_test = MODE == 1;
     auto compat_fast = [](int2 a, int2 o) -> bool { if (LOOKUP) return tex_pair_compatible<range_test>(a, o); return minu_pair_compatible(a, o); };
     auto dist_fast = [](int2 a, int2 o) -> float { float d; if (LOOKUP) { tex_pair_dist<range_test>(a, o, d); return d; } return minu_pair_dist(a, o); };
-    constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX, CACHE = SM::CACHE;
+    constexpr int U = SM::U, W = SM::W, NMAX = SM::NMAX;
     [[maybe_unused]] constexpr int PH = LOOKUP ? 8 : 0;
     GPH_INIT();
     const int lane = threadIdx.x;
@@ -399,16 +399,23 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     const int tail0 = num & ~63, R = num - tail0;
     const bool grouped = R > 0 && R <= 32;
     const int n_wide = grouped ? tail0 : num;                             // rows handled one per lane and block
-    int kk[U];                                                            // t + d (mod num), kept incrementally: add, compare, select
+    // t + d (mod num), kept incrementally as the BYTE offset of the partner point in xy[]: add, subtract, unsigned minimum (the difference
+    // wraps to a huge number until the offset reaches the end, where it is 0) — two full-rate instructions and a minimum instead of
+    // compare, select and the shift of the address (profiles/r03_valu_cost_table.json: shifts left, compares and selects cost twice an add)
+    uint32_t kb[U];
+    const uint32_t num8 = (uint32_t)num * 8u;
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; kk[u] = t < num ? t : 0; }
+    for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; kb[u] = t < num ? (uint32_t)t * 8u : 0u; }
     for (int d = 1; n_wide > 0 && d <= half; ++d) {
         const bool last = d == half && even;                              // even num: the antipodal pairs belong to the lower half
         int2 other[U];                                                    // the U partner points are fetched together: one LDS round trip per d, not U
+        int kk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            int k = kk[u] + 1; k = k == num ? 0 : k; kk[u] = k;
-            other[u] = sm.xy[k];
+            const uint32_t a = kb[u] + 8u;
+            kb[u] = min(a, a - num8);
+            other[u] = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(sm.xy) + kb[u]);
+            kk[u] = (int)(kb[u] >> 3);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (fast) {
@@ -499,17 +506,24 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     int2 mine[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) mine[u] = myrow[u] >= 0 ? sm.xy[myrow[u]] : make_int2(0, 0);
-    // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle).  Iteration 0 computes every
-    // value and stashes the first CACHE of each row; later iterations read those back and recompute only the rest.
-    // Texture lists (7 mask words per row, most values recomputed): every lane walks the non-zeros of ITS row with a (word, remaining
-    // bits) cursor inside ONE loop whose trip count is the longest row of the pass: the n-th step handles the n-th non-zero of every row, so "stashed or recomputed" is a uniform decision and the
-    // wave pays max-row-length steps — not the sum over the bit-mask words of the per-word maxima, which is 2-3 x more (the rows are
-    // balanced by TOTAL count, their bits fall into different words).  Minutiae lists (4 denser words, everything stashed) are faster
-    // with the plain word-by-word walk (measured: +4.5 % with the cursor loop), so they keep it.
+    // power iteration, :1284-1289 / :1406-1411 (canonical order: k ascending, unfused; see oracle).
+    // Iteration 0 walks each row's bit mask (every lane ITS row, a (word, remaining bits) cursor inside ONE loop whose trip count is the longest
+    // row of the pass), computes every value and notes, per row, the first kIdxN neighbour indices as bytes and the first kValN values
+    // (idx8[n][row], vst[n][row]: together they fill the stash space).  Iterations 1.. read the n-th neighbour from there — a byte load instead of
+    // the bit walk with its divergent "next non-empty word" loop — take the value from the stash (n < kValN) or recompute it (20 instructions
+    // in the fp16 form); only rows longer than kIdxN go on with the bit walk, from the cursor iteration 0 left at position kIdxN.
+    // Texture lists (200 rows, 17 neighbours on average, 3200 B): 16 indices and no values.  Minutiae lists (120 rows, 10 on average, 2880 B): 24 indices
+    // and no values either — 6 values + 16 indices in 4800 B were 2 % faster at equal occupancy, but the smaller footprint admits a fifth list per SIMD (-4.5 %).
+    // (Before the index lists: 4 and 10 values per row; the walk cost as much as a value.)
     constexpr bool kFlat = NMAX > 128;
-    constexpr int kIdxN = kFlat ? (CACHE * 4) : 1;                            // neighbour indices per row in the stash space (texture lists)
-    unsigned char* const idx8 = reinterpret_cast<unsigned char*>(sm.x.stash);
-    [[maybe_unused]] int cur_w[U]; [[maybe_unused]] uint32_t cur_bits[U];
+#ifndef AFIS_MINU_VALN
+#define AFIS_MINU_VALN 0
+#endif
+    constexpr int kValN = kFlat ? 0 : AFIS_MINU_VALN, kIdxN = 4 * SM::CACHE - 4 * kValN;   // 4 kValN + kIdxN bytes per row = the stash space (CACHE floats per row)
+    static_assert(kValN * NMAX * 4 + kIdxN * NMAX <= (int)sizeof(sm.x.stash), "index lists + value stash exceed the stash space");
+    float* const vst = sm.x.stash;
+    unsigned char* const idx8 = reinterpret_cast<unsigned char*>(sm.x.stash + kValN * NMAX);
+    int cur_w[U]; uint32_t cur_bits[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { cur_w[u] = 0; cur_bits[u] = 0u; }
     auto value = [&](int2 own, int k) -> float {
@@ -524,73 +538,45 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
             const int t = myrow[u];
             const uint32_t* hrow = sm.hb[t >= 0 ? t : 0];
             float acc = 0.0f;
-            if (kFlat) {
-                // Iteration 0 walks the row's bit mask, computes every value and notes the first kIdxN neighbour indices of the row as bytes
-                // (idx[n][row], in the space a value stash would take: 16 indices instead of 4 values per row).  Iterations 1.. read the n-th
-                // neighbour from there — a byte load instead of the bit walk with its divergent "next non-empty word" loop — and recompute
-                // the value (20 instructions since the fp16 form); only rows longer than kIdxN go on with the bit walk, from the cursor
-                // (word, remaining bits) iteration 0 left at position kIdxN.
-                if (it == 0) {
-                    int w = 0;
-                    uint32_t bits = t >= 0 ? hrow[0] : 0u;
-                    for (int n = 0; n < trip[u]; ++n) {                      // uniform
-                        if (n == kIdxN) { cur_w[u] = w; cur_bits[u] = bits; }   // uniform condition
-                        while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }   // next non-empty word of this lane's row
-                        if (bits) {
-                            const int k = w * 32 + __ffs(bits) - 1;
-                            bits &= bits - 1;
-                            if (n < kIdxN) idx8[n * NMAX + t] = (unsigned char)k;
-                            const float p = value(mine[u], k) * sm.b[k];
-                            acc += p;
-                        }
-                    }
-                } else {
-                    const int nA = min(trip[u], kIdxN);
-                    const unsigned char* ip = idx8 + (t >= 0 ? t : 0);
-                    for (int n = 0; n < nA; ++n) {                           // uniform
-                        if (n < rlen[u]) {
-                            const int k = ip[n * NMAX];
-                            const float p = value(mine[u], k) * sm.b[k];
-                            acc += p;
-                        }
-                    }
-                    if (trip[u] > kIdxN) {
-                        int w = cur_w[u];
-                        uint32_t bits = cur_bits[u];
-                        for (int n = kIdxN; n < trip[u]; ++n) {
-                            while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }
-                            if (bits) {
-                                const int k = w * 32 + __ffs(bits) - 1;
-                                bits &= bits - 1;
-                                const float p = value(mine[u], k) * sm.b[k];
-                                acc += p;
-                            }
-                        }
+            if (it == 0) {
+                int w = 0;
+                uint32_t bits = t >= 0 ? hrow[0] : 0u;
+                for (int n = 0; n < trip[u]; ++n) {                          // uniform
+                    if (n == kIdxN) { cur_w[u] = w; cur_bits[u] = bits; }    // uniform condition
+                    while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }   // next non-empty word of this lane's row
+                    if (bits) {
+                        const int k = w * 32 + __ffs(bits) - 1;
+                        bits &= bits - 1;
+                        const float h = value(mine[u], k);
+                        if (n < kIdxN) idx8[n * NMAX + t] = (unsigned char)k;
+                        if (n < kValN) vst[n * NMAX + t] = h;
+                        const float p = h * sm.b[k];
+                        acc += p;
                     }
                 }
-            } else if (t >= 0) {
-                int n = 0;
-                for (int w = 0; w < Wn; ++w) {
-                    uint32_t bits = hrow[w];
-                    if (it == 0) {
-                        while (bits) {
-                            const int k = w * 32 + __ffs(bits) - 1;
-                            bits &= bits - 1;
-                            const float h = value(mine[u], k);
-                            if (n < CACHE) sm.x.stash[n * NMAX + t] = h;
-                            const float p = h * sm.b[k];
-                            acc += p;
-                            ++n;
-                        }
-                    } else {
-                        while (bits && n < CACHE) {                      // stashed values
-                            const int k = w * 32 + __ffs(bits) - 1;
-                            bits &= bits - 1;
-                            const float p = sm.x.stash[n * NMAX + t] * sm.b[k];
-                            acc += p;
-                            ++n;
-                        }
-                        while (bits) {                                   // beyond the stash: recomputed
+            } else {
+                const int nV = min(trip[u], kValN), nA = min(trip[u], kIdxN);
+                const int tt = t >= 0 ? t : 0;
+                for (int n = 0; n < nV; ++n) {                               // uniform
+                    if (n < rlen[u]) {
+                        const int k = idx8[n * NMAX + tt];
+                        const float p = vst[n * NMAX + tt] * sm.b[k];
+                        acc += p;
+                    }
+                }
+                for (int n = nV; n < nA; ++n) {
+                    if (n < rlen[u]) {
+                        const int k = idx8[n * NMAX + tt];
+                        const float p = value(mine[u], k) * sm.b[k];
+                        acc += p;
+                    }
+                }
+                if (trip[u] > kIdxN) {
+                    int w = cur_w[u];
+                    uint32_t bits = cur_bits[u];
+                    for (int n = kIdxN; n < trip[u]; ++n) {
+                        while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }
+                        if (bits) {
                             const int k = w * 32 + __ffs(bits) - 1;
                             bits &= bits - 1;
                             const float p = value(mine[u], k) * sm.b[k];
@@ -926,12 +912,17 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // minutiae lists (produced by k_minu_cands, already in rank order): S8a + S9
 // =====================================================================================================================
 #ifndef AFIS_MINU_CACHE
-#define AFIS_MINU_CACHE 10
+#define AFIS_MINU_CACHE 6
 #endif
 typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE, true> MinuGraphSmem;
 
 // corr_out / corr_n (optional): the surviving correspondences of every task as (lx, ly, rx, ry), matcher.cpp:497-505
-__global__ __launch_bounds__(64) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
+// Five lists per SIMD: 7680 B of LDS (24 neighbour indices per row, no value stash: recomputing a value costs 20 instructions, the stash cost a wave per SIMD)
+// and <= 96 registers.  Measured at 100k templates (minutiae stage): 4 waves with 6 values + 16 indices per row 93.7 ms, 5 waves 89.5 ms, 6 waves (16 indices) 90.3 ms.
+#ifndef AFIS_MINU_WAVES
+#define AFIS_MINU_WAVES 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_MINU_WAVES, AFIS_MINU_WAVES))) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
                                                        const int32_t* __restrict__ cand_n, float* __restrict__ parts,
                                                        short4* __restrict__ corr_out, int32_t* __restrict__ corr_n, GraphTap tap)
 {

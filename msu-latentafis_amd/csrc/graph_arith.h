@@ -23,7 +23,14 @@ __device__ __forceinline__ float diff_n(int a, int o)
     const ga_v2h d = __builtin_bit_cast(ga_v2h, a) - __builtin_bit_cast(ga_v2h, o);
     return __builtin_amdgcn_fdot2(d, d, 0.0f, false);
 }
-__device__ __forceinline__ void pair_n(int2 a, int2 o, float& n1, float& n2) { n1 = diff_n(a.x, o.x); n2 = diff_n(a.y, o.y); }
+// Both sides of a pair.  The three-operand form with an inline 0 accumulator: the builtin selects the accumulate-in-place v_dot2c and pays a
+// v_mov 0 per call.  A DOT result needs wait states before a VALU reads it, which the compiler cannot know about for an asm's outputs: s_nop 2.
+__device__ __forceinline__ void pair_n(int2 a, int2 o, float& n1, float& n2)
+{
+    const ga_v2h dl = __builtin_bit_cast(ga_v2h, a.x) - __builtin_bit_cast(ga_v2h, o.x);
+    const ga_v2h dr = __builtin_bit_cast(ga_v2h, a.y) - __builtin_bit_cast(ga_v2h, o.y);
+    asm("v_dot2_f32_f16 %0, %2, %2, 0\n\tv_dot2_f32_f16 %1, %3, %3, 0\n\ts_nop 2" : "=&v"(n1), "=v"(n2) : "v"(dl), "v"(dr));
+}
 // |d| < 50 for all four coordinate differences (matcher.cpp:1257); only lists with a block coordinate outside [0, 49] ask (never a real template)
 __device__ __forceinline__ bool tex_in_range(int2 a, int2 o)
 {

@@ -50,8 +50,22 @@
     X(40, "v_cndmask_b32 vcc, src0 = 0 (VOP2 e32)", "v_cndmask_b32 %0, 0, %0, vcc") \
     X(41, "v_cmp_ne_u32 vcc + v_cndmask_b32 vcc (pair)", "v_cmp_ne_u32 vcc, %0, %8\n v_cndmask_b32 %0, 0, %0, vcc") \
     X(42, "v_cmp_ne_u32 sgpr + v_cndmask_b32_e64 sgpr (pair)", "v_cmp_ne_u32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %0, 0, %0, s[20:21]") \
-    X(43, "v_sub_u32 + v_min_u32 (pair: wrap without a select)", "v_sub_u32 %1, %0, %8\n v_min_u32 %0, %0, %1")
-constexpr int NK = 44;
+    X(43, "v_sub_u32 + v_min_u32 (pair: wrap without a select)", "v_sub_u32 %1, %0, %8\n v_min_u32 %0, %0, %1") \
+    X(44, "v_dot2c_f32_f16 (VOP2)", "v_dot2c_f32_f16 %0, %8, %9") \
+    X(45, "v_dot2_f32_f16 (VOP3P)", "v_dot2_f32_f16 %0, %8, %9, 0") \
+    X(46, "v_pk_add_f16 (VOP3P)", "v_pk_add_f16 %0, %0, %8") \
+    X(47, "v_fma_f32 (VOP3)", "v_fma_f32 %0, %0, %8, %9") \
+    X(48, "v_fmaak_f32 (VOP2 + literal)", "v_fmaak_f32 %0, %0, %8, 0x3f000000") \
+    X(49, "v_mul_f32 with abs modifier (VOP3)", "v_mul_f32_e64 %0, %0, |%8|") \
+    X(50, "v_xor_b32 (VOP2)", "v_xor_b32 %0, %0, %8") \
+    X(51, "v_sqrt_f32 (VOP1, transcendental)", "v_sqrt_f32 %0, %0") \
+    X(52, "v_cmp_gt_f32 -> sgpr pair (VOP3)", "v_cmp_gt_f32_e64 s[20:21], %0, %8") \
+    X(53, "v_bfi_b32 (VOP3)", "v_bfi_b32 %0, %8, %0, %9") \
+    X(54, "v_add3_u32 (VOP3)", "v_add3_u32 %0, %0, %8, %9") \
+    X(55, "v_lshrrev_b32 (VOP2)", "v_lshrrev_b32 %0, 1, %0") \
+    X(56, "v_add_u32 with literal (VOP2 + literal)", "v_add_u32 %0, 0x12345, %0") \
+    X(57, "v_readfirstlane_b32 (VOP1 -> SGPR)", "v_readfirstlane_b32 s22, %0")
+constexpr int NK = 58;
 #define NAME(i, n, a) n,
 static const char* kNames[NK] = {LIST(NAME)};
 template <int KIND>
@@ -64,7 +78,7 @@ __global__ void k(unsigned* out, unsigned long long* cyc, int iters)
     asm volatile("s_mov_b32 s20, 0x55555555\n s_mov_b32 s21, 0x55555555\n s_mov_b32 vcc_lo, 0x33333333\n s_mov_b32 vcc_hi, 0x33333333" ::: "s20", "s21", "vcc");
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
-#define ONE(r, tmpl) asm volatile(tmpl : "+v"(a[r]) , "+v"(a[(r + 1) & 7]), "+v"(a[(r + 2) & 7]), "+v"(a[(r + 3) & 7]), "+v"(a[(r + 4) & 7]), "+v"(a[(r + 5) & 7]), "+v"(a[(r + 6) & 7]), "+v"(a[(r + 7) & 7]) : "v"(b), "v"(c), "v"(w0), "v"(w1) : "vcc", "s20", "s21");
+#define ONE(r, tmpl) asm volatile(tmpl : "+v"(a[r]) , "+v"(a[(r + 1) & 7]), "+v"(a[(r + 2) & 7]), "+v"(a[(r + 3) & 7]), "+v"(a[(r + 4) & 7]), "+v"(a[(r + 5) & 7]), "+v"(a[(r + 6) & 7]), "+v"(a[(r + 7) & 7]) : "v"(b), "v"(c), "v"(w0), "v"(w1) : "vcc", "s20", "s21", "s22");
 #define BODY(i, n, tmpl) if (KIND == i) { ONE(0, tmpl) ONE(1, tmpl) ONE(2, tmpl) ONE(3, tmpl) ONE(4, tmpl) ONE(5, tmpl) ONE(6, tmpl) ONE(7, tmpl) }
         LIST(BODY)
     }
