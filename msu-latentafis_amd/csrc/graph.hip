@@ -23,6 +23,7 @@
 //   * H (200x200 fp32 = 160 KB)        -> never stored: LDS keeps the bitmask of its non-zero entries, values are recomputed on
 //                                        demand and cached per row; a zero entry would only add +0.0f, so skipping it is exact.
 #include "afis_device.h"
+#include <type_traits>
 #include "atan2f_libm.h"
 #include "graph_arith.h"
 
@@ -406,50 +407,76 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     const uint32_t num8 = (uint32_t)num * 8u;
 #pragma unroll
     for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; kb[u] = t < num ? (uint32_t)t * 8u : 0u; }
-    for (int d = 1; n_wide > 0 && d <= half; ++d) {
-        const bool last = d == half && even;                              // even num: the antipodal pairs belong to the lower half
-        int2 other[U];                                                    // the U partner points are fetched together: one LDS round trip per d, not U
-        int kk[U];
+#ifndef AFIS_PAIR_UNROLL
+#define AFIS_PAIR_UNROLL 1
+#endif
+    constexpr int DU = fast ? AFIS_PAIR_UNROLL : 1;                       // offsets d handled per trip of the loop: DU x U independent chains per lane
+    // UA = row blocks that hold one-per-lane rows (a texture list of 200 rows: 3 — its 8-row fourth block is taken by the lane groups below —
+    // so a fourth chain would compute on nothing for the whole loop)
+    auto pair_loop = [&](auto ua_tag) {
+    constexpr int UA = decltype(ua_tag)::value;
+    for (int d = 1; d <= half; d += DU) {
+        int2 other[DU][UA];                                                // the partner points are fetched together: one LDS round trip per trip
+        int kk[DU][UA];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t a = kb[u] + 8u;
-            kb[u] = min(a, a - num8);
-            other[u] = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(sm.xy) + kb[u]);
-            kk[u] = (int)(kb[u] >> 3);
+        for (int s2 = 0; s2 < DU; ++s2) {
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const uint32_t a = kb[u] + 8u;
+                kb[u] = min(a, a - num8);
+                other[s2][u] = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(sm.xy) + kb[u]);
+                kk[s2][u] = (int)(kb[u] >> 3);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (fast) {
-            // the U predicates are evaluated without control flow between them (rows beyond the list compute on zeros), so their
+            // the predicates are evaluated without control flow between them (rows beyond the list compute on zeros), so their
             // instruction chains interleave; the rare band case of any of them is one uniform branch for all
-            float n1[U], n2[U]; bool hit[U], near[U]; bool any_near = false;
+            float n1[DU][UA], n2[DU][UA]; bool hit[DU][UA], near[DU][UA]; bool any_near = false;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                pair_n(me[u], other[u], n1[u], n2[u]);
-                hit[u] = pair_compatible_t<LOOKUP>(n1[u], n2[u], near[u]);
-                any_near |= near[u];
+            for (int s2 = 0; s2 < DU; ++s2) {
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    pair_n(me[u], other[s2][u], n1[s2][u], n2[s2][u]);
+                    hit[s2][u] = pair_compatible_t<LOOKUP>(n1[s2][u], n2[s2][u], near[s2][u]);
+                    any_near |= near[s2][u];
+                }
             }
             if (__builtin_amdgcn_ballot_w64(any_near) != 0ull) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) if (near[u]) hit[u] = pair_compatible_exact<LOOKUP>(n1[u], n2[u]);
+                for (int s2 = 0; s2 < DU; ++s2) {
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) if (near[s2][u]) hit[s2][u] = pair_compatible_exact<LOOKUP>(n1[s2][u], n2[s2][u]);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = lane + 64 * u, k = kk[u];
-                bool ok = hit[u] && t < n_wide && !(last && t >= half);
-                if (LOOKUP && range_test) ok = ok && tex_in_range(me[u], other[u]);
-                if (ok) {
-                    atomicOr(hb0 + (t * W + (k >> 5)), 1u << (k & 31));
-                    atomicOr(hb0 + (__umul24(k, W) + (t >> 5)), 1u << (t & 31));
+            for (int s2 = 0; s2 < DU; ++s2) {
+                const bool last = d + s2 == half && even;                 // even num: the antipodal pairs belong to the lower half
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    const int t = lane + 64 * u, k = kk[s2][u];
+                    bool ok = hit[s2][u] && t < n_wide && d + s2 <= half && !(last && t >= half);
+                    if (LOOKUP && range_test) ok = ok && tex_in_range(me[u], other[s2][u]);
+                    if (ok) {
+                        atomicOr(hb0 + (t * W + (k >> 5)), 1u << (k & 31));
+                        atomicOr(hb0 + (__umul24(k, W) + (t >> 5)), 1u << (t & 31));
+                    }
                 }
             }
         } else {
+            const bool last = d == half && even;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UA; ++u) {
                 const int t = lane + 64 * u;
-                if (t < n_wide && !(last && t >= half)) pair(me[u], t, kk[u], other[u]);
+                if (t < n_wide && !(last && t >= half)) pair(me[u], t, kk[0][u], other[0][u]);
             }
         }
     }
+    };
+    const int n_blk = (n_wide + 63) >> 6;
+    if (n_blk >= U) pair_loop(std::integral_constant<int, U>{});
+    else if (U > 1 && n_blk == U - 1) pair_loop(std::integral_constant<int, (U > 1 ? U - 1 : 1)>{});
+    else if (n_blk > 0) pair_loop(std::integral_constant<int, U>{});
     if (grouped) {
         const int sh = R <= 8 ? 3 : R <= 16 ? 4 : 5, RG = 1 << sh, dstep = 64 >> sh;
         const int r = lane & (RG - 1), t = tail0 + r;

@@ -9,7 +9,7 @@ cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stri
 args = sys.argv[1:]
 G = int(args.pop(0)) if args and args[0].isdigit() else 20000
 Q = int(args.pop(0)) if args and args[0].isdigit() else 8
-lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb); S.plant_mates(1, gal, cb, lats)
+lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb, n_minu_mean=float(os.environ.get("AFIS_AB_MINU_MEAN", "80"))); S.plant_mates(1, gal, cb, lats)
 paths = [M.LIB_PATH] + sorted(args)
 ms = []
 for path in paths:
