@@ -97,10 +97,14 @@ __device__ __forceinline__ Pt unpack_xy(int2 v) { Pt p; p.lx = (int)(short)v.x; 
 template <int N, bool OWN> struct SimStore { float simv[N]; };
 template <int N> struct SimStore<N, false> {};
 
+#ifndef AFIS_MINU_ALIAS
+#define AFIS_MINU_ALIAS 1
+#endif
 template <int NMAX_, int CACHE_, bool OWN_SIM_>
 struct __attribute__((aligned(16))) WaveSmem : SimStore<NMAX_, OWN_SIM_> {
     static constexpr int NMAX = NMAX_, CACHE = CACHE_;
     static constexpr bool OWN_SIM = OWN_SIM_;
+    static constexpr bool ALIAS_ORI = NMAX_ > 128 || AFIS_MINU_ALIAS;   // texture lists: LDS is what limits the lists per CU, the angle stage's orientations live in b[] / cc[] while H is built
     static constexpr int W = (NMAX + 31) / 32;
     static constexpr int N4 = (NMAX + 3) / 4 * 4;
     static constexpr int U = (NMAX + 63) / 64;
@@ -115,8 +119,8 @@ struct __attribute__((aligned(16))) WaveSmem : SimStore<NMAX_, OWN_SIM_> {
     // LDS is what limits how many lists a CU works on at once, so buffers with disjoint lifetimes share storage:
     union {
         float stash[CACHE * NMAX];                                                  // power iterations: [n][t] = value of the n-th non-zero of row t
-        struct { u64 keys[N4]; float lo[NMAX], ro[NMAX]; } s;                       // sorts (after the iterations); orientations (angle stage only)
-        struct { u64 keys[N4]; short te[NMAX], targ[NMAX]; } pick;               // texture rows picked by S7, before they are ranked
+        struct { u64 keys[N4]; float lo[ALIAS_ORI ? 1 : NMAX], ro[ALIAS_ORI ? 1 : NMAX]; } s;   // sorts (after the iterations); orientations (angle stage, unless they borrow b / cc)
+        struct { uint32_t keys[N4]; short te[NMAX], targ[NMAX]; } pick;          // texture rows picked by S7, before they are ranked (32-bit keys)
     } x;
 #ifdef AFIS_PHASE_TIMING
     u64 ph[16];
@@ -539,8 +543,8 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     // (idx8[n][row], vst[n][row]: together they fill the stash space).  Iterations 1.. read the n-th neighbour from there — a byte load instead of
     // the bit walk with its divergent "next non-empty word" loop — take the value from the stash (n < kValN) or recompute it (20 instructions
     // in the fp16 form); only rows longer than kIdxN go on with the bit walk, from the cursor iteration 0 left at position kIdxN.
-    // Texture lists (200 rows, 17 neighbours on average, 3200 B): 16 indices and no values.  Minutiae lists (120 rows, 10 on average, 2880 B): 24 indices
-    // and no values either — 6 values + 16 indices in 4800 B were 2 % faster at equal occupancy, but the smaller footprint admits a fifth list per SIMD (-4.5 %).
+    // Texture lists (200 rows, 17 neighbours on average): 8 indices per row, minutiae lists (120 rows, 10 on average): 12, and no values — values + indices
+    // were 2-4 % faster at equal occupancy, but LDS decides how many lists a SIMD holds, and two more texture lists per CU / two more minutiae lists per SIMD are worth more.
     // (Before the index lists: 4 and 10 values per row; the walk cost as much as a value.)
     constexpr bool kFlat = NMAX > 128;
 #ifndef AFIS_MINU_VALN
@@ -684,10 +688,16 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
     [[maybe_unused]] constexpr int PH = SM::NMAX > 128 ? 8 : 0;
     GPH_INIT();
     const int lane = threadIdx.x;
-    for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
-    for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
-    const float s0 = (float)(1.0 / num);                                   // :1558
-    for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.y.cc[t] = 0.0f; }
+    // texture lists: the orientations are needed while the boolean H is built, b[] and cc[] only by the iterations after it: they share the storage
+    if constexpr (SM::ALIAS_ORI) {
+        for (int t = lane; t < num; t += 64) { sm.b[t] = lori[sm.li[t]]; sm.y.cc[t] = rori[sm.ri[t]]; }
+        for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
+    } else {
+        for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
+        for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
+        const float s0 = (float)(1.0 / num);                                   // :1558
+        for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.y.cc[t] = 0.0f; }
+    }
     WSYNC();
     // row t visits the pairs (t, t+d mod num), d = 1..num/2: every unordered pair once, evaluated as (lower, higher) index.
     // Survivor lists are short (usually < 32): the lanes of a partial block of <= 32 rows are split into groups that take different
@@ -696,7 +706,10 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
     const bool even = !(num & 1);
     auto pair = [&](int t, int k) {
         const int i = t < k ? t : k, j = t < k ? k : t;
-        if (angle_compatible(unpack_xy(sm.xy[i]), sm.x.s.lo[i], sm.x.s.ro[i], unpack_xy(sm.xy[j]), sm.x.s.lo[j], sm.x.s.ro[j])) {
+        bool ok;
+        if constexpr (SM::ALIAS_ORI) ok = angle_compatible(unpack_xy(sm.xy[i]), sm.b[i], sm.y.cc[i], unpack_xy(sm.xy[j]), sm.b[j], sm.y.cc[j]);
+        else ok = angle_compatible(unpack_xy(sm.xy[i]), sm.x.s.lo[i], sm.x.s.ro[i], unpack_xy(sm.xy[j]), sm.x.s.lo[j], sm.x.s.ro[j]);
+        if (ok) {
             atomicOr(&sm.hb[i][j >> 5], 1u << (j & 31));
             atomicOr(&sm.hb[j][i >> 5], 1u << (i & 31));
         }
@@ -722,6 +735,11 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
         }
     }
     WSYNC();
+    if constexpr (SM::ALIAS_ORI) {
+        const float s0 = (float)(1.0 / num);                               // :1558
+        for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.y.cc[t] = 0.0f; }
+        WSYNC();
+    }
     GPH(PH + 4);
     for (int it = 0; it < 5; ++it) {                                       // :1563-1581
         for (int t = lane; t < num; t += 64) {
@@ -793,13 +811,18 @@ __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, con
 // =====================================================================================================================
 // texture lists: S7 (top-200 rows of the ADC row maxima) + S8b + S9
 // =====================================================================================================================
+// 14 lists per CU: 11 200 B of LDS (8 neighbour indices per row; sort keys, picked rows and the angle stage's orientations share what is left) and 128 registers
+// (26 spilled).  Measured (texture stage, 100k templates): 16 indices at 12 lists per CU 47.6 ms, 8 indices at 12 lists 51.6, 8 indices at 14 lists 46.2.
 #ifndef AFIS_TEX_CACHE
-#define AFIS_TEX_CACHE 4
+#define AFIS_TEX_CACHE 2
+#endif
+#ifndef AFIS_TEX_WAVES
+#define AFIS_TEX_WAVES 4
 #endif
 typedef WaveSmem<kTopTex, AFIS_TEX_CACHE, false> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
 
-__global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAVES, AFIS_TEX_WAVES))) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
                                                       const float* __restrict__ rm_val, const int32_t* __restrict__ rm_arg,
                                                       float* __restrict__ parts, GraphTap tap)
 {
@@ -841,7 +864,7 @@ __global__ __launch_bounds__(64) void k_graph_texture(QueryDev q, GalleryDev g, 
             for (int u = 0; u < kTexRegs; ++u) if (u < n_regs) n_gt += g_wave_popc(key[u] > T);
             const int need = kTopTex - n_gt;                             // of the keys equal to T keep the lowest indices
             int base_gt = 0, base_eq = 0;
-            uint32_t* const key32 = reinterpret_cast<uint32_t*>(sm.x.pick.keys);   // 200 ordered-float keys, read four at a time below
+            uint32_t* const key32 = sm.x.pick.keys;   // 200 ordered-float keys, read four at a time below
 #pragma unroll
             for (int u = 0; u < kTexRegs; ++u) {                         // u ascending, lane ascending = index ascending
                 if (u < n_regs) {
@@ -939,15 +962,16 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // minutiae lists (produced by k_minu_cands, already in rank order): S8a + S9
 // =====================================================================================================================
 #ifndef AFIS_MINU_CACHE
-#define AFIS_MINU_CACHE 6
+#define AFIS_MINU_CACHE 3
 #endif
 typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE, true> MinuGraphSmem;
 
 // corr_out / corr_n (optional): the surviving correspondences of every task as (lx, ly, rx, ry), matcher.cpp:497-505
-// Five lists per SIMD: 7680 B of LDS (24 neighbour indices per row, no value stash: recomputing a value costs 20 instructions, the stash cost a wave per SIMD)
-// and <= 96 registers.  Measured at 100k templates (minutiae stage): 4 waves with 6 values + 16 indices per row 93.7 ms, 5 waves 89.5 ms, 6 waves (16 indices) 90.3 ms.
+// Six lists per SIMD: 6240 B of LDS (12 neighbour indices per row, no value stash: recomputing a value costs 20 instructions, the stash cost waves; the angle
+// stage's orientations borrow b[] / cc[]) and 80 registers.  Measured at 100k templates (minutiae stage, candidates included): 4 waves with 6 values + 16 indices per row
+// 93.7 ms, 5 waves with 24 indices 89.7-90.4, 6 waves with 12 indices 88.9 (12 indices at 5 waves: 92.3).
 #ifndef AFIS_MINU_WAVES
-#define AFIS_MINU_WAVES 5
+#define AFIS_MINU_WAVES 6
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_MINU_WAVES, AFIS_MINU_WAVES))) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
                                                        const int32_t* __restrict__ cand_n, float* __restrict__ parts,
