@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 // the two waves of a SIMD half a period apart (one in its MFMA burst while the other tracks); the decode spread over the tile steps;
 // s_setprio 3 around the MFMA burst; one pipelined stream per wave after tools/ubench/mfma_stream_model.hip with the decode between the MFMAs and the
 // stage barrier in the middle of a step (3 % faster, 256 registers with spills: not kept); an s_sleep of 0 / 200 / 400 cycles by wave class after each
-// stage barrier, so that the three waves of a SIMD start their stages staggered (no change).
+// stage barrier, so that the three waves of a SIMD start their stages staggered (no change); fixed wave priorities 3 / 2 / 1 for the three waves of a SIMD (no change).
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int kM12Threads = 768, kM12RowBlocks = 24, kM12StageTiles = 6;
 struct __align__(16) M12Stage {
@@ -187,16 +187,12 @@ struct __align__(16) M12Stage {
 __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
                                                             const int2* __restrict__ pair_meta, const int32_t* __restrict__ pair0, const uint4* __restrict__ cw16,
                                                             const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
-                                                            int n_rg, int chunk, uint2* __restrict__ rec, int prio_mode)
+                                                            int n_rg, int chunk, uint2* __restrict__ rec)
 {
     __shared__ uint4 s_cw[kM * kK];                                     // 64 KB
     __shared__ M12Stage s_st[2];                                        // 2 x 37.7 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (prio_mode) {
-        const int c = prio_mode == 1 ? wave % 3 : prio_mode == 2 ? 2 - wave % 3 : wave >> 2;
-        if (c == 0) __builtin_amdgcn_s_setprio(3); else if (c == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
-    }
     const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
     const int t_lo = chunk_id * chunk, t_hi = min(g.G, t_lo + chunk);
     if (t_lo >= t_hi) return;
@@ -572,9 +568,6 @@ hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float
     return hipGetLastError();
 }
 
-static int g_mf_prio_mode = 0;
-void set_mf_prio_mode(int m) { g_mf_prio_mode = m; }
-
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* pair_meta, const int32_t* pair0, const void* cw16,
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream)
 {
@@ -584,7 +577,7 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
     const long long blocks = (long long)n_rg * n_chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kM12Threads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)pair_meta, pair0,
-                       (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, g_mf_prio_mode);
+                       (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
     return hipGetLastError();
 }
 

@@ -119,7 +119,6 @@ hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const voi
 hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hipStream_t stream);
 hipError_t launch_mf_pairs(const GalleryDev& g, const int32_t* q_blk, const float* cwn, void* codes_p, float* nrm_p, void* pair_meta, hipStream_t stream);
 hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream);
-void set_mf_prio_mode(int m);
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* pair_meta, const int32_t* pair0, const void* cw16,
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream);
 hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
