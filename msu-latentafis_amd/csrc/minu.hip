@@ -285,7 +285,11 @@ constexpr int kBinBase = (127 - 15) * 16 - 1;        // key bits 30..19 of 2^-15
 constexpr int kHistMinN = 512;                       // smaller pairs go to the fallback kernel
 constexpr int kCandCap = 256;                        // entries that may still be in the top 120 (exact keys computed for these)
 constexpr uint32_t kKeySlack = 16;                   // 2E
-struct RtSmem {
+#ifndef AFIS_PF_TILES
+#define AFIS_PF_TILES 2
+#endif
+constexpr int kPfTiles = AFIS_PF_TILES;              // latent row tiles of the next task copied ahead into the tail of simi[] (6 KB each)
+struct __attribute__((aligned(16))) RtSmem {
     float simi[kFastN];                              // 32 KB, row stride ld (odd unless nR == 128)
     float rowsum[kFastL];
     float colsum[kFastR];
@@ -349,6 +353,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
 #pragma unroll
             for (int v = 0; v < 24; ++v) bres[v] = 0.0f;
         }
+        // The latent row tiles of the NEXT task of this rolled template are copied into the unused tail of simi[] while this task is being selected from
+        // (global_load_lds: memory -> LDS without registers; one 16-byte element per lane, one copy for the four waves, which each fetched every tile
+        // themselves before) — the fetch was the exposed L2 round trip at the head of every task.  pf_qs: the task whose tiles the tail holds (-1: none).
+        int pf_qs = -1;
         for (int qs = 0; qs < nqs; ++qs) {
             const long long task = (long long)qs * g.G + gi;
             const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
@@ -361,6 +369,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             // hold exactly that per (tile, v, lane), so a fragment is six fully coalesced 1 KB loads.
             const int n_it = (nL + 15) >> 4;
             const float4* atiles = lat_frag + (size_t)q.lm_tile_off[qs] * (6 * 64) + lane;
+            const int n_pf = pf_qs == qs ? min(n_it, kPfTiles) : 0;                 // uniform: row tiles 0 .. n_pf - 1 wait in the tail of simi[]
+            const float4* const a_lds = reinterpret_cast<const float4*>(sm.simi + kFastN) - kPfTiles * (6 * 64) + lane;
             auto load_frag = [&](const float4* __restrict__ tiles, int t, float (&f)[24]) {
 #pragma unroll
                 for (int v = 0; v < 6; ++v) { const float4 x = tiles[(t * 6 + v) * 64]; f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w; }
@@ -388,9 +398,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 // waits 40+ cycles for each result)
                 for (int it = 0; it < n_it; it += 2) {
                     float a0[24], a1[24];
-                    load_frag(atiles, it, a0);
+                    if (it < n_pf) load_frag(a_lds, it, a0); else load_frag(atiles, it, a0);
                     if (it + 1 < n_it) {
-                        load_frag(atiles, it + 1, a1);
+                        if (it + 1 < n_pf) load_frag(a_lds, it + 1, a1); else load_frag(atiles, it + 1, a1);
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -410,13 +420,26 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 const int jt = kWaves + item / n_it, it = item - (jt - kWaves) * n_it;
                 float af[24], bf[24];
                 load_frag(btiles, jt, bf);
-                load_frag(atiles, it, af);
+                if (it < n_pf) load_frag(a_lds, it, af); else load_frag(atiles, it, af);
                 __builtin_amdgcn_sched_barrier(0);
                 store_tile(it, jt, mfma_tile(af, bf));
             }
             sm.hist[tid] = 0u;
             if (tid == 0) sm.thr_bin = -1;
             __syncthreads();
+            pf_qs = -1;
+            if (qs + 1 < nqs) {                                                      // uniform
+                const int nLn = q.lm_off[qs + 2] - q.lm_off[qs + 1];
+                const int n_cp = min((nLn + 15) >> 4, kPfTiles);
+                // the tail must clear this task's matrix (still being read) and the next one's (written before the tiles are read)
+                if (nLn > 0 && nLn <= kFastL && max(nL, nLn) * ld + kPfTiles * (6 * 64 * 4) <= kFastN) {
+                    const float4* src = lat_frag + (size_t)q.lm_tile_off[qs + 1] * (6 * 64) + lane;
+                    float4* dst = reinterpret_cast<float4*>(sm.simi + kFastN) - kPfTiles * (6 * 64);
+                    for (int c = wave; c < n_cp * 6; c += kWaves)                    // chunk = 64 lanes x 16 B = one (tile, v) slice
+                        __builtin_amdgcn_global_load_lds(src + c * 64, (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
+                    pf_qs = qs + 1;
+                }
+            }
             PHASE(16);
             // ---- S2 (:455-456): index-ascending sums; odd row stride: both walks are conflict free.  Eight reads are issued before
             // the eight dependent adds (one LDS round trip per eight elements instead of one per element).
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             __syncthreads();
             PHASE(30);
             const int B = sm.thr_bin;
-            if (B < 2) { if (tid == 0) to_fallback(task); __syncthreads(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
+            if (B < 2) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
             // ---- the candidates: approximate key >= edge(B) - 2E ----
             {
                 const uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
@@ -517,13 +540,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             __syncthreads();
             PHASE(31);
             const int n_c = (int)sm.hist[B];                                         // >= 120: group B ends the list
-            if (n_c > kCandCap) { if (tid == 0) to_fallback(task); __syncthreads(); continue; }
+            if (n_c > kCandCap) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }
             int ci = 0, cj2 = 0, cbin = 0;
             if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
                 const uint32_t pe = sm.cand_e[tid];
                 cbin = (int)(pe >> 16); ci = (int)((pe >> 8) & 255u); cj2 = (int)(pe & 255u);
                 sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 13) | (u64)(8191 - (ci * nR + cj2));
             } else if (tid == n_c) sm.cand[tid & (kCandCap - 1)] = 0ull;             // pad of an odd list (n_c == kCandCap is even: nothing is overwritten)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the next task's tiles has landed in LDS (waited for here, before the list's stores join the counter)
             __syncthreads();
             PHASE(18);
             // ---- rank the candidates by counting (composites are unique); ranks < 120 are the list, in the reference's order.
