@@ -37,7 +37,7 @@ n_valu = sq["SQ_INSTS_VALU"] - sq["SQ_INSTS_MFMA"]                          # SQ
 fetch_b = 2 * hb["FETCH_SIZE"] * 1024; write_b = hb["WRITE_SIZE"] * 1024
 out = {
     "round": "round 3", "kernel": "afis::k_adc_mfma (adc_variant 9, default)",
-    "workload": "bench.py default: 100 latents x 100k gallery, launch groups cut by latent texture rows (12 launches per step)",
+    "workload": "bench.py default: 100 latents x 100k gallery, launch groups cut by latent texture rows (6 launches per step)",
     "avg_launch_ms_rocprof_stats": float(ks["afis::k_adc_mfma"]["avg_ms"]), "launches_profiled": int(ks["afis::k_adc_mfma"]["calls"]),
     "sq_counters_per_launch": sq, "FETCH_SIZE_KB_per_launch_raw": hb["FETCH_SIZE"], "WRITE_SIZE_KB_per_launch_raw": hb["WRITE_SIZE"],
     "correction": "FETCH_SIZE x 2: the kernel's reads are 16 B / 4 B per lane coalesced streams (pair-aligned codes, point terms, B fragments), for which FETCH_SIZE reports half the bytes "
