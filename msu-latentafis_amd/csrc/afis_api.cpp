@@ -583,10 +583,10 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
     int64_t by_mem = ctx->rowmax_budget_bytes / (G * kTexMax * 8);
     // latents per launch group: the option, or (0 = auto) as many as keep about two million (latent, rolled) pairs in a launch — 20 at a 100k-template
-    // shard, 64 at 12.5k: the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
+    // shard, 128 at <= 15k (a 12.5k-template shard: 100 latents in one launch 310.7 ms, in 64 + 36: 315.1): the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
     // each cost 1.2 x their share of a 100k-template step; 2 launches do not).  Measured at 100k templates, 100 latents: 7 per launch 2 495 ms, 10: 2 486,
     // 15: 2 466, 20: 2 463, 34: 2 468.
-    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : std::min<int64_t>(64, std::max<int64_t>(10, (2000000 + G / 2) / G));
+    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : std::min<int64_t>(128, std::max<int64_t>(10, (2000000 + G / 2) / G));
     int per = (int)std::max<int64_t>(1, std::min<int64_t>(want, by_mem));
     afis_queries* q = new afis_queries();
     q->n_q = n_q;
