@@ -52,17 +52,16 @@ __global__ __launch_bounds__(256) void k_mf_codebook(const float* __restrict__ c
     cwn[e] = (float)n2;
 }
 
-// Pair-aligned copy of the gallery's texture codes: template t owns ceil(n/64) pairs of tiles (64 entries of 16 code bytes, zero beyond
-// the template's points) starting at pair q_blk[t]; per entry also G's point term -|b_j|^2 / 2 (kMfNeg beyond the points), and per pair
-// (template, pair index in the template | 256 on the template's last pair).  grid = G, block = 64.
-__global__ __launch_bounds__(64) void k_mf_pairs(GalleryDev g, const int32_t* __restrict__ q_blk, const float* __restrict__ cwn,
-                                                 uint4* __restrict__ codes_p, float* __restrict__ nrm_p, int2* __restrict__ pair_meta)
+// Tile-aligned copy of the gallery's texture codes: template t owns ceil(n/32) tiles (32 entries of 16 code bytes, zero beyond the template's
+// points) starting at tile t_blk[t]; per entry also G's point term -|b_j|^2 / 2 (kMfNeg beyond the points), and per tile
+// (template, tile index in the template | 256 on the template's last tile).  grid = G, block = 64.
+__global__ __launch_bounds__(64) void k_mf_pairs(GalleryDev g, const int32_t* __restrict__ t_blk, const float* __restrict__ cwn,
+                                                 uint4* __restrict__ codes_p, float* __restrict__ nrm_p, int2* __restrict__ tile_meta)
 {
     const int t = blockIdx.x, lane = threadIdx.x;
     const int p0 = g.tex_off[t], n = g.tex_off[t + 1] - p0;
-    const int nb = (n + 63) >> 6;
-    for (int k = 0; k < nb; ++k) {
-        const int p = k * 64 + lane;
+    const int nt = (n + 31) >> 5;
+    for (int p = lane; p < nt * 32; p += 64) {
         uint4 c = make_uint4(0, 0, 0, 0);
         float nrm = kMfNeg;
         if (p < n) {
@@ -73,9 +72,9 @@ __global__ __launch_bounds__(64) void k_mf_pairs(GalleryDev g, const int32_t* __
             for (int m = 0; m < kM; ++m) s += cwn[m * kK + ((w[m >> 2] >> (8 * (m & 3))) & 255u)];
             nrm = -0.5f * s;
         }
-        const size_t e = ((size_t)q_blk[t] + k) * 64 + lane;
+        const size_t e = (size_t)t_blk[t] * 32 + p;
         codes_p[e] = c; nrm_p[e] = nrm;
-        if (lane == 0) pair_meta[q_blk[t] + k] = make_int2(t, k | (k == nb - 1 ? 256 : 0));
+        if ((p & 31) == 0) { const int k = p >> 5; tile_meta[t_blk[t] + k] = make_int2(t, k | (k == nt - 1 ? 256 : 0)); }
     }
 }
 
@@ -156,7 +155,8 @@ __global__ __launch_bounds__(256) void k_mf_rows(const float* __restrict__ lt_de
 // The bound pass.  grid = row groups (768 latent rows) x gallery chunks, block = 768 = 12 waves, three per SIMD (<= 168 VGPRs).
 //   LDS: fp16 codebook (64 KB) + two stages of 6 tiles: per tile 12 operand groups x 32 points x 16 B (group gidx = halves 8 gidx .. 8 gidx + 7
 //   of the point's 96, i.e. exactly what lane (point, k half) of MFMA step gidx / 2 wants: reads and writes are conflict free), 32 point terms
-//   and the pair's directory entry (it travels with the tile: a scalar load in the tile loop would share the operand reads' lgkmcnt).
+//   and the tile's directory entry (template, tile index | last: it travels with the tile — a scalar load in the tile loop would share the operand reads' lgkmcnt).
+//   A template owns ceil(n / 32) tiles of the stream (16 padding points per template on average; the pair-of-tiles alignment this replaced had 32: -2 %).
 //   Every thread decodes one (point, 4 sub-quantizers) item per stage: 4 codebook reads (12 bytes used of 16), 3 operand-group writes — three
 //   groups are exactly four codewords' 24 halves, so no repacking arithmetic at all.
 //   Wave w keeps the B fragments of row blocks 2w, 2w + 1 in 48 registers for its whole life and runs every tile through both.
@@ -180,8 +180,7 @@ constexpr int kM12Threads = 768, kM12RowBlocks = 24, kM12StageTiles = 6;
 struct __align__(16) M12Stage {
     uint4 a[kM12StageTiles][12][32];
     float nrm[kM12StageTiles][32];
-    int2 meta[kM12StageTiles / 2];
-    int2 pad;
+    int2 meta[kM12StageTiles];
 };
 
 __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
@@ -196,10 +195,10 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
     const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
     const int t_lo = chunk_id * chunk, t_hi = min(g.G, t_lo + chunk);
     if (t_lo >= t_hi) return;
-    const int pair_lo = pair0[t_lo], pair_hi = pair0[t_hi];
-    const int n_pairs = pair_hi - pair_lo;
-    if (n_pairs <= 0) return;
-    const int n_stages = (n_pairs + 2) / 3;
+    const int tile_lo = pair0[t_lo], tile_hi = pair0[t_hi];                // tiles of 32 rolled points; a template owns ceil(n/32) of them
+    const int n_tiles = tile_hi - tile_lo;
+    if (n_tiles <= 0) return;
+    const int n_stages = (n_tiles + kM12StageTiles - 1) / kM12StageTiles;
     for (int i = tid; i < kM * kK; i += kM12Threads) s_cw[i] = cw16[i];
 
     const int h = lane >> 5, col = lane & 31;
@@ -221,16 +220,16 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
         Tg[blk] = rk.z; force[blk] = rk.w != 0.0f;
     }
     const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;       // point in tile, sub-quantizer quad, tile of the stage (0..5)
-    const bool meta_thread = pQ == 1 && pp == 0 && (pj & 1) == 0;
+    const bool meta_thread = pQ == 1 && pp == 0;
     struct Pf { uint32_t code; float nrm; int2 meta; };
     auto fetch = [&](int s, Pf& f) {
-        const int pair = pair_lo + 3 * s + (pj >> 1);
+        const int tile = tile_lo + kM12StageTiles * s + pj;
         f.code = 0u; f.nrm = kMfNeg; f.meta = make_int2(0, 0);
-        if (pair < pair_hi) {
-            const size_t e = (size_t)pair * 64 + (pj & 1) * 32 + pp;
+        if (tile < tile_hi) {
+            const size_t e = (size_t)tile * 32 + pp;
             f.code = reinterpret_cast<const uint32_t*>(codes_p)[e * 4 + pQ];
             if (pQ == 0) f.nrm = nrm_p[e];
-            if (meta_thread) f.meta = pair_meta[pair];
+            if (meta_thread) f.meta = pair_meta[tile];
         }
     };
     auto decode = [&](int buf, const Pf& f) {
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
         st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
         st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
         if (pQ == 0) st.nrm[pj][pp] = f.nrm;
-        if (meta_thread) st.meta[pj >> 1] = f.meta;
+        if (meta_thread) st.meta[pj] = f.meta;
     };
     Pf pf_cur, pf_nxt;
     fetch(0, pf_cur);
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
                     const float4 v = *reinterpret_cast<const float4*>(&st.nrm[j][8 * q4 + 4 * h]);
                     nrm[4 * q4] = v.x; nrm[4 * q4 + 1] = v.y; nrm[4 * q4 + 2] = v.z; nrm[4 * q4 + 3] = v.w;
                 }
-                const int2 mv = st.meta[j >> 1];
+                const int2 mv = st.meta[j];
                 half8 af[6];
 #pragma unroll
                 for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[j][2 * kk + h][col]);
@@ -314,10 +313,10 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
                     X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[1][kk], X1, 0, 0, 0);
                 }
                 const int my = __builtin_amdgcn_readfirstlane(mv.y);
-                const uint32_t gid = (uint32_t)(4 * (my & 255) + 2 * (j & 1));
+                const uint32_t gid = (uint32_t)(2 * (my & 255));
                 track(0, X0, gid);
                 track(1, X1, gid);
-                if ((j & 1) && (my & 256)) finish_template(__builtin_amdgcn_readfirstlane(mv.x));
+                if (my & 256) finish_template(__builtin_amdgcn_readfirstlane(mv.x));
             }
         }
         if (s + 1 < n_stages) decode((s + 1) & 1, pf_cur);

@@ -63,11 +63,12 @@ struct afis_ctx {
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
-    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_tex_codes_q, g_tex_q_blk, g_empty, g_task_ctr;
+    DevBuf g_minu_off, g_minu_xy, g_minu_ori, g_minu_des, g_minu_frag, g_minu_tile_off, g_tex_off, g_tex_xy, g_tex_ori, g_tex_codes, g_tex_codes_cf, g_tex_cf_blk, g_tex_codes_q, g_tex_q_blk, g_tex_t32_blk, g_empty, g_task_ctr;
     bool codes_cf_built = false;         // variants 6 / 7: their lane-ordered code stream, laid out on first use
     int64_t cf_blocks = 0;
     bool codes_q_built = false;          // adc_variant 8's lane-ordered code stream is laid out on first use
     int64_t q_blocks = 0;
+    int64_t t32_tiles = 0;               // tiles of 32 rolled texture points (ceil(n/32) per template): the matrix-core bound pass's stream
     int max_nR = 0;
     int64_t total_tex_points = 0;
     // adc_variant 9: fp16 codebook + |cw|^2 (once), pair-aligned gallery codes / point terms / pair directory (first use), per group B fragments,
@@ -192,7 +193,7 @@ std::vector<float> fragment_tiles(const std::vector<float>& des, const std::vect
 void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
-    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_empty.release(); c->g_task_ctr.release();
+    c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_tex_t32_blk.release(); c->g_empty.release(); c->g_task_ctr.release();
     c->g_codes_p.release(); c->g_nrm_p.release(); c->g_pair_meta.release(); c->mf_gal_built = false;
 }
 
@@ -483,6 +484,15 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
         ctx->q_blocks = nb;
         HIPCHK(ctx, upload(ctx->g_tex_q_blk, qb, ctx->stream));
     }
+    {   // tile offsets of the matrix-core bound pass's stream (ceil(n/32) tiles of 32 points per template); the stream itself is made on first use
+        std::vector<int32_t> tb(G + 1);
+        int64_t nt = 0;
+        for (int64_t t = 0; t < G; ++t) { tb[t] = (int32_t)nt; nt += (hg.tex_off[t + 1] - hg.tex_off[t] + 31) / 32; }
+        tb[G] = (int32_t)nt;
+        if (nt > 0x7fffffff / 32) return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for the bound pass's code stream; split the gallery into more shards");
+        ctx->t32_tiles = nt;
+        HIPCHK(ctx, upload(ctx->g_tex_t32_blk, tb, ctx->stream));
+    }
     HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
     HIPCHK(ctx, ctx->g_task_ctr.ensure(64));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -689,11 +699,11 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
         ctx->mf_cb_built = true;
     }
     if (!ctx->mf_gal_built) {
-        const size_t n_ent = std::max<size_t>((size_t)ctx->q_blocks * 64, 1);
+        const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
         HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
         HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
-        HIPCHK(ctx, ctx->g_pair_meta.ensure(std::max<size_t>((size_t)ctx->q_blocks * 8, 16)));
-        HIPCHK(ctx, launch_mf_pairs(g, ctx->g_tex_q_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, s));
+        HIPCHK(ctx, ctx->g_pair_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
+        HIPCHK(ctx, launch_mf_pairs(g, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, s));
         ctx->mf_gal_built = true;
     }
     const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
@@ -708,7 +718,7 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     const int n_rg = (n_rb + 23) / 24;                                 // 24 row blocks per workgroup (adc_mfma.hip)
     const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
-    HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, ctx->g_tex_q_blk.as<int32_t>(), ctx->mf_cw16.p,
+    HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
                                 ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_rec.p, s));
     if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
     HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
