@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_mf_codebook(const float* __restrict__ c
 // Tile-aligned copy of the gallery's texture codes: template t owns ceil(n/32) tiles (32 entries of 16 code bytes, zero beyond the template's
 // points) starting at tile t_blk[t]; per entry also G's point term -|b_j|^2 / 2 (kMfNeg beyond the points), and per tile
 // (template, tile index in the template | 256 on the template's last tile).  grid = G, block = 64.
-__global__ __launch_bounds__(64) void k_mf_pairs(GalleryDev g, const int32_t* __restrict__ t_blk, const float* __restrict__ cwn,
+__global__ __launch_bounds__(64) void k_mf_tiles(GalleryDev g, const int32_t* __restrict__ t_blk, const float* __restrict__ cwn,
                                                  uint4* __restrict__ codes_p, float* __restrict__ nrm_p, int2* __restrict__ tile_meta)
 {
     const int t = blockIdx.x, lane = threadIdx.x;
@@ -184,7 +184,7 @@ struct __align__(16) M12Stage {
 };
 
 __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
-                                                            const int2* __restrict__ pair_meta, const int32_t* __restrict__ pair0, const uint4* __restrict__ cw16,
+                                                            const int2* __restrict__ tile_meta, const int32_t* __restrict__ tile0, const uint4* __restrict__ cw16,
                                                             const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
                                                             int n_rg, int chunk, uint2* __restrict__ rec)
 {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
     const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
     const int t_lo = chunk_id * chunk, t_hi = min(g.G, t_lo + chunk);
     if (t_lo >= t_hi) return;
-    const int tile_lo = pair0[t_lo], tile_hi = pair0[t_hi];                // tiles of 32 rolled points; a template owns ceil(n/32) of them
+    const int tile_lo = tile0[t_lo], tile_hi = tile0[t_hi];                // tiles of 32 rolled points; a template owns ceil(n/32) of them
     const int n_tiles = tile_hi - tile_lo;
     if (n_tiles <= 0) return;
     const int n_stages = (n_tiles + kM12StageTiles - 1) / kM12StageTiles;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
             const size_t e = (size_t)tile * 32 + pp;
             f.code = reinterpret_cast<const uint32_t*>(codes_p)[e * 4 + pQ];
             if (pQ == 0) f.nrm = nrm_p[e];
-            if (meta_thread) f.meta = pair_meta[tile];
+            if (meta_thread) f.meta = tile_meta[tile];
         }
     };
     auto decode = [&](int buf, const Pf& f) {
@@ -553,10 +553,10 @@ hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hi
     return hipGetLastError();
 }
 
-hipError_t launch_mf_pairs(const GalleryDev& g, const int32_t* q_blk, const float* cwn, void* codes_p, float* nrm_p, void* pair_meta, hipStream_t stream)
+hipError_t launch_mf_tiles(const GalleryDev& g, const int32_t* q_blk, const float* cwn, void* codes_p, float* nrm_p, void* tile_meta, hipStream_t stream)
 {
     if (g.G <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mf_pairs, dim3(g.G), dim3(64), 0, stream, g, q_blk, cwn, (uint4*)codes_p, nrm_p, (int2*)pair_meta);
+    hipLaunchKernelGGL(k_mf_tiles, dim3(g.G), dim3(64), 0, stream, g, q_blk, cwn, (uint4*)codes_p, nrm_p, (int2*)tile_meta);
     return hipGetLastError();
 }
 
@@ -567,7 +567,7 @@ hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float
     return hipGetLastError();
 }
 
-hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* pair_meta, const int32_t* pair0, const void* cw16,
+hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream)
 {
     if (n_rb <= 0 || g.G <= 0) return hipSuccess;
@@ -575,7 +575,7 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
     const int n_rg = (n_rb + kM12RowBlocks - 1) / kM12RowBlocks;
     const long long blocks = (long long)n_rg * n_chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kM12Threads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)pair_meta, pair0,
+    hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kM12Threads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
                        (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
     return hipGetLastError();
 }

@@ -73,7 +73,7 @@ struct afis_ctx {
     int64_t total_tex_points = 0;
     // adc_variant 9: fp16 codebook + |cw|^2 (once), pair-aligned gallery codes / point terms / pair directory (first use), per group B fragments,
     // row constants and the bound pass's records
-    DevBuf mf_cw16, mf_cwn, g_codes_p, g_nrm_p, g_pair_meta, mf_bfrag, mf_rowk, mf_rec, mf_stats;
+    DevBuf mf_cw16, mf_cwn, g_codes_p, g_nrm_p, g_tile_meta, mf_bfrag, mf_rowk, mf_rec, mf_stats;
     bool mf_cb_built = false, mf_gal_built = false;
     int mf_collect_stats = 0;
     DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // adc_variant 8: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step, margin), fp32 table
@@ -194,7 +194,7 @@ void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
     c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_tex_t32_blk.release(); c->g_empty.release(); c->g_task_ctr.release();
-    c->g_codes_p.release(); c->g_nrm_p.release(); c->g_pair_meta.release(); c->mf_gal_built = false;
+    c->g_codes_p.release(); c->g_nrm_p.release(); c->g_tile_meta.release(); c->mf_gal_built = false;
 }
 
 }  // namespace
@@ -702,8 +702,8 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
         const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
         HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
         HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
-        HIPCHK(ctx, ctx->g_pair_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
-        HIPCHK(ctx, launch_mf_pairs(g, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, s));
+        HIPCHK(ctx, ctx->g_tile_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
+        HIPCHK(ctx, launch_mf_tiles(g, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, s));
         ctx->mf_gal_built = true;
     }
     const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
@@ -718,7 +718,7 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     const int n_rg = (n_rb + 23) / 24;                                 // 24 row blocks per workgroup (adc_mfma.hip)
     const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
-    HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_pair_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
+    HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
                                 ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_rec.p, s));
     if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
     HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),

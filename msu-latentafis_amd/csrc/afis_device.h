@@ -112,14 +112,14 @@ hipError_t launch_codes_cf(const GalleryDev& g, void* out, hipStream_t stream);
 hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const void* codes_q, const int32_t* q_blk, const void* lutq_tiles, const void* rowc,
                                const float* lut32, int chunk, int share, float* rm_val, int32_t* rm_arg, hipStream_t stream);
 // adc_variant 9 (adc_mfma.hip): fp16 matrix-core bound pass + exact recomputation.  launch_mf_codebook: fp16 codebook (16-byte entries) and
-// |cw|^2 table, once per context.  launch_mf_pairs: tile-aligned (32 points) codes / point terms / tile directory of the gallery (first use).
+// |cw|^2 table, once per context.  launch_mf_tiles: tile-aligned (32 points) codes / point terms / tile directory of the gallery (first use).
 // launch_mf_rows: per latent row of a query group the fp16 B fragments and (c, Es, Tg, force).  launch_adc_mfma: the bound pass ->
 // rec[(template * 2 + half) * R_pad + row].  launch_tex_refine: bounds -> the rows that can reach the top 200 -> exact (max, first arg-max)
 // into rm_val / rm_arg, -inf for the other rows (all_rows != 0: every row exactly; the parity taps use it).
 hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hipStream_t stream);
-hipError_t launch_mf_pairs(const GalleryDev& g, const int32_t* t32_blk, const float* cwn, void* codes_p, float* nrm_p, void* pair_meta, hipStream_t stream);
+hipError_t launch_mf_tiles(const GalleryDev& g, const int32_t* t32_blk, const float* cwn, void* codes_p, float* nrm_p, void* tile_meta, hipStream_t stream);
 hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream);
-hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* pair_meta, const int32_t* pair0, const void* cw16,
+hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream);
 hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
                              float* rm_val, int32_t* rm_arg, unsigned long long* stats, hipStream_t stream);
