@@ -104,7 +104,7 @@ template <int NMAX_, int CACHE_, bool OWN_SIM_>
 struct __attribute__((aligned(16))) WaveSmem : SimStore<NMAX_, OWN_SIM_> {
     static constexpr int NMAX = NMAX_, CACHE = CACHE_;
     static constexpr bool OWN_SIM = OWN_SIM_;
-    static constexpr bool ALIAS_ORI = NMAX_ > 128 || AFIS_MINU_ALIAS;   // texture lists: LDS is what limits the lists per CU, the angle stage's orientations live in b[] / cc[] while H is built
+    static constexpr bool ALIAS_ORI = NMAX_ > 128 || AFIS_MINU_ALIAS;   // LDS is what limits the lists per CU: the angle stage's orientations live in b[] / cc[] while its H is built
     static constexpr int W = (NMAX + 31) / 32;
     static constexpr int N4 = (NMAX + 3) / 4 * 4;
     static constexpr int U = (NMAX + 63) / 64;
@@ -114,11 +114,11 @@ struct __attribute__((aligned(16))) WaveSmem : SimStore<NMAX_, OWN_SIM_> {
         struct { short order[NMAX]; short sel[NMAX]; } os;     // rank -> candidate index; accepted candidates
     } y;
     short li[NMAX], ri[NMAX];
-    int2 xy[NMAX];                         // .x = lx | ly << 16 (latent point), .y = rx | ry << 16 (rolled point)
+    int2 xy[NMAX];                         // .x = latent point, .y = rolled point: (x, y) as two fp16 on the packed paths (graph_arith.h), x | y << 16 as 16-bit integers otherwise and after S8
     uint32_t hb[NMAX][W];                  // bit rows: non-zero pattern of H (distance stage), then the boolean H of the angle stage
     // LDS is what limits how many lists a CU works on at once, so buffers with disjoint lifetimes share storage:
     union {
-        float stash[CACHE * NMAX];                                                  // power iterations: [n][t] = value of the n-th non-zero of row t
+        float stash[CACHE * NMAX];                                                  // power iterations: CACHE * 4 bytes per row for the rows' first neighbour indices (bytes, [n][t]) and, optionally, values
         struct { u64 keys[N4]; float lo[ALIAS_ORI ? 1 : NMAX], ro[ALIAS_ORI ? 1 : NMAX]; } s;   // sorts (after the iterations); orientations (angle stage, unless they borrow b / cc)
         struct { uint32_t keys[N4]; short te[NMAX], targ[NMAX]; } pick;          // texture rows picked by S7, before they are ranked (32-bit keys)
     } x;
