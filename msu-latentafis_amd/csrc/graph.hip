@@ -883,15 +883,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
             // rank by counting on the 32-bit keys.  Picked rows sit in index order, so equal keys would need the index as a tie-break:
             // ties make the ranks collide, which their sum shows (a permutation of 0..199 sums to 19900, anything else to less); the
             // 64-bit (key, ~index) composites are ranked only then.
+            // The 200 keys are first dealt into 64 bins of equal width between the smallest and the largest (counting sort through LDS counters; b[] and
+            // cc[] are free until the distance stage), highest bin first; a key then counts the larger keys of ITS bin only and adds the bins above it:
+            // 200 x 200 comparisons become 200 x (a bin's population).
             uint32_t m32[TexSmem::U]; int r[TexSmem::U];
+            uint32_t* const s_cnt = reinterpret_cast<uint32_t*>(sm.b);          // [64] fill pointers, [64..128) bin starts
+            uint32_t* const s_gkey = reinterpret_cast<uint32_t*>(sm.y.cc);      // [200] the keys grouped by bin
+            int dmax = 0;
 #pragma unroll
-            for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; m32[u] = t < num ? key32[t] : 0xffffffffu; r[u] = 0; }
-            const uint4* k4 = reinterpret_cast<const uint4*>(key32);
-#pragma unroll 2
-            for (int k = 0; k < kTopTex / 4; ++k) {
-                const uint4 kk = k4[k];
+            for (int u = 0; u < TexSmem::U; ++u) {
+                const int t = lane + 64 * u;
+                m32[u] = t < num ? key32[t] : T;
+                dmax = max(dmax, (int)(m32[u] - T));                              // keys are >= T (the 200th largest) and share its sign: the difference is small and non-negative
+            }
+            dmax = g_wave_max(dmax);
+            const int shift = max(0, 26 - __clz(dmax | 1));                       // bin = (key - T) >> shift in [0, 63]
+            int bin[TexSmem::U];
 #pragma unroll
-                for (int u = 0; u < TexSmem::U; ++u) { r[u] += kk.x > m32[u]; r[u] += kk.y > m32[u]; r[u] += kk.z > m32[u]; r[u] += kk.w > m32[u]; }
+            for (int u = 0; u < TexSmem::U; ++u) bin[u] = (int)((m32[u] - T) >> shift);
+            s_cnt[lane] = 0u;
+            WSYNC();
+#pragma unroll
+            for (int u = 0; u < TexSmem::U; ++u) if (lane + 64 * u < num) atomicAdd(&s_cnt[bin[u]], 1u);
+            WSYNC();
+            {   // lane l owns bin l: start = number of keys in the bins above it
+                const int own = (int)s_cnt[lane];
+                int suf = own;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
+                WSYNC();
+                s_cnt[lane] = (uint32_t)(suf - own); s_cnt[64 + lane] = (uint32_t)(suf - own);
+            }
+            WSYNC();
+#pragma unroll
+            for (int u = 0; u < TexSmem::U; ++u) if (lane + 64 * u < num) s_gkey[atomicAdd(&s_cnt[bin[u]], 1u)] = m32[u];
+            WSYNC();
+#pragma unroll
+            for (int u = 0; u < TexSmem::U; ++u) {
+                r[u] = 0;
+                if (lane + 64 * u < num) {
+                    const int lo = (int)s_cnt[64 + bin[u]], hi = (int)s_cnt[bin[u]];   // the fill pointer ended at the bin's end
+                    int c = lo;
+                    for (int k = lo; k < hi; ++k) c += s_gkey[k] > m32[u];
+                    r[u] = c;
+                }
             }
             int rsum = 0;
 #pragma unroll
