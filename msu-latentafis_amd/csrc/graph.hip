@@ -154,36 +154,75 @@ __device__ __forceinline__ int next_task(int32_t* ctr)
     return __builtin_amdgcn_readfirstlane(t);                            // all lanes are active again: lane 0 holds the ticket
 }
 
-// ranks (0 = largest) of this lane's U keys among keys[0..n); keys are unique
-template <int U>
-__device__ __forceinline__ void rank_keys(const u64* keys, int n, const u64 (&mine)[U], int (&r)[U])
-{
-#pragma unroll
-    for (int u = 0; u < U; ++u) r[u] = 0;
-#pragma unroll 4
-    for (int k = 0; k < n; ++k) {
-        const u64 kk = keys[k];
-#pragma unroll
-        for (int u = 0; u < U; ++u) r[u] += kk > mine[u];
-    }
-}
-
-// sort the candidates by score b (descending, ties by index): order[rank] = index
+// sort the candidates by score b (descending, ties by index): order[rank] = index.
+// The ordered 32-bit keys are dealt into 64 bins of equal width between the smallest and the largest (counting sort through LDS counters, highest bin
+// first); a key counts the larger keys of ITS bin only and adds the bins above it.  Equal scores make ranks collide, which the sum of the ranks shows (a
+// permutation of 0 .. num-1 sums to num (num-1) / 2): the (key, ~index) composites are ranked against every other one only then.
 template <class SM>
 __device__ __forceinline__ void sort_scores(SM& sm, int num)
 {
     const int lane = threadIdx.x;
-    u64 mine[SM::U]; int r[SM::U];
+    constexpr int U = SM::U;
+    uint32_t* const s_key = reinterpret_cast<uint32_t*>(sm.x.s.keys);         // [NMAX] keys in index order, then [128] bin fill pointers / starts
+    uint32_t* const s_cnt = s_key + SM::N4;
+    uint32_t* const s_gkey = reinterpret_cast<uint32_t*>(sm.y.cc);            // [NMAX] keys grouped by bin (cc is dead; order[] / sel[], which alias it, are written after the ranking)
+    static_assert(sizeof(sm.x) >= (size_t)(SM::N4 + 128) * 4, "sort scratch exceeds the union");
+    uint32_t m32[U]; int r[U];
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
-    for (int u = 0; u < SM::U; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int t = lane + 64 * u;
-        mine[u] = t < num ? g_make_key(sm.b[t], t) : 0ull;
-        if (t < num) sm.x.s.keys[t] = mine[u];
+        m32[u] = t < num ? g_ord_f32(sm.b[t]) : 0u;
+        if (t < num) { s_key[t] = m32[u]; kmin = min(kmin, m32[u]); kmax = max(kmax, m32[u]); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off)); }
+    const uint32_t span = kmax - kmin;
+    const int sh = max(0, 26 - __clz((int)(span | 1u)));                      // bin = (key - kmin) >> sh in [0, 63]
+    int bin[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) bin[u] = (int)((m32[u] - kmin) >> sh) & 63;
+    s_cnt[lane] = 0u;
+    WSYNC();
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (lane + 64 * u < num) atomicAdd(&s_cnt[bin[u]], 1u);
+    WSYNC();
+    {
+        const int own = (int)s_cnt[lane];
+        int suf = own;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
+        WSYNC();
+        s_cnt[lane] = (uint32_t)(suf - own); s_cnt[64 + lane] = (uint32_t)(suf - own);
     }
     WSYNC();
-    rank_keys<SM::U>(sm.x.s.keys, num, mine, r);
 #pragma unroll
-    for (int u = 0; u < SM::U; ++u) { const int t = lane + 64 * u; if (t < num) sm.y.os.order[r[u]] = (short)t; }
+    for (int u = 0; u < U; ++u) if (lane + 64 * u < num) s_gkey[atomicAdd(&s_cnt[bin[u]], 1u)] = m32[u];
+    WSYNC();
+    int rsum = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        r[u] = 0;
+        if (lane + 64 * u < num) {
+            const int lo = (int)s_cnt[64 + bin[u]], hi = (int)s_cnt[bin[u]];
+            int c = lo;
+            for (int k = lo; k < hi; ++k) c += s_gkey[k] > m32[u];
+            r[u] = c; rsum += c;
+        }
+    }
+    if (g_wave_sum(rsum) != num * (num - 1) / 2) {                            // equal scores: rank the (key, ~index) composites
+        u64 mine[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? ((u64)m32[u] << 32) | (uint32_t)(~(uint32_t)t) : 0ull; r[u] = 0; }
+        for (int k = 0; k < num; ++k) {
+            const u64 kk = ((u64)s_key[k] << 32) | (uint32_t)(~(uint32_t)k);
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] += kk > mine[u];
+        }
+    }
+    WSYNC();
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; if (t < num) sm.y.os.order[r[u]] = (short)t; }
     WSYNC();
 }
 
