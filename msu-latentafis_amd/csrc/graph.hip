@@ -168,6 +168,17 @@ __device__ __forceinline__ void sort_scores(SM& sm, int num)
     uint32_t* const s_gkey = reinterpret_cast<uint32_t*>(sm.y.cc);            // [NMAX] keys grouped by bin (cc is dead; order[] / sel[], which alias it, are written after the ranking)
     static_assert(sizeof(sm.x) >= (size_t)(SM::N4 + 128) * 4, "sort scratch exceeds the union");
     uint32_t m32[U]; int r[U];
+    if (num <= 48) {                                                          // short lists (the angle stage's): the bins' bookkeeping costs more than it saves
+        const u64 mine = lane < num ? g_make_key(sm.b[lane], lane) : 0ull;
+        if (lane < num) sm.x.s.keys[lane] = mine;
+        WSYNC();
+        int rr = 0;
+        for (int k = 0; k < num; ++k) rr += sm.x.s.keys[k] > mine;
+        WSYNC();
+        if (lane < num) sm.y.os.order[rr] = (short)lane;
+        WSYNC();
+        return;
+    }
     uint32_t kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
