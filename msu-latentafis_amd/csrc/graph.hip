@@ -493,16 +493,13 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
                 for (int u = 0; u < UA; ++u) {
                     pair_n(me[u], other[s2][u], n1[s2][u], n2[s2][u]);
                     hit[s2][u] = pair_compatible_t<LOOKUP>(n1[s2][u], n2[s2][u], near[s2][u]);
-                    any_near |= near[s2][u];
+                    hit[s2][u] = hit[s2][u] | near[s2][u];
                 }
             }
-            if (__builtin_amdgcn_ballot_w64(any_near) != 0ull) {
-#pragma unroll
-                for (int s2 = 0; s2 < DU; ++s2) {
-#pragma unroll
-                    for (int u = 0; u < UA; ++u) if (near[s2][u]) hit[s2][u] = pair_compatible_exact<LOOKUP>(n1[s2][u], n2[s2][u]);
-                }
-            }
+            // A pair inside the guard band of the square-root-free test (graph_arith.h) is simply taken as a hit: every consumer of a set bit evaluates
+            // the pair's exact value — the power iterations multiply by h (= 0 for a distance of 30 or a hair more: x + 0.0f == x), the greedy selection
+            // tests h >= 1e-5 — so a spurious bit changes no result, only adds a zero-valued neighbour (1e-4 of the pairs at most).
+            (void)any_near;
 #pragma unroll
             for (int s2 = 0; s2 < DU; ++s2) {
                 const bool last = d + s2 == half && even;                 // even num: the antipodal pairs belong to the lower half
