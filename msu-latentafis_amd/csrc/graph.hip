@@ -641,19 +641,17 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
             } else {
                 const int nV = min(trip[u], kValN), nA = min(trip[u], kIdxN);
                 const int tt = t >= 0 ? t : 0;
+                // no divergent region per step: a lane whose row has ended computes on a stale index byte (any byte addresses LDS of this list) and adds
+                // +0.0f instead (acc >= +0: x + 0.0f == x) — the exec bookkeeping of a branch costs more than the masked lanes' work
                 for (int n = 0; n < nV; ++n) {                               // uniform
-                    if (n < rlen[u]) {
-                        const int k = idx8[n * NMAX + tt];
-                        const float p = vst[n * NMAX + tt] * sm.b[k];
-                        acc += p;
-                    }
+                    const int k = idx8[n * NMAX + tt];
+                    const float p = vst[n * NMAX + tt] * sm.b[k];
+                    acc += n < rlen[u] ? p : 0.0f;
                 }
                 for (int n = nV; n < nA; ++n) {
-                    if (n < rlen[u]) {
-                        const int k = idx8[n * NMAX + tt];
-                        const float p = value(mine[u], k) * sm.b[k];
-                        acc += p;
-                    }
+                    const int k = idx8[n * NMAX + tt];
+                    const float p = value(mine[u], k) * sm.b[k];
+                    acc += n < rlen[u] ? p : 0.0f;
                 }
                 if (trip[u] > kIdxN) {
                     int w = cur_w[u];
