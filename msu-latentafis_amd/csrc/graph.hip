@@ -658,12 +658,11 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
                     uint32_t bits = cur_bits[u];
                     for (int n = kIdxN; n < trip[u]; ++n) {
                         while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }
-                        if (bits) {
-                            const int k = w * 32 + __ffs(bits) - 1;
-                            bits &= bits - 1;
-                            const float p = value(mine[u], k) * sm.b[k];
-                            acc += p;
-                        }
+                        const bool have = bits != 0u;                        // as above: no divergent region around the value, an ended row adds +0.0f
+                        const int k = (w * 32 + __ffs(bits) - 1) & 255;
+                        bits &= bits - 1;
+                        const float p = value(mine[u], k) * sm.b[k];
+                        acc += have ? p : 0.0f;
                     }
                 }
             }
