@@ -623,19 +623,20 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
             const uint32_t* hrow = sm.hb[t >= 0 ? t : 0];
             float acc = 0.0f;
             if (it == 0) {
-                int w = 0;
-                uint32_t bits = t >= 0 ? hrow[0] : 0u;
-                for (int n = 0; n < trip[u]; ++n) {                          // uniform
-                    if (n == kIdxN) { cur_w[u] = w; cur_bits[u] = bits; }    // uniform condition
-                    while (bits == 0u && w + 1 < Wn) { ++w; bits = t >= 0 ? hrow[w] : 0u; }   // next non-empty word of this lane's row
-                    if (bits) {
-                        const int k = w * 32 + __ffs(bits) - 1;
+                if (t >= 0) {                                                // lanes beyond the list sit the pass out: ONE divergent region, not one per step
+                    int w = 0;
+                    uint32_t bits = hrow[0];
+                    for (int n = 0; n < trip[u]; ++n) {                      // uniform
+                        if (n == kIdxN) { cur_w[u] = w; cur_bits[u] = bits; }    // uniform condition
+                        while (bits == 0u && w + 1 < Wn) { ++w; bits = hrow[w]; }   // next non-empty word of this lane's row
+                        const bool have = bits != 0u;                        // an ended row notes a stale index (never read: n >= its length) and adds +0.0f
+                        const int k = (w * 32 + __ffs(bits) - 1) & 255;
                         bits &= bits - 1;
                         const float h = value(mine[u], k);
                         if (n < kIdxN) idx8[n * NMAX + t] = (unsigned char)k;
                         if (n < kValN) vst[n * NMAX + t] = h;
                         const float p = h * sm.b[k];
-                        acc += p;
+                        acc += have ? p : 0.0f;
                     }
                 }
             } else {
