@@ -284,7 +284,8 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
             const bool many = (tu[blk] >= thr) | (u3 >= thr) | force[blk];
             const uint32_t desc = (f2u(tb[blk]) & 63u) | ((f2u(ts[blk]) & 63u) << 6) | ((f2u(b3) & 7u) << 12) | ((f2u(s3) & 7u) << 15) |
                                   ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
-            if (row_ok[blk]) rec[((size_t)tmpl * 2 + h) * R_pad + (size_t)(rb0 + blk) * 32 + col] = make_uint2(f2u(b3), desc);
+            // padding rows of a partial row block store too (their records are never read: R_pad covers them); only a row block beyond the last is skipped — a uniform test
+            if (rb0 + blk < n_rb) rec[((size_t)tmpl * 2 + h) * R_pad + (size_t)(rb0 + blk) * 32 + col] = make_uint2(f2u(b3), desc);
         }
         reset();
     };
