@@ -330,8 +330,8 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
 // Selection by bounds + exact evaluation.  Persistent workgroups of 8 waves (the fp32 codebook, 96 KB, in LDS); each wave draws
 // (latent, rolled) pairs from a counter and owns a 4 KB item list.
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kRfWaves = 16, kRfItems = 384;        // 96 KB codebook + 16 x 3 KB item lists = 144 KB of LDS; <= 128 VGPRs
-struct __align__(16) RfWave { unsigned short row[kRfItems]; unsigned short pt[kRfItems]; float val[kRfItems]; };
+constexpr int kRfWaves = 16, kRfItems = 384;        // 96 KB codebook + 16 x 3.75 KB item lists = 156 KB of LDS; <= 128 VGPRs
+struct __align__(16) RfWave { unsigned short row[kRfItems]; unsigned short pt[kRfItems]; unsigned short slot[kRfItems]; float val[kRfItems]; };
 
 __device__ __forceinline__ uint32_t ord_f32(float v) { const uint32_t b = f2u(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 // this wave's own LDS traffic in program order (the waves of the workgroup work on different pairs: no workgroup barrier may be used)
@@ -364,7 +364,8 @@ __device__ __forceinline__ void rf_argmax(float& v, int& i)             // value
 // stats (optional): [0] pairs, [1] rows, [2] active rows, [3] items evaluated, [4] rows evaluated in full, [5] rows whose exact maximum fell outside its bounds (must stay 0)
 __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, GalleryDev g, const float* __restrict__ cw32, const uint2* __restrict__ rec,
                                                                const float4* __restrict__ rowk, int R_pad, int all_rows, float* __restrict__ rm_val,
-                                                               int32_t* __restrict__ rm_arg, int32_t* __restrict__ task_ctr, unsigned long long* __restrict__ stats)
+                                                               int32_t* __restrict__ rm_arg, int32_t* __restrict__ task_ctr, unsigned long long* __restrict__ stats,
+                                                               float* __restrict__ rm_cv, int32_t* __restrict__ rm_n)
 {
     __shared__ float s_cw[kM * kK * kDsub];                             // 96 KB
     __shared__ RfWave s_w[kRfWaves];                                    // 32 KB
@@ -449,7 +450,8 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             }
         }
         // ---- C: candidate items of the active rows ------------------------------------------------------------------------
-        int n_items = 0;
+        int n_items = 0, n_act = 0;
+        const bool compact = rm_n != nullptr;
         unsigned long long st_active = 0, st_items = 0, st_full = 0;
         auto flush = [&]() {
             RF_WSYNC();
@@ -463,7 +465,8 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                         const float v = W.val[j]; const int p = W.pt[j];
                         if (v > bv || (v == bv && p < bp)) { bv = v; bp = p; }
                     }
-                    rm_val[o + row] = bv; rm_arg[o + row] = bp;
+                    rm_val[o + row] = bv;
+                    if (compact) { const int sl = W.slot[it]; rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else rm_arg[o + row] = bp;
                     if (stats) {                                        // self-check of the bounds: the exact row maximum must lie inside them
                         const float4 rk = rowk[l0 + row];
                         const float mid = rk.x + 2.0f * fmaxf(u2f(rec0[row].x), u2f(rec1[row].x));
@@ -486,7 +489,11 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 float lo, hi; bounds(e, ra, rb, lo, hi);
                 active = ord_f32(hi) >= C;
             }
-            if (in && !active) { rm_val[o + e] = -INFINITY; rm_arg[o + e] = 0; }
+            if (in && !active && !compact) { rm_val[o + e] = -INFINITY; rm_arg[o + e] = 0; }
+            // compact form: the active rows' (value, row | point << 16) side by side in row order (what S7 reads: a third of the rows), values also at their row (for the list's sums)
+            const unsigned long long am = __ballot(active);
+            const int my_slot = n_act + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0));
+            n_act += (int)__popcll(am);
             uint32_t pts[4]; int cnt = 0; bool full = false;
             if (active) {
                 const float tg = rowk[l0 + e].z;
@@ -525,7 +532,8 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 float bv = -INFINITY; int bp = 0x7fffffff;
                 for (int p = lane; p < n_rt; p += 64) { const float v = exact_sim(row, p); if (v > bv) { bv = v; bp = p; } }
                 rf_argmax(bv, bp);
-                if (lane == 0) { rm_val[o + row] = bv; rm_arg[o + row] = bp; }
+                const int sl = __shfl(my_slot, src);
+                if (lane == 0) { rm_val[o + row] = bv; if (compact) { rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else rm_arg[o + row] = bp; }
                 ++st_full;
             }
             // append this round's items, rows in ascending order (a row's items stay adjacent)
@@ -536,10 +544,11 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             if (n_items + total > kRfItems) flush();
             const int base = n_items + incl - cnt;
 #pragma unroll
-            for (int z = 0; z < 4; ++z) if (z < cnt) { W.row[base + z] = (unsigned short)e; W.pt[base + z] = (unsigned short)pts[z]; }
+            for (int z = 0; z < 4; ++z) if (z < cnt) { W.row[base + z] = (unsigned short)e; W.pt[base + z] = (unsigned short)pts[z]; W.slot[base + z] = (unsigned short)my_slot; }
             n_items += total;
         }
         flush();
+        if (compact && lane == 0) rm_n[task] = n_act;
         if (stats && lane == 0) {
             atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)n_lt); atomicAdd(stats + 2, st_active);
             atomicAdd(stats + 3, st_items); atomicAdd(stats + 4, st_full);
@@ -582,7 +591,7 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
 }
 
 hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
-                             float* rm_val, int32_t* rm_arg, unsigned long long* stats, hipStream_t stream)
+                             float* rm_val, int32_t* rm_arg, unsigned long long* stats, float* rm_cv, int32_t* rm_n, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * g.G;
     if (n_tasks <= 0) return hipSuccess;
@@ -591,7 +600,7 @@ hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float
     if (e0 != hipSuccess) return e0;
     const int grid = (int)std::min<long long>(256, (n_tasks + kRfWaves - 1) / kRfWaves);
     hipLaunchKernelGGL(k_tex_refine, dim3(grid), dim3(kRfWaves * 64), 0, stream, q, g, codewords, (const uint2*)rec, (const float4*)rowk, R_pad, all_rows,
-                       rm_val, rm_arg, g.task_ctr + 2, stats);
+                       rm_val, rm_arg, g.task_ctr + 2, stats, rm_cv, rm_n);
     return hipGetLastError();
 }
 

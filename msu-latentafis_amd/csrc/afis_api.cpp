@@ -77,14 +77,14 @@ struct afis_ctx {
     bool mf_cb_built = false, mf_gal_built = false;
     int mf_collect_stats = 0;
     DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // adc_variant 8: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step, margin), fp32 table
-    DevBuf lut, rm_val, rm_arg, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
+    DevBuf lut, rm_val, rm_arg, rm_cv, rm_n, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // adc_variant 8: consecutive chunks per tile on an XCD; 0 = 4 (the refine's fp32 table stays in L2)
     int query_batch = 0;                 // latents per launch group at most; 0 = by shard size (afis_queries_upload); adc_variant 9 places the cuts by latent texture rows
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
-    int64_t rowmax_budget_bytes = 24ll << 30;
+    int64_t rowmax_budget_bytes = 36ll << 30;   // row-maximum buffers of a launch group: 12 B per (pair, latent texture row) with the compact lists of adc_variant 9
     afis_timing timing = {};
 };
 
@@ -246,7 +246,7 @@ void afis_destroy(afis_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gallery_dev(c);
-    c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release();
+    c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release(); c->rm_cv.release(); c->rm_n.release();
     c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
     c->mf_cw16.release(); c->mf_cwn.release(); c->mf_bfrag.release(); c->mf_rowk.release(); c->mf_rec.release(); c->mf_stats.release();
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
@@ -589,9 +589,9 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     if (!ctx || !out || n_q < 0 || (n_q > 0 && !queries)) return fail(ctx, AFIS_EINVAL, "afis_queries_upload: bad argument");
     if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_queries_upload: commit the gallery first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // group size: bounded by the option and by the rowmax buffer budget (nq * G * 1000 rows * 8 B)
+    // group size: bounded by the option and by the rowmax buffer budget (nq * G * 1000 rows * 12 B)
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
-    int64_t by_mem = ctx->rowmax_budget_bytes / (G * kTexMax * 8);
+    int64_t by_mem = ctx->rowmax_budget_bytes / (G * kTexMax * 12);
     // latents per launch group: the option, or (0 = auto) as many as keep about two million (latent, rolled) pairs in a launch — 20 at a 100k-template
     // shard, 128 at <= 15k (a 12.5k-template shard: 100 latents in one launch 310.7 ms, in 64 + 36: 315.1): the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
     // each cost 1.2 x their share of a 100k-template step; 2 launches do not).  Measured at 100k templates, 100 latents: 7 per launch 2 495 ms, 10: 2 486,
@@ -686,7 +686,7 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
 
 // S4-S6 (+ the row selection of S7) of adc_variant 9 for one query group: row constants, matrix-core bound pass, selection by bounds and exact
 // recomputation.  all_rows: every row is evaluated exactly (parity taps); otherwise rows that cannot reach the pair's top 200 get -inf.
-static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr)
+static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr, bool compact = false)
 {
     const QueryDev& d = grp.dev;
     hipStream_t s = ctx->stream;
@@ -722,7 +722,8 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
                                 ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_rec.p, s));
     if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
     HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
-                                  ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr, s));
+                                  ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr,
+                                  compact ? ctx->rm_cv.as<float>() : nullptr, compact ? ctx->rm_n.as<int32_t>() : nullptr, s));
     return AFIS_OK;
 }
 
@@ -758,6 +759,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
             HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
             HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
+            if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
             HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
             // minutiae scratch per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs the fast kernel cannot take use it)
             size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
@@ -780,7 +782,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
             if (ctx->adc_variant == 9) {                                    // fp16 matrix-core bound pass + exact recomputation
-                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6]);
+                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true);
                 if (rc9 != AFIS_OK) return rc9;
             } else if (ctx->adc_variant == 8) {                             // 16-bit fixed-point LDS-table bound pass + exact refine
                 int rc16 = adc_stage_q(ctx, grp, chunk, true, ev[1]);
@@ -792,7 +794,9 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             }
             HIPCHK(ctx, hipEventRecord(ev[2], s));
-            HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
+            const bool compact9 = ctx->adc_variant == 9;                  // the recomputation kernel's compact list of the rows that matter (S7 reads a third of the rows)
+            HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), compact9 ? ctx->rm_cv.as<float>() : nullptr,
+                                             compact9 ? ctx->rm_n.as<int32_t>() : nullptr, ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
             HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
@@ -946,7 +950,7 @@ int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, flo
     if (width == 0 || G == 0) return AFIS_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int n_pq = std::max((n_minu + 2) / 3, n_tex);
-    const int64_t by_mem = std::max<int64_t>(1, ctx->rowmax_budget_bytes / (std::max<int64_t>(1, G) * kTexMax * 8));
+    const int64_t by_mem = std::max<int64_t>(1, ctx->rowmax_budget_bytes / (std::max<int64_t>(1, G) * kTexMax * 12));
     const int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch > 0 ? ctx->query_batch : 10, by_mem));
     std::vector<float> parts;
     for (int j0 = 0; j0 < n_pq; j0 += per) {
@@ -1171,7 +1175,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             one.tex_codes_cf = ctx->gal.tex_codes_cf;
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), av, s));
             HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, av, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
-            HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->parts.as<float>(),
+            HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), nullptr, nullptr, ctx->parts.as<float>(),
                                              d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
         } else {
             slot = which - 1; cap = kTopMinu;

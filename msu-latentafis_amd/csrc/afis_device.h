@@ -122,12 +122,12 @@ hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream);
 hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
-                             float* rm_val, int32_t* rm_arg, unsigned long long* stats, hipStream_t stream);
+                             float* rm_val, int32_t* rm_arg, unsigned long long* stats, float* rm_cv, int32_t* rm_n, hipStream_t stream);
 // one correspondence of a minutiae-template list (S3 output), 8 bytes
 struct MinuCand { float sim; short li, ri; };
 // S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
-                                const float* rm_val, const int32_t* rm_arg, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
+                                const float* rm_val, const int32_t* rm_arg, const float* rm_cv, const int32_t* rm_n, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
 // (task = (q*3+s)*G + g).  Pairs with <= 64 latent and <= 128 rolled minutiae go through the rolled-template-stationary MFMA kernel;
 // what it cannot take (other shapes, degenerate key distributions) it appends to `fallback` ([1 + n_tasks] ints: count, task ids), which the

@@ -875,6 +875,7 @@ constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAVES, AFIS_TEX_WAVES))) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
                                                       const float* __restrict__ rm_val, const int32_t* __restrict__ rm_arg,
+                                                      const float* __restrict__ rm_cv, const int32_t* __restrict__ rm_n,
                                                       float* __restrict__ parts, GraphTap tap)
 {
     __shared__ TexSmem sm;
@@ -893,14 +894,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
         const size_t o = (size_t)task * q.lt_pad;
         int num;
         if (n_lt > kTopTex) {                                            // :736-747: the 200 rows with the largest maxima
-            const int n_regs = (n_lt + 63) >> 6;                         // registers per lane that hold a row (uniform)
+            // compact form (adc_variant 9): the rows that can be among the 200 — a third of them — side by side in row order as (value, row | point << 16);
+            // otherwise every row's value and point at its row, -inf for rows that cannot
+            const bool compact = rm_n != nullptr;
+            const int n_in = compact ? rm_n[task] : n_lt;                // >= 200: the selection keeps at least the 200 rows with the largest lower bounds
+            const int n_regs = (n_in + 63) >> 6;                         // registers per lane that hold a row (uniform)
             uint32_t key[kTexRegs]; int arg[kTexRegs];
 #pragma unroll
             for (int u = 0; u < kTexRegs; ++u) {
                 const int e = u * 64 + lane;
-                const bool in = e < n_lt;
-                key[u] = in ? g_ord_f32(rm_val[o + e]) : 0u;             // real keys are never 0
-                arg[u] = in ? rm_arg[o + e] : 0;                         // fetched with the values: one round trip, not one per picked row
+                const bool in = e < n_in;
+                key[u] = 0u; arg[u] = 0;                                 // real keys are never 0
+                if (u < n_regs) {                                        // uniform
+                    key[u] = in ? g_ord_f32(compact ? rm_cv[o + e] : rm_val[o + e]) : 0u;
+                    arg[u] = in ? rm_arg[o + e] : 0;                     // fetched with the values: one round trip, not one per picked row
+                }
             }
             uint32_t T = 0;                                              // 200th largest key, built bit by bit ...
             for (int bit = 31; bit >= 0; --bit) {
@@ -925,7 +933,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
                     int pos = -1;
                     if (gt) pos = base_gt + g_lane_prefix(mg);
                     else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
-                    if (pos >= 0) { key32[pos] = key[u]; sm.x.pick.te[pos] = (short)e; sm.x.pick.targ[pos] = (short)arg[u]; }
+                    if (pos >= 0) { key32[pos] = key[u]; sm.x.pick.te[pos] = (short)(compact ? arg[u] & 0xffff : e); sm.x.pick.targ[pos] = (short)(compact ? arg[u] >> 16 : arg[u]); }
                     base_gt += __popcll(mg); base_eq += __popcll(me);
                 }
             }
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
             }
         } else {                                                         // :748-749 rows stay in index order
             num = n_lt;
-            for (int t = lane; t < num; t += 64) { sm.li[t] = (short)t; sm.ri[t] = (short)rm_arg[o + t]; }
+            for (int t = lane; t < num; t += 64) { sm.li[t] = (short)t; sm.ri[t] = (short)(rm_n ? rm_arg[o + t] >> 16 : rm_arg[o + t]); }   // compact form: every row is listed, slot = row
         }
         WSYNC();
         int out_of_range = 0, not_small = 0;                             // any block coordinate outside [0, 2047]: generic arithmetic for this list;
@@ -1032,7 +1040,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
 }
 
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
-                                const float* rm_val, const int32_t* rm_arg, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream)
+                                const float* rm_val, const int32_t* rm_arg, const float* rm_cv, const int32_t* rm_n, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * g.G;
     if (n_tasks <= 0) return hipSuccess;
@@ -1040,7 +1048,7 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
     const int grid = (int)(n_tasks < 16384 ? n_tasks : 16384);
     hipError_t e0 = hipMemsetAsync(g.task_ctr + 0, 0, 4, stream);
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, parts, GraphTap{tap_out, tap_n, tap_stage});
+    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, rm_cv, rm_n, parts, GraphTap{tap_out, tap_n, tap_stage});
     return hipGetLastError();
 }
 
