@@ -80,6 +80,10 @@ typedef struct afis_timing {
     int64_t pairs;         /* (query, gallery template) pairs scored                    */
     float   adc_bound_ms;  /* part of adc_ms: the bound pass over every cell (adc_variant 8: the whole kernel; 9: k_adc_mfma) */
     float   adc_refine_ms; /* part of adc_ms: adc_variant 9's selection + exact recomputation kernel; 0 otherwise             */
+    float   cands_ms;      /* part of minu_ms: S1-S3 (descriptor GEMM, normalisation, top-120 candidates)                      */
+    float   minu_graph_ms; /* part of minu_ms: S8a + S9 on the minutiae correspondence lists                                   */
+    int32_t launch_groups; /* launch groups the queries were cut into                                                          */
+    int32_t reserved_;
 } afis_timing;
 
 /* Replaces PQ::Matcher::Matcher(code_file) (matcher.cpp:31-94).  codewords = [M][K][dsub] fp32 exactly as stored
@@ -184,7 +188,11 @@ int afis_encode_rolled_dat(afis_ctx* ctx, const void* bytes, size_t len, void* o
 int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const int64_t* gallery_idx, int n,
                          int32_t* counts /*[n][3]*/, int16_t* xy /*[n][3][120][4]*/);
 
+/* afis_get_timing2 copies min(struct_size, sizeof(afis_timing)) bytes: pass sizeof(afis_timing) of the header the caller was compiled
+ * against, so that a library with a longer struct never writes past the caller's.  afis_get_timing (kept for callers of the round-2
+ * header) fills only the fields up to `pairs` (48 bytes, the struct of that header); the fields after it need afis_get_timing2. */
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
+int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
 /* Tunables: "adc_variant" — every variant gives bit-identical results: 9 [default] = an fp16 matrix-core pass over all (latent row, rolled
  * point) cells bounds every row maximum and pins its candidate points; the rows that can reach a pair's top 200 then get the exact fp32
  * value of their candidates, the table entries recomputed in the reference's arithmetic and order (adc_mfma.hip) — 0.62 x the time of 8;
@@ -198,38 +206,9 @@ int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
  * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
 
-/* Parity-test taps (stage intermediates; not needed by a production caller). */
-/* S4: the per-query LUT of queries[0].tex[0], out = [n][16][256] in the reference's m_dist_codewords layout. */
-int afis_debug_lut(afis_ctx* ctx, const afis_template_view* query, float* out, int32_t* n_rows);
-/* S5+S6: row maxima / first arg-max of latent texture 0 vs gallery template g (g is shard-local). */
-int afis_debug_texture_rowmax(afis_ctx* ctx, const afis_template_view* query, int64_t g,
-                              float* val, int32_t* arg, int32_t* n_rows);
-
-/* S3 / S7 / S8 / S9: the correspondence list of (query, gallery template g) inside one scorer, as (sim, latent index, rolled
- * index) triples in list order.  which: 0 = texture scorer, 1..3 = minutiae scorer of selected latent template 27 / 3 / 12;
- * stage: 0 = the candidates (top 120 / top 200), 1 = after the distance filter, 2 = after the angle filter.  Capacity 200.
- * *n = -1 when the reference does not run that scorer for the pair. */
-int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_t g, int which, int stage,
-                          float* sim, int32_t* li, int32_t* ri, int32_t* n);
-
-/* S9: the angle stage's atan2 (matching/matcher.cpp:1516, :1524) on every integer coordinate difference of the grid
- * [-R, R]^2: out[(dy + R) * (2R + 1) + (dx + R)] = line angle atan2(dy, dx) as the device evaluates it.  R <= 4096. */
-int afis_debug_atan2_grid(afis_ctx* ctx, int R, float* out);
-
-/* S8: the distance stage's packed arithmetic (csrc/graph_arith.h: a one-transcendental correctly rounded square root of integers and
- * a square-root-free "H != 0" test with a guard band) against the plain evaluation of matching/matcher.cpp:1246-1272, :1372-1393 that
- * it replaces, on the device.  out8[0] = integers n in [0, 2*2047^2] whose root differs; out8[1..3] = texture pairs checked (all of
- * [0, 4802]^2), pairs inside the guard band, wrong decisions; out8[4..6] = the same for minutiae pairs near the 30 px threshold
- * (4e8 of them).  out8[0], [3], [6] must be 0. */
-int afis_debug_graph_arith(afis_ctx* ctx, unsigned long long* out8);
-/* adc_variant 9 with afis_set_option("mf_stats", 1): counters of the selection / recomputation kernel since the last reset:
- * out8[0] pairs, [1] latent rows, [2] rows evaluated exactly, [3] candidate cells evaluated, [4] rows evaluated over every point,
- * [5] rows whose exact maximum lay outside the bounds the selection used (a self-check: must be 0). */
-int afis_debug_refine_stats(afis_ctx* ctx, unsigned long long* out8, int reset);
-
-/* In-kernel phase timers (only when the library is built with PHASE_TIMING=1; all zeros otherwise): 32 cycle counters
- * accumulated since the last reset.  Development aid. */
-int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset);
+/* The parity-test taps (stage intermediates: afis_debug_*) are NOT part of this library: they are declared in
+ * include/afis_matcher_taps.h and exported only by libafis_hip_test.so (the same objects with afis_api.cpp built -DAFIS_PARITY_TAPS),
+ * which tests/ load.  libafis_hip.so exports exactly the functions declared above. */
 
 #ifdef __cplusplus
 }

@@ -1,9 +1,13 @@
 // afis_api.cpp — implementation of the C ABI in include/afis_matcher.h: gallery packing (SoA), upload, query
 // grouping and the launch sequence of the HIP kernels.  Host C++ only; device code lives in adc.hip, minu.hip, graph.hip and pq_encode.hip.
 #include "../../include/afis_matcher.h"
+#ifdef AFIS_PARITY_TAPS
+#include "../../include/afis_matcher_taps.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -56,7 +60,7 @@ struct afis_queries {
 struct afis_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> evpool;      // 7 per query group + 2: the groups of a search run back to back, timings are read at the end
+    std::vector<hipEvent_t> evpool;      // 8 per query group + 2: the groups of a search run back to back, timings are read at the end
     std::string err;
     DevBuf codewords, table;
     HostGallery hg;
@@ -84,7 +88,7 @@ struct afis_ctx {
     int query_batch = 0;                 // latents per launch group at most; 0 = by shard size (afis_queries_upload); adc_variant 9 places the cuts by latent texture rows
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
-    int64_t rowmax_budget_bytes = 36ll << 30;   // row-maximum buffers of a launch group: 12 B per (pair, latent texture row) with the compact lists of adc_variant 9
+    int64_t rowmax_budget_bytes = 0;     // device memory a launch group's per-pair buffers may take (option rowmax_budget_mb); 0 = 60 % of what hipMemGetInfo reports free
     afis_timing timing = {};
 };
 
@@ -188,6 +192,24 @@ std::vector<float> fragment_tiles(const std::vector<float>& des, const std::vect
         }
     });
     return out;
+}
+
+// Device bytes one latent of a launch group costs at worst (1000 texture rows): row maxima (value, point, compact list: 12 B per (pair, row)),
+// adc_variant 9's bound-pass records (kMfRecBytes per (template, row)), the minutiae candidate lists and the per-part scores.
+constexpr int64_t kMfRecBytesPerRow = 16;
+int64_t group_bytes_per_query(const afis_ctx* ctx, int64_t G)
+{
+    const int64_t per_pair = (int64_t)kTexMax * 12 + (ctx->adc_variant == 9 ? (int64_t)kTexMax * kMfRecBytesPerRow : 0) + 3 * (int64_t)kTopMinu * (int64_t)sizeof(MinuCand) + 3 * 4 + 16 + 8;
+    return std::max<int64_t>(1, G) * per_pair;
+}
+// What a launch group may take: the option, or 60 % of the free device memory (buffers this context already holds for earlier groups are reused, so they count as free).
+int64_t group_budget_bytes(const afis_ctx* ctx)
+{
+    if (ctx->rowmax_budget_bytes > 0) return ctx->rowmax_budget_bytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 36ll << 30;
+    const size_t held = ctx->rm_val.bytes + ctx->rm_arg.bytes + ctx->rm_cv.bytes + ctx->rm_n.bytes + ctx->mf_rec.bytes + ctx->cands.bytes + ctx->cand_n.bytes + ctx->parts.bytes + ctx->minu_fb.bytes;
+    return std::max<int64_t>(1ll << 30, (int64_t)((double)(free_b + held) * 0.6));
 }
 
 void free_gallery_dev(afis_ctx* c)
@@ -589,9 +611,9 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     if (!ctx || !out || n_q < 0 || (n_q > 0 && !queries)) return fail(ctx, AFIS_EINVAL, "afis_queries_upload: bad argument");
     if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_queries_upload: commit the gallery first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    // group size: bounded by the option and by the rowmax buffer budget (nq * G * 1000 rows * 12 B)
+    // group size: bounded by the option and by the memory budget of a group's per-pair buffers
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
-    int64_t by_mem = ctx->rowmax_budget_bytes / (G * kTexMax * 12);
+    const int64_t by_mem = group_budget_bytes(ctx) / group_bytes_per_query(ctx, G);
     // latents per launch group: the option, or (0 = auto) as many as keep about two million (latent, rolled) pairs in a launch — 20 at a 100k-template
     // shard, 128 at <= 15k (a 12.5k-template shard: 100 latents in one launch 310.7 ms, in 64 + 36: 315.1): the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
     // each cost 1.2 x their share of a 100k-template step; 2 launches do not).  Measured at 100k templates, 100 latents: 7 per launch 2 495 ms, 10: 2 486,
@@ -746,14 +768,14 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     // The groups run back to back on the stream: no host round trip between them.  Scores of ALL queries stay on the device
     // ([n_q][G]) for the rank-list kernel; they cross PCIe only when the caller asks for them.
     const size_t n_groups = q->groups.size();
-    while (ctx->evpool.size() < n_groups * 7 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
+    while (ctx->evpool.size() < n_groups * 8 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
     if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
     int q0 = 0;
     size_t gi = 0;
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
-        hipEvent_t* ev = &ctx->evpool[gi * 7];
+        hipEvent_t* ev = &ctx->evpool[gi * 8];
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
@@ -799,6 +821,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                                              compact9 ? ctx->rm_n.as<int32_t>() : nullptr, ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
             HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
+            HIPCHK(ctx, hipEventRecord(ev[7], s));
             HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[4], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), grp_scores, s));
@@ -817,7 +840,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     }
     // ---- rank lists (matcher.cpp:306-309; ties by ascending index) ----
     const bool dev_topk = k > 0 && k <= kDeviceTopK && G > 0 && nq_all > 0;
-    hipEvent_t* evk = &ctx->evpool[n_groups * 7];
+    hipEvent_t* evk = &ctx->evpool[n_groups * 8];
     if (dev_topk) {
         HIPCHK(ctx, ctx->topk_idx.ensure((size_t)nq_all * k * 8));
         HIPCHK(ctx, ctx->topk_score.ensure((size_t)nq_all * k * 4));
@@ -836,7 +859,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (G > 0) {
         for (size_t i = 0; i < n_groups; ++i) {
-            hipEvent_t* ev = &ctx->evpool[i * 7];
+            hipEvent_t* ev = &ctx->evpool[i * 8];
             float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
             for (int j = 0; j < 5; ++j) HIPCHK(ctx, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
             HIPCHK(ctx, hipEventElapsedTime(&tot, ev[0], ev[5]));
@@ -845,6 +868,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, hipEventElapsedTime(&tb_, ev[1], ev[6])); HIPCHK(ctx, hipEventElapsedTime(&tr_, ev[6], ev[2]));
                 tm.adc_bound_ms += tb_; tm.adc_refine_ms += tr_;
             } else tm.adc_bound_ms += ms[1];
+            { float tc_ = 0, tg_ = 0; HIPCHK(ctx, hipEventElapsedTime(&tc_, ev[3], ev[7])); HIPCHK(ctx, hipEventElapsedTime(&tg_, ev[7], ev[4])); tm.cands_ms += tc_; tm.minu_graph_ms += tg_; }
             tm.lut_ms += ms[0]; tm.adc_ms += ms[1]; tm.tex_tail_ms += ms[2]; tm.minu_ms += ms[3]; tm.fuse_ms += ms[4]; tm.total_ms += tot;
         }
         if (dev_topk) { float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, evk[0], evk[1])); tm.topk_ms = t; tm.total_ms += t; }
@@ -863,6 +887,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             }
         }
     }
+    tm.launch_groups = (int32_t)n_groups;
     ctx->timing = tm;
     return AFIS_OK;
 }
@@ -950,7 +975,7 @@ int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, flo
     if (width == 0 || G == 0) return AFIS_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int n_pq = std::max((n_minu + 2) / 3, n_tex);
-    const int64_t by_mem = std::max<int64_t>(1, ctx->rowmax_budget_bytes / (std::max<int64_t>(1, G) * kTexMax * 12));
+    const int64_t by_mem = std::max<int64_t>(1, group_budget_bytes(ctx) / group_bytes_per_query(ctx, G));
     const int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch > 0 ? ctx->query_batch : 10, by_mem));
     std::vector<float> parts;
     for (int j0 = 0; j0 < n_pq; j0 += per) {
@@ -1008,10 +1033,16 @@ int afis_search_dat(afis_ctx* ctx, const void* const* latent_bytes, const size_t
     return afis_search(ctx, views.data(), n_q, scores, parts, status, k, topk_idx, topk_score);
 }
 
+// The round-2 header's struct ended at `pairs` (48 bytes); a caller compiled against it must not be written past that.
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out)
 {
-    if (!ctx || !out) return AFIS_EINVAL;
-    *out = ctx->timing;
+    return afis_get_timing2(ctx, out, offsetof(afis_timing, pairs) + sizeof(int64_t));
+}
+
+int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size)
+{
+    if (!ctx || !out || struct_size < sizeof(float)) return AFIS_EINVAL;
+    memcpy(out, &ctx->timing, std::min(struct_size, sizeof(afis_timing)));
     return AFIS_OK;
 }
 
@@ -1031,6 +1062,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     return AFIS_OK;
 }
 
+#ifdef AFIS_PARITY_TAPS   // the parity taps exist only in libafis_hip_test.so (include/afis_matcher_taps.h)
 int afis_debug_phase_cycles(afis_ctx* ctx, unsigned long long* out32, int reset)
 {
     if (!ctx || !out32) return AFIS_EINVAL;
@@ -1199,5 +1231,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
     d_out.release(); d_n.release(); grp.release();
     return rc;
 }
+
+#endif  // AFIS_PARITY_TAPS
 
 }  // extern "C"

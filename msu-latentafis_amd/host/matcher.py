@@ -16,7 +16,8 @@ import numpy as np
 from .templates import Codebook, FPTemplate, read_latent, read_rolled
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libafis_hip.so")
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libafis_hip.so")            # the product: include/afis_matcher.h, nothing else
+TEST_LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libafis_hip_test.so")  # the same objects + the parity taps (include/afis_matcher_taps.h); tests only
 
 
 class AfisError(RuntimeError):
@@ -39,13 +40,16 @@ class TemplateView(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("lut_ms", C.c_float), ("adc_ms", C.c_float), ("tex_tail_ms", C.c_float), ("minu_ms", C.c_float), ("fuse_ms", C.c_float), ("topk_ms", C.c_float),
-                ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64), ("adc_bound_ms", C.c_float), ("adc_refine_ms", C.c_float)]
+                ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64), ("adc_bound_ms", C.c_float), ("adc_refine_ms", C.c_float),
+                ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("reserved_", C.c_int32)]
 
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_set_option", "afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles", "afis_debug_atan2_grid", "afis_debug_graph_arith", "afis_debug_refine_stats"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option"]
+# include/afis_matcher_taps.h: exported by libafis_hip_test.so only
+TAP_EXPORTS = ["afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles", "afis_debug_atan2_grid", "afis_debug_graph_arith", "afis_debug_refine_stats"]
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -74,16 +78,19 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_correspondences.argtypes = [vp, vp, i64p, C.c_int, i32p, C.POINTER(C.c_int16)]
     lib.afis_queries_free.argtypes = [vp, vp]; lib.afis_queries_free.restype = None
     lib.afis_match_all_templates.argtypes = [vp, vp, fp, i32p, i32p]
-    lib.afis_debug_stage_list.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, fp, i32p, i32p, i32p]
     lib.afis_pq_encode.argtypes = [vp, fp, C.c_int64, C.POINTER(C.c_uint8)]
     lib.afis_encode_rolled_dat.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), i32p]
     lib.afis_get_timing.argtypes = [vp, C.POINTER(Timing)]
+    if hasattr(lib, "afis_get_timing2"):                                # absent from older builds compared by tools/lib_ab.py
+        lib.afis_get_timing2.argtypes = [vp, C.POINTER(Timing), C.c_size_t]
     lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
-    lib.afis_debug_lut.argtypes = [vp, C.POINTER(TemplateView), fp, i32p]
-    lib.afis_debug_texture_rowmax.argtypes = [vp, C.POINTER(TemplateView), C.c_int64, fp, i32p, i32p]
-    lib.afis_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
-    lib.afis_debug_atan2_grid.argtypes = [vp, C.c_int, fp]
-    if hasattr(lib, "afis_debug_graph_arith"):                          # absent from older builds compared by tools/lib_ab.py; tests/test_host.py checks the exports
+    if hasattr(lib, "afis_debug_stage_list"):                           # the parity taps: libafis_hip_test.so (and older builds) only
+        lib.afis_debug_stage_list.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, fp, i32p, i32p, i32p]
+        lib.afis_debug_lut.argtypes = [vp, C.POINTER(TemplateView), fp, i32p]
+        lib.afis_debug_texture_rowmax.argtypes = [vp, C.POINTER(TemplateView), C.c_int64, fp, i32p, i32p]
+        lib.afis_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        lib.afis_debug_atan2_grid.argtypes = [vp, C.c_int, fp]
+    if hasattr(lib, "afis_debug_graph_arith"):
         lib.afis_debug_graph_arith.argtypes = [vp, C.POINTER(C.c_ulonglong)]
     if hasattr(lib, "afis_debug_refine_stats"):
         lib.afis_debug_refine_stats.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
@@ -125,8 +132,10 @@ class _Views:
 class Matcher:
     """`PQ::Matcher` (matching/matcher.h:35) on one MI355X.  One instance = one device = one gallery shard."""
 
-    def __init__(self, code_file, device: int = 0, lib_path: str = LIB_PATH):
-        self.lib = load_library(lib_path)
+    def __init__(self, code_file, device: int = 0, lib_path: Optional[str] = None, taps: bool = False):
+        """taps=True loads libafis_hip_test.so (the product objects + the afis_debug_* parity taps); the default is the product library."""
+        self.lib = load_library(lib_path or (TEST_LIB_PATH if taps else LIB_PATH))
+        self.has_taps = hasattr(self.lib, "afis_debug_stage_list")
         if isinstance(code_file, Codebook):
             buf = code_file.to_bytes()
         elif isinstance(code_file, (bytes, bytearray)):
@@ -292,36 +301,44 @@ class Matcher:
 
     def timing(self) -> dict:
         t = Timing()
-        self._chk(self.lib.afis_get_timing(self.ctx, C.byref(t)))
-        return {n: getattr(t, n) for n, _ in Timing._fields_}
+        if hasattr(self.lib, "afis_get_timing2"):
+            self._chk(self.lib.afis_get_timing2(self.ctx, C.byref(t), C.sizeof(Timing)))
+        else:
+            self._chk(self.lib.afis_get_timing(self.ctx, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Timing._fields_ if n != "reserved_"}
+
+    def _tap(self, name: str):
+        if not hasattr(self.lib, name):
+            raise AfisError(f"{name} is a parity tap: construct Matcher(..., taps=True) (libafis_hip_test.so); the product library does not export it")
+        return getattr(self.lib, name)
 
     def phase_cycles(self, reset: bool = True):
         out = (C.c_uint64 * 32)()
-        self._chk(self.lib.afis_debug_phase_cycles(self.ctx, out, 1 if reset else 0))
+        self._chk(self._tap("afis_debug_phase_cycles")(self.ctx, out, 1 if reset else 0))
         return list(out)
 
     # ---- parity taps ------------------------------------------------------------------------------------------
     def debug_atan2_grid(self, R: int) -> np.ndarray:
         out = np.empty((2 * R + 1, 2 * R + 1), np.float32)
-        self._chk(self.lib.afis_debug_atan2_grid(self.ctx, R, _ptr(out, C.c_float)))
+        self._chk(self._tap("afis_debug_atan2_grid")(self.ctx, R, _ptr(out, C.c_float)))
         return out
 
     def debug_graph_arith(self) -> list:
         out = (C.c_ulonglong * 8)()
-        self._chk(self.lib.afis_debug_graph_arith(self.ctx, out))
+        self._chk(self._tap("afis_debug_graph_arith")(self.ctx, out))
         return list(out)
 
     def refine_stats(self, reset: bool = True) -> dict:
         """adc_variant 9 with set_option("mf_stats", 1): what the selection / recomputation kernel did since the last reset."""
         out = (C.c_ulonglong * 8)()
-        self._chk(self.lib.afis_debug_refine_stats(self.ctx, out, 1 if reset else 0))
+        self._chk(self._tap("afis_debug_refine_stats")(self.ctx, out, 1 if reset else 0))
         return dict(zip(("pairs", "rows", "rows_evaluated", "cells_evaluated", "rows_evaluated_in_full", "bound_violations"), list(out)[:6]))
 
     def debug_stage_list(self, latent: FPTemplate, g: int, which: int, stage: int):
         """(sim, li, ri) of the scorer's correspondence list after a stage (None when the scorer is not run)."""
         v = _Views([latent])
         sim = np.zeros(200, np.float32); li = np.zeros(200, np.int32); ri = np.zeros(200, np.int32); n = C.c_int32(0)
-        self._chk(self.lib.afis_debug_stage_list(self.ctx, v.arr, g, which, stage, _ptr(sim, C.c_float), _ptr(li, C.c_int32), _ptr(ri, C.c_int32), C.byref(n)))
+        self._chk(self._tap("afis_debug_stage_list")(self.ctx, v.arr, g, which, stage, _ptr(sim, C.c_float), _ptr(li, C.c_int32), _ptr(ri, C.c_int32), C.byref(n)))
         if n.value < 0:
             return None
         return sim[:n.value], li[:n.value], ri[:n.value]
@@ -330,13 +347,13 @@ class Matcher:
         v = _Views([latent])
         n = latent.tex[0].n if latent.tex else 0
         out = np.empty((max(n, 1), 16, 256), np.float32); nr = C.c_int32(0)
-        self._chk(self.lib.afis_debug_lut(self.ctx, v.arr, _ptr(out, C.c_float), C.byref(nr)))
+        self._chk(self._tap("afis_debug_lut")(self.ctx, v.arr, _ptr(out, C.c_float), C.byref(nr)))
         return out[:nr.value]
 
     def debug_texture_rowmax(self, latent: FPTemplate, g: int):
         v = _Views([latent])
         val = np.zeros(1000, np.float32); arg = np.zeros(1000, np.int32); nr = C.c_int32(0)
-        self._chk(self.lib.afis_debug_texture_rowmax(self.ctx, v.arr, g, _ptr(val, C.c_float), _ptr(arg, C.c_int32), C.byref(nr)))
+        self._chk(self._tap("afis_debug_texture_rowmax")(self.ctx, v.arr, g, _ptr(val, C.c_float), _ptr(arg, C.c_int32), C.byref(nr)))
         return val[:nr.value], arg[:nr.value]
 
     # ---- the reference's drivers (matching/matcher.cpp:96-337) ---------------------------------------------------

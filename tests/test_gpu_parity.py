@@ -31,8 +31,8 @@ def small(cb):
     return cases.small_set(cb)
 
 
-def _matcher(codebook_bytes, gal, variant=None):
-    m = M.Matcher(codebook_bytes)
+def _matcher(codebook_bytes, gal, variant=None, taps=False):
+    m = M.Matcher(codebook_bytes, taps=taps)        # taps: libafis_hip_test.so (the product objects + afis_debug_*); default = the product library
     if variant is not None:
         m.set_option("adc_variant", variant)
     m.gallery_add(gal)
@@ -42,7 +42,7 @@ def _matcher(codebook_bytes, gal, variant=None):
 
 def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
     lats, gal = small
-    m = _matcher(codebook_bytes, gal[:2])
+    m = _matcher(codebook_bytes, gal[:2], taps=True)
     ocb = oracle.codebook(codebook_bytes)
     for L in lats:
         got = m.debug_lut(L)
@@ -54,7 +54,7 @@ def test_lut_bit_exact(codebook_bytes, cb, oracle, small):
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9])
 def test_rowmax_bit_exact(codebook_bytes, cb, oracle, small, variant):
     lats, gal = small
-    m = _matcher(codebook_bytes, gal, variant)
+    m = _matcher(codebook_bytes, gal, variant, taps=True)
     ocb = oracle.codebook(codebook_bytes)
     hl, hr = cases.to_orc(oracle, ocb, lats, gal)
     for qi in range(len(lats)):
@@ -273,7 +273,7 @@ def test_stage_lists_match_oracle_traces(codebook_bytes, cb, oracle, small):
     against the oracle's traces: same members, same order, same raw similarities (bit for bit).  Final scores alone would not
     notice a 1-ulp slip inside the graph stages; this does as soon as a selection changes."""
     lats, gal = small
-    m = _matcher(codebook_bytes, gal)
+    m = _matcher(codebook_bytes, gal, taps=True)
     ocb = oracle.codebook(codebook_bytes)
     hl, hr = cases.to_orc(oracle, ocb, lats, gal)
     n_lists = n_nonempty_final = 0
@@ -367,7 +367,7 @@ def test_candidate_selection_degenerate_keys(codebook_bytes, cb, oracle):
     ]
     ocb = oracle.codebook(codebook_bytes)
     for ci, (L, R) in enumerate(cases_):
-        m = M.Matcher(codebook_bytes); m.gallery_add([R]); m.gallery_commit(0)
+        m = M.Matcher(codebook_bytes, taps=True); m.gallery_add([R]); m.gallery_commit(0)
         hl, _ = oracle.latent(ocb, T.write_latent(L)); hr, _ = oracle.rolled(T.write_rolled(R))
         for stage in (0, 1, 2):
             want = oracle.trace(ocb, hl, hr, which=1, stage=stage, tie_mode=1)
@@ -430,7 +430,7 @@ def test_texture_coordinates_off_the_beaten_path(codebook_bytes, cb, oracle):
         R0 = S.make_mate(rng, cb, base, frac=0.7, n_tex=500)
         rx, ry = spread(R0.tex[0], scale, off_r)
         R = T.FPTemplate(minu=list(R0.minu), tex=[T.TextureTemplate(rx, ry, R0.tex[0].ori, codes=R0.tex[0].codes)])
-        m = M.Matcher(codebook_bytes); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
+        m = M.Matcher(codebook_bytes, taps=True); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
         hl, _ = oracle.latent(ocb, T.write_latent(L)); hr, _ = oracle.rolled(T.write_rolled(R))
         for stage in (0, 1, 2):
             want = oracle.trace(ocb, hl, hr, which=0, stage=stage, tie_mode=1)
@@ -451,7 +451,7 @@ def test_texture_top200_with_tied_row_maxima(codebook_bytes, cb, oracle):
     base = S.make_latent(rng, n_tex_lo=330, n_tex_hi=360)
     R = S.make_mate(rng, cb, base, frac=0.7, n_tex=600)
     ocb = oracle.codebook(codebook_bytes)
-    m = M.Matcher(codebook_bytes); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
+    m = M.Matcher(codebook_bytes, taps=True); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
     hr, _ = oracle.rolled(T.write_rolled(R))
     t0 = base.tex[0]
     n = len(t0.x)
@@ -773,7 +773,7 @@ def test_angle_stage_atan2_equals_libm_on_every_coordinate_difference(codebook_b
     as the CPU's atan2f" is checked here EXHAUSTIVELY over every (dy, dx) with |dy|, |dx| <= 2047 — the whole range of
     minutiae pixel coordinates (images up to 2048 px; the generator's are 768 x 800) and of texture block coordinates."""
     R = 2047
-    m = M.Matcher(codebook_bytes)
+    m = M.Matcher(codebook_bytes, taps=True)
     got = m.debug_atan2_grid(R)
     m.close()
     want = oracle.atan2f_grid(R)
@@ -787,7 +787,7 @@ def test_distance_stage_packed_arithmetic_equals_the_plain_evaluation(codebook_b
     band.  Both are compared on the device with the plain evaluation (correctly rounded roots, float subtraction, compare): every
     integer up to 2 * 2047^2; every texture pair of [0, 4802]^2 (|d| < 50 blocks per axis, matcher.cpp:1257); 4e8 minutiae pairs
     within +-12 of the 30 px threshold.  Not one root and not one decision may differ; the band must stay a rare case."""
-    m = M.Matcher(codebook_bytes)
+    m = M.Matcher(codebook_bytes, taps=True)
     c = m.debug_graph_arith()
     m.close()
     assert c[0] == 0, c
@@ -839,7 +839,7 @@ def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes,
     """adc_variant 8 (16-bit bound pass + exact evaluation of the candidates) against the direct exact kernel (7): every row maximum and
     every first arg-max of 6 latents x 40 gallery templates (about 160 000 rows), bit for bit."""
     lats, gal, planted = medium
-    m = M.Matcher(codebook_bytes)
+    m = M.Matcher(codebook_bytes, taps=True)
     m.gallery_add_packed(gal); m.gallery_commit(0)
     rng = np.random.default_rng(8)
     n = 0
@@ -879,7 +879,7 @@ def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
     enc = np.repeat(cb.encode(des[:350]), 2, axis=0)[:n].astype(np.uint8)                         # every latent row's best code, twice
     gal = [rolled(same), rolled(two), rolled(near), rolled(near2), rolled(enc), rolled(rng.integers(0, 256, (65, 16)).astype(np.uint8)),
            rolled(rng.integers(0, 256, (1, 16)).astype(np.uint8))]
-    m = _matcher(codebook_bytes, gal)
+    m = _matcher(codebook_bytes, gal, taps=True)
     for g in range(len(gal)):
         m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
         for v in (8, 9):
@@ -910,7 +910,7 @@ def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_b
     near = np.tile(cb.encode(lt.des[7:8]), (n, 1)).astype(np.uint8)
     near[np.arange(n), rng.integers(0, 16, n)] = rng.integers(0, 256, n).astype(np.uint8)
     gal = [rolled(rng.integers(0, 256, (n, 16)).astype(np.uint8)), rolled(near), rolled(rng.integers(0, 256, (130, 16)).astype(np.uint8))]
-    m = _matcher(codebook_bytes, gal)
+    m = _matcher(codebook_bytes, gal, taps=True)
     per_row = np.where(np.arange(lt.n)[:, None] % 3 == 0, 1.0, np.where(np.arange(lt.n)[:, None] % 3 == 1, 17.0, 0.01)).astype(np.float32)
     huge = lt.des.copy(); huge[::5] *= np.float32(3000)                 # beyond what fp16 operands carry: variant 9 evaluates those rows over every point
     for name, des in (("x8", lt.des * np.float32(8)), ("x40", lt.des * np.float32(40)), ("+3", lt.des + np.float32(3)), ("mixed", lt.des * per_row), ("huge", huge)):
@@ -932,7 +932,7 @@ def test_matrix_core_bound_pass_selection_statistics(codebook_bytes, cb, medium)
     bit for bit on 6 latents x 3000 templates, and the kernel's own counters say what it did — every exact row maximum inside the bounds the
     selection used, about a third of the rows evaluated, about one candidate cell per evaluated row, next to no row evaluated in full."""
     lats, gal, planted = medium
-    m = M.Matcher(codebook_bytes)
+    m = M.Matcher(codebook_bytes, taps=True)
     m.gallery_add_packed(gal); m.gallery_commit(0)
     m.set_option("adc_variant", 7); r7 = m.search(lats, k=24, want_parts=True)
     m.set_option("adc_variant", 9); m.set_option("mf_stats", 1)
@@ -971,7 +971,7 @@ def test_matrix_core_bound_pass_tile_stage_and_chunk_edges(codebook_bytes, cb):
         return T.FPTemplate(minu=list(base.minu), tex=tex)
     lats = [latent(n) for n in (1, 31, 33, 767, 0, 769, 1000)]
     gal[13] = S.make_mate(rng, cb, base, frac=0.6, n_tex=700)       # one real mate so that the texture scorer has something to find
-    m = _matcher(codebook_bytes, gal)
+    m = _matcher(codebook_bytes, gal, taps=True)
     m.set_option("adc_variant", 7)
     want = m.search(lats, k=0, want_parts=True)
     taps = {(qi, g): m.debug_texture_rowmax(lats[qi], g) for qi in (0, 2, 3, 5, 6) for g in (0, 3, 6, 9, 10, 11, 13, 15)}
@@ -1002,7 +1002,7 @@ def test_minutiae_coordinates_beyond_the_packed_path(codebook_bytes, cb, oracle)
             return T.MinutiaeTemplate(x, y, m.ori, m.des)
         L = T.FPTemplate(minu=[shift(m_, off_l) for m_ in base.minu], tex=list(base.tex))
         R = T.FPTemplate(minu=[shift(R0.minu[0], off_r)], tex=list(R0.tex))
-        m = M.Matcher(codebook_bytes); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
+        m = M.Matcher(codebook_bytes, taps=True); m.gallery_add_dat(T.write_rolled(R)); m.gallery_commit(0)
         hl, _ = oracle.latent(ocb, T.write_latent(L)); hr, _ = oracle.rolled(T.write_rolled(R))
         for which in (1, 2, 3):
             for stage in (1, 2):

@@ -141,9 +141,19 @@ def test_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert set(M.EXPORTS) == set(declared)
+    assert not any(n.startswith("afis_debug") for n in declared)          # the product ABI carries no parity taps ...
+    for name in M.TAP_EXPORTS:
+        assert not hasattr(lib, name), name                                # ... and the product library exports none
     # no torch / C++ types in the signatures
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # signatures only, comments stripped
     assert "std::" not in code and "torch" not in code and "hip" not in code.lower() and "&" not in code
+    # the test library = the product's exports + exactly the taps of include/afis_matcher_taps.h
+    taps_hdr = open(os.path.join(ROOT, "include", "afis_matcher_taps.h")).read()
+    tap_decl = sorted(set(re.findall(r"\b(afis_debug_[a-z0-9_]+)\s*\(", taps_hdr)))
+    assert set(M.TAP_EXPORTS) == set(tap_decl)
+    tlib = M.load_library(M.TEST_LIB_PATH)
+    for name in declared + tap_decl:
+        assert hasattr(tlib, name), name
 
 
 def test_cli_help_runs_without_gpu():
