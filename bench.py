@@ -70,10 +70,11 @@ def host_cpu_limits():
     return info
 
 
-def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=20):
+def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=800):
     """The CPU restatement of the reference path (oracle/, OpenMP) timed on bounded samples of the same workload:
        compute-only   gallery parsed once and resident in RAM, T host threads taking one pair at a time (dynamic schedule), for T = 8, 16, 32, ...
-                      up to every CPU this process may use: the CURVE is reported, the best point is the `value` of cpu_baseline
+                      up to every CPU this process may use: the CURVE is reported, the best point is the `value` of cpu_baseline.  Every point scores
+                      pairs_per_thread x T pairs — about 2 s of wall time at the ~350 pairs/s a core manages (round 3 timed 55 ms per point: noise-limited)
        compute-only   8 threads, schedule(static,16): the reference's OpenMP setting (matcher.cpp:168, :273)
        reference-faithful  8 threads, static 16, and every rolled .dat RE-READ AND RE-PARSED for every pair from page-cache-warm
                       files, which is what the reference's loop does (matcher.cpp:173, :278)."""
@@ -88,7 +89,7 @@ def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=20):
     if lim["cgroup_quota_cpus"]: usable = max(1, min(usable, int(lim["cgroup_quota_cpus"] + 0.5)))
     ladder = sorted({t for t in (8, 16, 32, 64, 128, 256) if t < usable} | {usable})
     hl = orc.latent(ocb, T.write_latent(lats[0]))[0]
-    n_max = int(min(gal.G, max(480, pairs_per_thread * ladder[-1])))
+    n_max = int(min(gal.G, max(480, pairs_per_thread * min(ladder[-1], 32))))    # at most 25 600 templates parsed for the sample
     dats = [T.write_rolled(gal.template(g)) for g in range(n_max)]
     hr = [orc.rolled(d)[0] for d in dats]
     orc.search(ocb, hl, hr[:64], tie_mode=1, threads=min(usable, 64))                 # warm: page in the LUT and the code
@@ -100,7 +101,7 @@ def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=20):
             t0 = time.perf_counter(); orc.search(ocb, hl, hr[:n], tie_mode=1, threads=t); dt = min(dt, time.perf_counter() - t0)
         curve.append({"threads": t, "pairs": n, "pairs_per_s": round(n / dt, 1)})
     best = max(curve, key=lambda c: c["pairs_per_s"])
-    n8 = min(len(hr), 480)
+    n8 = min(len(hr), max(480, pairs_per_thread * 8))
     wall8 = 1e30
     for _ in range(2):
         t1 = time.perf_counter(); orc.search(ocb, hl, hr[:n8], tie_mode=1, threads=0); wall8 = min(wall8, time.perf_counter() - t1)
@@ -124,30 +125,57 @@ def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=20):
             "sample_8_threads": f"1 latent x {n8} gallery templates, 8 threads schedule(static,16)"}
 
 
+def _free_ports(n):
+    """n distinct TCP ports that are free on 127.0.0.1 right now (bound together, then released)."""
+    import socket
+    socks = []
+    for _ in range(n):
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); socks.append(sk)
+    ports = [sk.getsockname()[1] for sk in socks]
+    for sk in socks: sk.close()
+    return ports
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` started by hand or by the driver (no torchrun): become the launcher — N copies of this command line, one
-    process per GPU (LOCAL_RANK = GPU), a free rendezvous port on 127.0.0.1; rank 0 owns stdout (the one JSON line)."""
-    import socket
+    process per GPU (LOCAL_RANK = GPU), verified-free rendezvous ports on 127.0.0.1 (torch's store, and the C++ exchange's own id hand-off);
+    rank 0 owns stdout (the one JSON line).  EVERY child is polled: the first non-zero exit tears the whole job down at once (a rank that waits
+    in a collective for a dead peer would otherwise sit there until the backend's own timeout)."""
     import subprocess
-    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    port, xport = _free_ports(2)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   AFIS_BENCH_CHILD="1")
+                   AFIS_EXCHANGE_PORT=str(xport), AFIS_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    try:
-        for p in procs:
-            p.wait()
-            rc = rc or p.returncode
-            if p.returncode != 0:                                         # one rank down: the others would wait in the next collective
-                for q in procs:
-                    if q.poll() is None: q.terminate()
-    except KeyboardInterrupt:
+
+    def tear_down():
         for q in procs:
             if q.poll() is None: q.terminate()
+        t_end = time.time() + 10
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc = bad[0][1]
+                print(f"bench.py: rank {bad[0][0]} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                tear_down()
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        tear_down()
         rc = 130
     return rc
 
@@ -184,6 +212,8 @@ def main():
             sys.exit(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible (use --share-gpu to put every rank on GPU 0: test mode)")
         sys.exit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("AFIS_BENCH_FAIL_RANK") == str(rank) and world > 1:          # test hook (tests/test_sharding.py): this rank dies before the rendezvous
+        sys.exit(7)
     if world != a.gpus and not a.force_dist:
         sys.exit(f"bench.py: WORLD_SIZE={world} does not match --gpus {a.gpus}")
     if world > 1 and not a.share_gpu and torch.cuda.device_count() <= local:
@@ -231,12 +261,18 @@ def main():
 
     xch = SH.CppExchange(gpu) if (a.exchange == "cpp" and use_dist) else None     # rendezvous on MASTER_PORT + 1 (torch's store owns MASTER_PORT)
 
+    wall = {"search": 0.0, "exchange": 0.0}                 # host wall time of this rank's two halves of a step (reset after the warm-up)
+
     def step():
-        r = m.search_resident(qh, k=a.k)
+        t_a = time.perf_counter()
+        r = m.search_resident(qh, k=a.k)                    # returns with the shard's rank lists on the host: the stream is drained
+        t_b = time.perf_counter()
         if xch is not None:
-            return xch.gather_topk(r["topk_idx"], r["topk_score"], a.k)
-        idx, sc = SH.gather_topk(r["topk_idx"], r["topk_score"], a.k, device=dev, force=a.force_dist)
-        return idx, sc
+            out_ = xch.gather_topk(r["topk_idx"], r["topk_score"], a.k)
+        else:
+            out_ = SH.gather_topk(r["topk_idx"], r["topk_score"], a.k, device=dev, force=a.force_dist)
+        wall["search"] += t_b - t_a; wall["exchange"] += time.perf_counter() - t_b
+        return out_
 
     def sync():
         torch.cuda.synchronize()
@@ -247,6 +283,7 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
+    wall["search"] = wall["exchange"] = 0.0
     t0 = time.perf_counter()
     tm_acc = None
     for _ in range(a.steps):
@@ -261,6 +298,14 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / max(1, a.steps)
     value = Q / (ms_per_step / 1000.0)
+    # where a step's time goes on each rank: the search of the rank's shard, and the exchange step (all-gather + merge; a rank that finishes its
+    # shard early waits here for the slowest one, so max(exchange) - min(exchange) is the imbalance and min(exchange) the cost of the step itself)
+    per_rank = np.array([wall["search"], wall["exchange"]], np.float64) * 1000.0 / max(1, a.steps)
+    pr_min, pr_max = per_rank.copy(), per_rank.copy()
+    if use_dist:
+        t_lo = torch.tensor(per_rank, dtype=torch.float64, device=dev); t_hi = t_lo.clone()
+        dist.all_reduce(t_lo, op=dist.ReduceOp.MIN); dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
+        pr_min, pr_max = t_lo.cpu().numpy(), t_hi.cpu().numpy()
 
     # ---- rank-list sanity: the planted true mate must be rank 1 ------------------------------------------------------
     hits = sum(1 for q in range(Q) if int(idx[q, 0]) == planted[q][0][0])
@@ -328,8 +373,13 @@ def main():
                                                                    "u16 fixed point in LDS: used for BOUNDS only" if variant == 8 else "none"), "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
             "roofline": dict(roofline, pipeline_achieved_GBps=round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 3)),
-            "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "fuse_ms", "total_ms")},
+            "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "cands_ms", "minu_graph_ms", "fuse_ms", "topk_ms", "total_ms")},
             "refine_stats": m.refine_stats() if a.refine_stats else None,
+            "per_rank_ms_per_step": {"search": {"min": round(float(pr_min[0]), 3), "max": round(float(pr_max[0]), 3)},
+                                     "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},
+                                     "note": "host wall time per rank; a rank that finishes its shard early waits in the exchange for the slowest: min(exchange) is the step's own cost"},
+            "exchange_ms_per_step": round(float(pr_min[1]), 3),
+            "latency_ms_per_query": round(ms_per_step / max(1, Q), 3), "launch_groups_per_step": tm_acc["launch_groups"] // max(1, a.steps),
             "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},
         }
         if world == 1 and not a.no_cpu_baseline:

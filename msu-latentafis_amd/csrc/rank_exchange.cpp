@@ -33,7 +33,8 @@ void world_from_env(RankWorld& w)
     w.local_rank = env_int("LOCAL_RANK", w.rank);
     const char* a = getenv("MASTER_ADDR");
     if (a && *a) w.addr = a;
-    w.port = env_int("MASTER_PORT", 29500) + 1;          // MASTER_PORT itself belongs to the launcher's own store
+    // MASTER_PORT itself belongs to the launcher's own store; a launcher that has verified a free port for this rendezvous passes it as AFIS_EXCHANGE_PORT
+    w.port = env_int("AFIS_EXCHANGE_PORT", env_int("MASTER_PORT", 29500) + 1);
     if (w.rank < 0 || w.rank >= w.world) { w.rank = 0; w.world = 1; }
 }
 

@@ -160,3 +160,51 @@ def test_bench_driver_command_form_spawns_its_own_ranks(tmp_path):
     n = torch.cuda.device_count()
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(2, n + 1)), *common], capture_output=True, text=True, timeout=300, env=env)
     assert bad.returncode != 0 and "GPU(s) visible" in bad.stderr
+
+
+
+def test_eight_rank_rehearsal_of_the_driver_command(tmp_path):
+    """The command the round driver runs on an 8-GPU node — `python bench.py --gpus 8` with no launcher — rehearsed with all eight ranks on GPU 0
+    (eight gallery shards, eight processes, the exchange step between eight ranks): ONE JSON line, n_gpus == 8, the merged rank lists equal to the
+    one-rank run's, with the Python exchange (torch.distributed) and with the C++ host's own (csrc/rank_exchange.cpp, its TCP form: RCCL cannot put
+    two ranks on one GPU).  No scaling number comes out of this: it proves the 8-rank path, not its speed."""
+    import json
+    common = ["--gallery", "3000", "--queries", "6", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-ranks", str(tmp_path / "one.npz")],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = np.load(tmp_path / "one.npz")
+    for exchange in ("cpp", "torch"):
+        r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--backend", "gloo", "--exchange", exchange,
+                             *common, "--dump-ranks", str(tmp_path / f"eight_{exchange}.npz")], capture_output=True, text=True, timeout=1500,
+                            env=dict(env, AFIS_EXCHANGE="tcp"))
+        assert r8.returncode == 0, r8.stderr[-2000:]
+        lines = [l for l in r8.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r8.stdout[-1000:]
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 8 and j["rank1_hits"] == "6/6" and j["config"]["parallelism"] == "gallery-shard x8" and j["config"]["exchange"].startswith(exchange)
+        pr = j["per_rank_ms_per_step"]
+        assert 0 < pr["search"]["min"] <= pr["search"]["max"] and 0 <= j["exchange_ms_per_step"] <= pr["exchange_and_merge"]["max"]
+        b = np.load(tmp_path / f"eight_{exchange}.npz")
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["score"], b["score"]), exchange
+
+
+def test_match_eight_ranks_equal_one_rank(match_case):
+    """`match` started eight times (WORLD_SIZE=8, AFIS_EXCHANGE=tcp, every rank on GPU 0): 22 templates in eight shards of 2-3, -ldir and -l;
+    every score / rank / correspondence file byte-equal to the single-process run."""
+    exe, d = match_case
+    for mode, extra in (("ldir", ["-ldir", str(d / "lat")]), ("l", ["-l", str(d / "lat" / "L0.dat")])):
+        outs = {}
+        for world in (1, 8):
+            sd = d / f"out8_{mode}_{world}"
+            sd.mkdir()
+            res = _run_match(exe, [*extra, "-g", str(d / "gal"), "-s", str(sd) + "/", "-c", str(d / "cb.dat")], d / "work", world, timeout=600)
+            for rc, o, e in res:
+                assert rc == 0, (mode, world, e[-1500:])
+            if world == 8:
+                assert all(o == "" for _, o, _ in res[1:]) and "Gallery size: 22" in res[0][1]
+            outs[world] = _files(sd)
+        assert set(outs[1]) == set(outs[8]) and len(outs[1]) >= (3 if mode == "ldir" else 2), (mode, sorted(outs[1]), sorted(outs[8]))
+        for f in outs[1]:
+            assert outs[1][f] == outs[8][f], (mode, f)

@@ -180,3 +180,19 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode != 0 and "does not match --gpus" in r.stderr
+
+
+def test_bench_launcher_tears_the_job_down_when_a_rank_dies():
+    """`python bench.py --gpus 4` (the driver's form: bench.py is its own launcher) with rank 2 dying before the rendezvous: the launcher polls EVERY
+    child, so it reports that rank's exit code and stops the three others — which sit in the rendezvous waiting for it — within seconds instead of
+    waiting on rank 0 until the backend's own timeout.  (No GPU needed: the ranks never get as far as creating a matcher.)"""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--share-gpu", "--backend", "gloo", "--gallery", "200", "--queries", "1"],
+                       capture_output=True, text=True, timeout=280, env=dict(env, AFIS_BENCH_FAIL_RANK="2"))
+    assert r.returncode == 7, (r.returncode, r.stderr[-1500:])
+    assert "rank 2 exited with code 7" in r.stderr
+    assert time.time() - t0 < 120
