@@ -419,7 +419,7 @@ static float sum_scores(const std::vector<Corr>& c)   // :508-514, :775-781
 }
 
 struct MinuTrace { std::vector<Corr> corr, corr2, corr3; std::vector<float> simi, norm; };
-struct TexTrace { std::vector<float> rowmax; std::vector<int> rowarg; std::vector<Corr> corr, corr2, corr3; };
+struct TexTrace { std::vector<float> rowmax; std::vector<int> rowarg; std::vector<Corr> corr, corr2, corr3; bool rowmax_only = false; };   // rowmax_only: stop after S6 (the tap of S5 + S6; also keeps NaN row maxima away from the sorts of S7)
 
 // ---- S1-S3 (+S8a, S9): minutiae-template scorer -----------------------------------------------------------------
 // One2One_minutiae_matching, matcher.cpp:420-516.
@@ -490,6 +490,7 @@ float texture_score(const LatTexTpl& L, const RolTexTpl& R, const Codebook& cb, 
         }
         rowmax[i] = best; rowarg[i] = besti;
     }
+    if (tr && tr->rowmax_only) { tr->rowmax = rowmax; tr->rowarg = rowarg; return 0.f; }
     std::vector<Corr> tmp(nL), corr;
     for (int i = 0; i < nL; ++i) tmp[i] = std::make_tuple(rowmax[i], i, rowarg[i]);
     if ((int)tmp.size() > cb.N) {                                         // :736-747
@@ -679,7 +680,7 @@ int orc_texture_rowmax(void* cb, void* lat, void* rol, float* val, int* arg)
 {
     Latent* L = (Latent*)lat; Rolled* R = (Rolled*)rol;
     if (L->tex.empty() || R->tex.empty()) return 0;
-    TexTrace tr;
+    TexTrace tr; tr.rowmax_only = true;
     texture_score(L->tex[0], R->tex[0], *(Codebook*)cb, 1, &tr);
     memcpy(val, tr.rowmax.data(), tr.rowmax.size() * 4);
     memcpy(arg, tr.rowarg.data(), tr.rowarg.size() * 4);

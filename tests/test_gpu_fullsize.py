@@ -97,9 +97,12 @@ def headline(codebook_bytes, cb):
     lats = S.make_latents(seed, Q)
     gal = S.make_packed_gallery(seed, G, cb)
     planted = S.plant_mates(seed, gal, cb, lats, G=G)
-    m = M.Matcher(codebook_bytes)
+    m = M.Matcher(codebook_bytes, taps=True)                           # the product objects + the parity taps: the bound pass's self-check counter is read below
     m.gallery_add_packed(gal); m.gallery_commit(0)
+    m.set_option("mf_stats", 1)
     res = m.search(lats, k=24, want_parts=True)
+    res["refine_stats"] = m.refine_stats()
+    m.set_option("mf_stats", 0)
     yield lats, gal, planted, m, res
     m.close()
 
@@ -107,6 +110,9 @@ def headline(codebook_bytes, cb):
 def test_config2_properties_all_pairs(headline):
     lats, gal, planted, m, res = headline
     _check_properties(res, planted, gal.G, 24)
+    # the matrix-core bound pass's self-check over ALL 10^7 pairs: every exactly evaluated row maximum lay inside the bounds the selection used
+    st = res["refine_stats"]
+    assert st["pairs"] == len(lats) * gal.G and st["bound_violations"] == 0 and st["rows_evaluated"] >= 200 * st["pairs"], st
     assert all(res["topk_score"][q][0] > 50 for q in range(len(lats)))
     # a second pass over resident queries gives the same bits (idempotence), without asking for the score matrix
     qh = m.upload_queries(lats)
@@ -154,7 +160,7 @@ def test_config2_variants_same_bits_on_a_query_slice(headline):
 SH = importlib.import_module("msu-latentafis_amd.host.sharding")
 
 
-def _search_shards(codebook_bytes, cb, seed, G, lats, world, k, keep=None, n_partial=3):
+def _search_shards(codebook_bytes, cb, seed, G, lats, world, k, keep=None, n_partial=3, stats=None):
     """Per-shard searches of a G-template gallery cut into `world` contiguous shards balanced by rolled texture points.
     keep: {global index} whose templates (after planting) and per-part scores are kept for the oracle sample.
     Returns merged (idx, score), the per-shard lists, planted, and {g: (template, parts[Q][4], scores[Q])} for g in keep."""
@@ -165,9 +171,12 @@ def _search_shards(codebook_bytes, cb, seed, G, lats, world, k, keep=None, n_par
     for lo, hi in bounds:
         gal = S.make_packed_gallery(seed, G, cb, lo, hi)
         planted = S.plant_mates(seed, gal, cb, lats, G=G, lo=lo, n_partial=n_partial)
-        m = M.Matcher(codebook_bytes)
+        m = M.Matcher(codebook_bytes, taps=stats is not None)
         m.gallery_add_packed(gal); m.gallery_commit(lo)
+        if stats is not None: m.set_option("mf_stats", 1)                # the bound pass's self-check counters of this shard (stats: a dict that accumulates them)
         res = m.search(lats, k=k, want_parts=True)
+        if stats is not None:
+            for k_, v in m.refine_stats().items(): stats[k_] = stats.get(k_, 0) + v
         m.close()
         assert res["scores"].shape == (len(lats), hi - lo)
         p = res["parts"]
@@ -213,7 +222,9 @@ def test_config4_one_million_templates_in_eight_virtual_shards(codebook_bytes, c
     rand = {q: rng.integers(0, G, 200) for q in sample_q}
     for q in sample_q:
         keep |= set(int(g) for g in rand[q])
-    idx, sc, bounds, planted, kept = _search_shards(codebook_bytes, cb, seed, G, lats, 8, k, keep=keep)
+    st = {}
+    idx, sc, bounds, planted, kept = _search_shards(codebook_bytes, cb, seed, G, lats, 8, k, keep=keep, stats=st)
+    assert st["pairs"] == Q * G and st["bound_violations"] == 0, st     # every exactly evaluated row maximum of the 1.2e7 pairs inside the bounds the selection used
     assert int(slots.max()) > 0.9 * G                                   # the planted indices do span the million
     for q in range(Q):
         want = [g for g, _ in planted[q]]

@@ -835,18 +835,35 @@ def test_the_tolerance_path_is_gone(codebook_bytes, cb, small):
     m.close()
 
 
-def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes, cb, medium):
-    """adc_variant 8 (16-bit bound pass + exact evaluation of the candidates) against the direct exact kernel (7): every row maximum and
-    every first arg-max of 6 latents x 40 gallery templates (about 160 000 rows), bit for bit."""
+def _orc_pair(oracle, ocb, lat, rolled):
+    """Oracle handles of one (latent, rolled) pair, from the .dat bytes the reference's own reader would parse."""
+    return oracle.latent(ocb, T.write_latent(lat))[0], oracle.rolled(T.write_rolled(rolled))[0]
+
+
+def _same_bits(a, b):
+    """Bit equality of two float arrays, NaN counted as equal to NaN (the payload of a NaN is not part of the contract)."""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    na, nb = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb) and np.array_equal(a.view(np.uint32)[~na], b.view(np.uint32)[~nb])
+
+
+def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes, cb, oracle, medium):
+    """adc_variant 8 (16-bit bound pass + exact evaluation of the candidates) and 9 (fp16 matrix-core bound pass + recomputation) against the ORACLE
+    (matcher.cpp:563-595, :723-735 restated) and the direct exact kernel (7): every row maximum and every first arg-max of 6 latents x 40 gallery
+    templates (about 160 000 rows), bit for bit."""
     lats, gal, planted = medium
     m = M.Matcher(codebook_bytes, taps=True)
     m.gallery_add_packed(gal); m.gallery_commit(0)
+    ocb = oracle.codebook(codebook_bytes)
     rng = np.random.default_rng(8)
     n = 0
     for qi in range(len(lats)):
         gs = [g for g, _ in planted[qi]] + [int(x) for x in rng.integers(0, gal.G, 36)]
         for g in gs:
             m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lats[qi], g)
+            hl, hr = _orc_pair(oracle, ocb, lats[qi], gal.template(g))
+            ov, oa = oracle.texture_rowmax(ocb, hl, hr)
+            assert np.array_equal(v7.view(np.uint32), ov.view(np.uint32)) and np.array_equal(a7, oa), (7, qi, g)
             for v in (8, 9):                                            # 8: 16-bit LDS-table bound pass; 9: fp16 matrix-core bound pass
                 m.set_option("adc_variant", v); v8, a8 = m.debug_texture_rowmax(lats[qi], g)
                 assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)) and np.array_equal(a7, a8), (v, qi, g, np.argwhere(a7 != a8)[:4])
@@ -855,11 +872,12 @@ def test_bound_and_refine_kernel_equals_direct_kernel_row_by_row(codebook_bytes,
     assert n > 100000
 
 
-def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
+def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb, oracle):
     """The bound logic at its edges: rolled templates whose points are all identical (every quantised sum ties: each lane's second
     sum equals its best, so the whole row is evaluated exactly and the FIRST point must win), alternate between two codes, or differ
     from one another in a single sub-quantizer (exact similarities closer than the quantisation step); latent rows with zero, tiny and
-    duplicated descriptors (degenerate table ranges).  Variant 8 must reproduce variant 7 bit for bit, values and first arg-maxima."""
+    duplicated descriptors (degenerate table ranges).  Variants 8 and 9 must reproduce the ORACLE (the reference's table arithmetic and std::max_element,
+    matcher.cpp:563-595, :723-735) bit for bit, values and first arg-maxima; the direct exact kernel (7) is the second witness."""
     rng = np.random.default_rng(21)
     base = S.make_latent(rng, n_tex_lo=330, n_tex_hi=360)
     lt = base.tex[0]
@@ -880,25 +898,28 @@ def test_bound_and_refine_kernel_on_ties_and_near_ties(codebook_bytes, cb):
     gal = [rolled(same), rolled(two), rolled(near), rolled(near2), rolled(enc), rolled(rng.integers(0, 256, (65, 16)).astype(np.uint8)),
            rolled(rng.integers(0, 256, (1, 16)).astype(np.uint8))]
     m = _matcher(codebook_bytes, gal, taps=True)
+    ocb = oracle.codebook(codebook_bytes)
+    want_parts = []
     for g in range(len(gal)):
-        m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
-        for v in (8, 9):
+        hl, hr = _orc_pair(oracle, ocb, lat, gal[g])
+        ov, oa = oracle.texture_rowmax(ocb, hl, hr)
+        want_parts.append(oracle.pair(ocb, hl, hr, 1)[1][:4])
+        for v in (7, 8, 9):
             m.set_option("adc_variant", v); v8, a8 = m.debug_texture_rowmax(lat, g)
-            assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (v, g, np.argwhere(v7 != v8)[:4])
-            assert np.array_equal(a7, a8), (v, g, np.argwhere(a7 != a8)[:4], a7[:8], a8[:8])
+            assert np.array_equal(ov.view(np.uint32), v8.view(np.uint32)), (v, g, np.argwhere(ov != v8)[:4])
+            assert np.array_equal(oa, a8), (v, g, np.argwhere(oa != a8)[:4], oa[:8], a8[:8])
     assert (m.debug_texture_rowmax(lat, 0)[1] == 0).all()                                          # all points identical: the first one
-    m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
-    for v in (8, 9):
+    for v in (7, 8, 9):
         m.set_option("adc_variant", v); r8 = m.search([lat], k=0, want_parts=True)
-        assert np.array_equal(r7["parts"].view(np.uint32), r8["parts"].view(np.uint32)), v
+        assert np.array_equal(np.asarray(want_parts, np.float32).view(np.uint32), r8["parts"][0].view(np.uint32)), v     # per-part scores of the oracle
     m.close()
 
 
-def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_bytes, cb):
+def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_bytes, cb, oracle):
     """The candidate margin of the bound pass comes from each row's own table (k_lutq_build), not from an assumed descriptor norm of 1.73:
     latent texture descriptors scaled by 8 and 40, shifted by +3, and mixed per row (table entries up to ~10^5: fp32 rounding errors far
-    above the normalised case's 2e-6) against random and near-tie rolled templates.  Variant 8 must equal the direct exact kernel
-    (variant 7) bit for bit, values and first arg-maxima."""
+    above the normalised case's 2e-6) against random and near-tie rolled templates.  Variants 8 and 9 must equal the ORACLE bit for bit, values
+    and first arg-maxima (the direct exact kernel, 7, is the second witness)."""
     rng = np.random.default_rng(77)
     base = S.make_latent(rng, n_tex_lo=300, n_tex_hi=340)
     lt = base.tex[0]
@@ -911,19 +932,98 @@ def test_bound_and_refine_kernel_with_unnormalised_latent_descriptors(codebook_b
     near[np.arange(n), rng.integers(0, 16, n)] = rng.integers(0, 256, n).astype(np.uint8)
     gal = [rolled(rng.integers(0, 256, (n, 16)).astype(np.uint8)), rolled(near), rolled(rng.integers(0, 256, (130, 16)).astype(np.uint8))]
     m = _matcher(codebook_bytes, gal, taps=True)
+    ocb = oracle.codebook(codebook_bytes)
     per_row = np.where(np.arange(lt.n)[:, None] % 3 == 0, 1.0, np.where(np.arange(lt.n)[:, None] % 3 == 1, 17.0, 0.01)).astype(np.float32)
     huge = lt.des.copy(); huge[::5] *= np.float32(3000)                 # beyond what fp16 operands carry: variant 9 evaluates those rows over every point
     for name, des in (("x8", lt.des * np.float32(8)), ("x40", lt.des * np.float32(40)), ("+3", lt.des + np.float32(3)), ("mixed", lt.des * per_row), ("huge", huge)):
         lat = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=np.ascontiguousarray(des, np.float32))])
+        want_parts = []
         for g in range(len(gal)):
-            m.set_option("adc_variant", 7); v7, a7 = m.debug_texture_rowmax(lat, g)
-            for v in (8, 9):
+            hl, hr = _orc_pair(oracle, ocb, lat, gal[g])
+            ov, oa = oracle.texture_rowmax(ocb, hl, hr)
+            want_parts.append(oracle.pair(ocb, hl, hr, 1)[1][:4])
+            for v in (7, 8, 9):
                 m.set_option("adc_variant", v); v8, a8 = m.debug_texture_rowmax(lat, g)
-                assert np.array_equal(v7.view(np.uint32), v8.view(np.uint32)), (v, name, g, np.argwhere(v7 != v8)[:4], v7[:3], v8[:3])
-                assert np.array_equal(a7, a8), (v, name, g, np.argwhere(a7 != a8)[:4])
-        m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
-        m.set_option("adc_variant", 9); r9 = m.search([lat], k=0, want_parts=True)
-        assert np.array_equal(r7["parts"].view(np.uint32), r9["parts"].view(np.uint32)), name
+                assert np.array_equal(ov.view(np.uint32), v8.view(np.uint32)), (v, name, g, np.argwhere(ov != v8)[:4], ov[:3], v8[:3])
+                assert np.array_equal(oa, a8), (v, name, g, np.argwhere(oa != a8)[:4])
+        for v in (7, 9):
+            m.set_option("adc_variant", v); r9 = m.search([lat], k=0, want_parts=True)
+            assert np.array_equal(np.asarray(want_parts, np.float32).view(np.uint32), r9["parts"][0].view(np.uint32)), (v, name)
+    m.close()
+
+
+def test_bound_pass_with_nan_and_inf_latent_descriptors(codebook_bytes, cb, oracle):
+    """Latent texture rows holding NaN, +inf, -inf, fp32 values beyond fp16's range (7e4, 3e38) and denormals.  fp16 operands cannot carry such rows:
+    k_mf_rows forces them (Tg = Es = inf) and k_tex_refine evaluates them over every point in the reference's fp32 arithmetic, where include.h:327-359 /
+    matcher.cpp:571-592, :730 define the result: a NaN table entry makes every similarity of the row NaN and std::max_element keeps the FIRST point;
+    an infinite one makes them all -inf, again the first point.  Row maxima / first arg-maxima of variants 7, 8 and 9 equal the oracle's (NaN == NaN),
+    the finite rows around them are untouched, and a search over such a latent neither hangs nor crashes and gives the same scores in variants 7 and 9
+    (the reference's own S7 sort of NaN keys is undefined behaviour: there is no oracle value for the pair score)."""
+    rng = np.random.default_rng(404)
+    base = S.make_latent(rng, n_tex_lo=300, n_tex_hi=320)
+    lt = base.tex[0]
+    des = lt.des.copy()
+    des[3, 5] = np.nan; des[4, :] = np.nan; des[9, 0] = np.inf; des[10, 95] = -np.inf; des[11, 40] = np.inf; des[11, 41] = -np.inf
+    des[20, 7] = 7e4; des[21, 8] = -3e38; des[22, :] = 1e-42; des[23, 17] = 1001.0; des[24, 17] = 999.0; des[25, :] = 0.0
+    lat = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=des)])
+    gal = [S.make_rolled(rng, cb, n_tex=n) for n in (640, 33, 1)] + [S.make_mate(rng, cb, base, frac=0.6, n_tex=500)]
+    m = _matcher(codebook_bytes, gal, taps=True)
+    ocb = oracle.codebook(codebook_bytes)
+    for g in range(len(gal)):
+        hl, hr = _orc_pair(oracle, ocb, lat, gal[g])
+        ov, oa = oracle.texture_rowmax(ocb, hl, hr)
+        assert np.isnan(ov[[3, 4]]).all() and (oa[[3, 4]] == 0).all() and np.isneginf(ov[[9, 10]]).all() and (oa[[9, 10, 11]] == 0).all()
+        for v in (7, 8, 9):
+            m.set_option("adc_variant", v); vv, aa = m.debug_texture_rowmax(lat, g)
+            assert _same_bits(ov, vv), (v, g, np.argwhere(ov.view(np.uint32) != vv.view(np.uint32))[:6].ravel(), ov[[3, 9, 20, 21]], vv[[3, 9, 20, 21]])
+            assert np.array_equal(oa, aa), (v, g, np.argwhere(oa != aa)[:6].ravel())
+    m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
+    m.set_option("adc_variant", 9); m.set_option("mf_stats", 1); r9 = m.search([lat], k=0, want_parts=True)
+    assert _same_bits(r7["parts"], r9["parts"])
+    m.close()
+
+
+def test_bound_pass_magnitude_sweep_up_to_the_forcing_threshold(codebook_bytes, cb, oracle):
+    """The bound's error term Eg grows with the descriptor's magnitude; rows are forced (evaluated everywhere) only beyond |a| > 1000.  Between the two —
+    descriptors scaled by 100, 300, 900 and to a largest component of exactly 999 and 1000 (fp16-representable, the largest Eg that is still trusted), and
+    just beyond (1000.5: forced) — the selection must still find every row maximum: oracle row maxima / first arg-maxima bit for bit in variant 9, the
+    kernel's self-check (every exact maximum inside its bounds) silent, and the per-part scores of the oracle."""
+    rng = np.random.default_rng(505)
+    base = S.make_latent(rng, n_tex_lo=260, n_tex_hi=280)
+    lt = base.tex[0]
+    n = 800
+    near = np.tile(cb.encode(lt.des[5:6]), (n, 1)).astype(np.uint8)
+    near[np.arange(n), rng.integers(0, 16, n)] = rng.integers(0, 256, n).astype(np.uint8)
+    def rolled(codes):
+        r = S.make_rolled(rng, cb, n_tex=len(codes))
+        r.tex[0].codes[:] = codes
+        return r
+    gal = [rolled(rng.integers(0, 256, (n, 16)).astype(np.uint8)), rolled(near), S.make_mate(rng, cb, base, frac=0.7, n_tex=600)]
+    m = _matcher(codebook_bytes, gal, taps=True)
+    m.set_option("adc_variant", 9); m.set_option("mf_stats", 1)
+    ocb = oracle.codebook(codebook_bytes)
+    amax = np.abs(lt.des).max(axis=1, keepdims=True)
+    cases_ = [("x100", lt.des * np.float32(100)), ("x300", lt.des * np.float32(300)), ("x900", lt.des * np.float32(900)),
+              ("max999", lt.des / amax * np.float32(999)), ("max1000", lt.des / amax * np.float32(1000)), ("max1000.5", lt.des / amax * np.float32(1000.5))]
+    for name, des in cases_:
+        lat = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=np.ascontiguousarray(des, np.float32))])
+        m.refine_stats()                                                # reset
+        want_parts = []
+        for g in range(len(gal)):
+            hl, hr = _orc_pair(oracle, ocb, lat, gal[g])
+            ov, oa = oracle.texture_rowmax(ocb, hl, hr)
+            want_parts.append(oracle.pair(ocb, hl, hr, 1)[1][:4])
+            vv, aa = m.debug_texture_rowmax(lat, g)
+            assert np.array_equal(ov.view(np.uint32), vv.view(np.uint32)), (name, g, np.argwhere(ov != vv)[:4].ravel())
+            assert np.array_equal(oa, aa), (name, g, np.argwhere(oa != aa)[:4].ravel())
+        r9 = m.search([lat], k=0, want_parts=True)
+        assert np.array_equal(np.asarray(want_parts, np.float32).view(np.uint32), r9["parts"][0].view(np.uint32)), name
+        st = m.refine_stats()
+        assert st["bound_violations"] == 0 and st["pairs"] >= len(gal), (name, st)
+        if name == "max1000.5":                                         # every row has a component beyond 1000: all rows are forced, i.e. evaluated over every point
+            assert st["rows_evaluated_in_full"] == st["rows_evaluated"] == st["rows"], (name, st)
+        else:
+            assert st["rows_evaluated_in_full"] < 0.5 * st["rows_evaluated"], (name, st)
     m.close()
 
 
@@ -951,11 +1051,12 @@ def test_matrix_core_bound_pass_selection_statistics(codebook_bytes, cb, medium)
     m.close()
 
 
-def test_matrix_core_bound_pass_tile_stage_and_chunk_edges(codebook_bytes, cb):
+def test_matrix_core_bound_pass_tile_stage_and_chunk_edges(codebook_bytes, cb, oracle):
     """k_adc_mfma's bookkeeping at its edges: rolled texture templates of 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000 and 1900 (clamped) points and none
     at all (tiles, pairs of tiles, padding tiles, the last-pair flag), latents of 1, 31, 33, 767, 769 and 1000 texture rows plus one without texture (row blocks,
     row groups of 768, launch-group cuts), and workgroup chunks of 1, 2, 3, 7 templates (stages that end inside a pair, chunks of empty templates).
-    Row maxima / arg-maxima through the parity tap and per-part scores through the search equal the direct exact kernel bit for bit."""
+    Row maxima / arg-maxima through the parity tap equal the ORACLE's (and the direct exact kernel's), per-part scores through the search the oracle's
+    texture scores and the direct kernel's parts, bit for bit."""
     rng = np.random.default_rng(909)
     sizes = [1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 1900, 0, 700, 0, 5]
     gal = []
@@ -975,6 +1076,13 @@ def test_matrix_core_bound_pass_tile_stage_and_chunk_edges(codebook_bytes, cb):
     m.set_option("adc_variant", 7)
     want = m.search(lats, k=0, want_parts=True)
     taps = {(qi, g): m.debug_texture_rowmax(lats[qi], g) for qi in (0, 2, 3, 5, 6) for g in (0, 3, 6, 9, 10, 11, 13, 15)}
+    ocb = oracle.codebook(codebook_bytes)
+    for (qi, g), (v7, a7) in taps.items():                            # the witness itself is checked against the oracle on exactly these shapes
+        hl, hr = _orc_pair(oracle, ocb, lats[qi], gal[g])
+        ov, oa = oracle.texture_rowmax(ocb, hl, hr)
+        assert np.array_equal(v7.view(np.uint32), ov.view(np.uint32)) and np.array_equal(a7, oa), (qi, g)
+        osc = oracle.pair(ocb, hl, hr, 1)[1]
+        assert np.array_equal(want["parts"][qi, g].view(np.uint32), osc[:4].view(np.uint32)), (qi, g, want["parts"][qi, g], osc)
     m.set_option("adc_variant", 9)
     for chunk in (0, 1, 2, 3, 7):
         m.set_option("chunk", chunk)
