@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax(QueryDev q, GalleryD
         if (lane < kTileRows && row0 + lane < n_lt) {
             const size_t o = ((size_t)qi * g.G + gi) * q.lt_pad + row0 + lane;
             rm_val[o] = outv;
-            rm_arg[o] = outi;
+            rm_arg[o] = outi == 0x7fffffff ? 0 : outi;     // no similarity ever exceeded -inf (an inf / NaN / overflowing latent row): the first point, as std::max_element
         }
     }
 }
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmax_cf(QueryDev q, Galle
         if (lane < kTileRows && row < n_lt) {
             const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row;
             rm_val[o] = rv;
-            rm_arg[o] = ri;
+            rm_arg[o] = ri == 0x7fffffff ? 0 : ri;        // no similarity ever exceeded -inf (an inf / NaN / overflowing latent row): the first point, as std::max_element
         }
     }
 }
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(kAdcThreads) void k_adc_rowmin_q(QueryDev q, Galler
             if (row_ok) {
                 const size_t o = ((size_t)qi * g.G + gi_cur) * q.lt_pad + row0 + lane;
                 rm_val[o] = out_v;
-                rm_arg[o] = out_i;
+                rm_arg[o] = out_i == 0x7fffffff ? 0 : out_i;   // no similarity ever exceeded -inf (an inf / NaN / overflowing latent row): the first point, as std::max_element
             }
         }
     }

@@ -47,10 +47,12 @@ __device__ __forceinline__ float med3f(float a, float b, float c) { return __bui
 // Tracking: a lane sees 16 values per tile and row block.  Two partitions of all the values it sees over a template:  G: 8 slots, slot k =
 //   registers k and k + 8 of every tile (running maxima m[k]);  H: 2 groups per tile, registers 0..7 and 8..15 (top three group maxima
 //   tb >= ts >= tu, low 6 bits = group id = 2 * tile + register half).  A slot and a group meet in exactly one value.  24 VALU per 16 values.
-// Records: rec[(template * 2 + h) * R_pad + row] = (value of the lane's best point, descriptor):
-//   bits 0-5 / 6-11 best / second group (group = 2 * tile + register half), 12-14 / 15-17 best / second slot (slot k = registers k, k + 8),
-//   18 second group within T, 19 second slot within T, 20 "many" (a third group or slot within T, or a forced row):
-//   candidates = {groups} x {slots}; register r = slot + 8 * (group & 1), point = 32 * (group >> 1) + (r & 3) + 8 (r >> 2) + 4 h.
+// Records: rec[template * R_pad + row] = (G of the row's best point, descriptor); the two lane halves h of a row are merged before the store:
+//   the PRIMARY half (the one holding the best value): bits 0-5 / 6-11 best / second group (group = 2 * tile + register half), 12-14 / 15-17 best / second
+//   slot (slot k = registers k, k + 8), 18 second group within T, 19 second slot within T; 21 = which half is primary;
+//   candidates = {groups} x {slots}; register r = slot + 8 * (group & 1), point = 32 * (group >> 1) + (r & 3) + 8 (r >> 2) + 4 h;
+//   22 = the OTHER half's best lies within T of the row's: its best cell (bits 23-28 group, 29-31 slot) is a candidate as well;
+//   20 "many": a third group or slot within T in the primary half, runners-up within T in the other half too, or a forced row: every point is evaluated.
 // What was tried on this kernel and left out (all within 3 % of this form): two waves per SIMD with the tracking of tile
 // i - 1 interleaved between the MFMAs of tile i (two accumulator sets); the same with a three-stage LDS ring and operand reads one tile ahead;
 // the two waves of a SIMD half a period apart (one in its MFMA burst while the other tracks); the decode spread over the tile steps;
@@ -153,7 +155,14 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
 #pragma unroll
         for (int k = 0; k < 8; ++k) m[blk][k] = max3f(m[blk][k], X[k], X[k + 8]);
     };
+    // Per (template, row) ONE record: the two lane halves of a row (lanes col and col + 32: the points 8q + 0..3 and 8q + 4..7 of every tile) are merged before
+    // the store.  v_permlane32_swap of (block 0's, block 1's) registers hands lanes 0-31 both halves of block 0's rows and lanes 32-63 both halves of
+    // block 1's, so the merge runs once for the wave's 64 rows and the wave stores 512 contiguous bytes per template (round 3 stored 16 B per row and
+    // template, 17.9 GB per launch, and the recomputation kernel read both halves of every row).
+    const float TgM = h ? Tg[1] : Tg[0];
+    typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
     auto finish_template = [&](int tmpl) {
+        uint32_t val[2], dsc[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
@@ -164,11 +173,22 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
             }
             const float thr = fminf(tb[blk], b3) - Tg[blk];
             const bool many = (tu[blk] >= thr) | (u3 >= thr) | force[blk];
-            const uint32_t desc = (f2u(tb[blk]) & 63u) | ((f2u(ts[blk]) & 63u) << 6) | ((f2u(b3) & 7u) << 12) | ((f2u(s3) & 7u) << 15) |
-                                  ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
-            // padding rows of a partial row block store too (their records are never read: R_pad covers them); only a row block beyond the last is skipped — a uniform test
-            if (rb0 + blk < n_rb) rec[((size_t)tmpl * 2 + h) * R_pad + (size_t)(rb0 + blk) * 32 + col] = make_uint2(f2u(b3), desc);
+            val[blk] = f2u(b3);
+            dsc[blk] = (f2u(tb[blk]) & 63u) | ((f2u(ts[blk]) & 63u) << 6) | ((f2u(b3) & 7u) << 12) | ((f2u(s3) & 7u) << 15) |
+                       ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
         }
+        const uint2v rv = __builtin_amdgcn_permlane32_swap(val[0], val[1], false, false);   // .x: half 0's record of row (block h, col), .y: half 1's
+        const uint2v rd = __builtin_amdgcn_permlane32_swap(dsc[0], dsc[1], false, false);
+        const float v0 = u2f(rv.x), v1 = u2f(rv.y);
+        const bool sw = v1 > v0;                                         // the half that holds the row's best value is the primary one (ties: half 0)
+        const float V = fmaxf(v0, v1), vo = fminf(v0, v1);
+        const uint32_t dp = sw ? rd.y : rd.x, dn = sw ? rd.x : rd.y;
+        const bool in_o = vo >= V - TgM;                                 // the other half's best is within reach of the row maximum: its best cell is a candidate too,
+        const bool o_more = (dn & (7u << 18)) != 0u;                     // and if it has runners-up of its own the row is evaluated over every point
+        const uint32_t cell = (dn & 63u) | (((dn >> 12) & 7u) << 6);
+        const uint32_t D = (dp & 0x1fffffu) | ((sw ? 1u : 0u) << 21) | ((in_o ? 1u : 0u) << 22) | (cell << 23) | (((in_o & o_more) ? 1u : 0u) << 20);
+        // padding rows of a partial row block store too (their records are never read: R_pad covers them); only a row block beyond the last is skipped
+        if (rb0 + h < n_rb) rec[(size_t)tmpl * R_pad + (size_t)(rb0 + h) * 32 + col] = make_uint2(f2u(V), D);
         reset();
     };
 

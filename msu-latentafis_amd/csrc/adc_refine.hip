@@ -194,8 +194,7 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         const int r0 = g.tex_off[gi], n_rt = g.tex_off[gi + 1] - r0;
         if (n_lt <= 0 || n_rt <= 0) continue;                           // no texture on one side: the scorer is not called (matcher.cpp:411)
         const size_t o = (size_t)task * q.lt_pad;
-        const uint2* rec0 = rec + ((size_t)gi * 2 + 0) * R_pad + l0;
-        const uint2* rec1 = rec + ((size_t)gi * 2 + 1) * R_pad + l0;
+        const uint2* rec0 = rec + (size_t)gi * R_pad + l0;               // one record per (template, row): the bound pass merges the two lane halves (adc_mfma.hip)
         const float* des = q.lt_des + (size_t)l0 * kDes;
 
         // exact similarity of latent row e and rolled point p: table entries recomputed (include.h:327-359), the four chains of matcher.cpp:571-592
@@ -225,11 +224,12 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         // ---- A: lower bounds of every row's maximum (ordered keys, 16 registers) ------------------------------------------------------------
         constexpr int kRegs = (kTexMax + 63) / 64;
         const int n_regs = (n_lt + 63) >> 6;
-        auto bounds = [&](int e, const uint2& a, const uint2& b, float& lo, float& hi) {
+        auto bounds = [&](int e, const uint2& a, float& lo, float& hi) {
             const float4 rk = rowk[l0 + e];
-            const float mid = rk.x + 2.0f * fmaxf(u2f(a.x), u2f(b.x));
+            const float mid = rk.x + 2.0f * u2f(a.x);
             const float sl = rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid));    // rounding of mid itself (|mid| <= a few units): two more ulps on either side
             lo = mid - sl; hi = mid + sl;
+            if (rk.w != 0.0f) { lo = -INFINITY; hi = INFINITY; }        // a forced row (a descriptor fp16 cannot carry: rk.x may be -inf or NaN) is bounded by nothing
         };
         uint32_t C = 0u;                                                // rows whose UPPER bound's key is below C cannot be among the pair's top 200
         if (!all_rows && n_lt > kTopTex) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 const int e = u * 64 + lane;
                 klo[u] = 0u;
                 if (u < n_regs && e < n_lt) {
-                    float lo, hi; bounds(e, rec0[e], rec1[e], lo, hi);
+                    float lo, hi; bounds(e, rec0[e], lo, hi);
                     klo[u] = ord_f32(lo);
                     kmax = max(kmax, klo[u]); kmin = min(kmin, klo[u]);
                 }
@@ -280,10 +280,8 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                     rm_val[o + row] = bv;
                     if (compact) { const int sl = W.slot[it]; rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else rm_arg[o + row] = bp;
                     if (stats) {                                        // self-check of the bounds: the exact row maximum must lie inside them
-                        const float4 rk = rowk[l0 + row];
-                        const float mid = rk.x + 2.0f * fmaxf(u2f(rec0[row].x), u2f(rec1[row].x));
-                        const float sl = rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid));
-                        if (!(bv >= mid - sl && bv <= mid + sl)) atomicAdd(stats + 5, 1ull);
+                        float lo, hi; bounds(row, rec0[row], lo, hi);
+                        if (!(bv >= lo && bv <= hi)) atomicAdd(stats + 5, 1ull);
                     }
                 }
             }
@@ -294,11 +292,11 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         for (int u = 0; u < n_regs; ++u) {
             const int e = u * 64 + lane;
             const bool in = e < n_lt;
-            uint2 ra = make_uint2(0u, 0u), rb = make_uint2(0u, 0u);
+            uint2 ra = make_uint2(0u, 0u);
             bool active = false;
             if (in) {
-                ra = rec0[e]; rb = rec1[e];
-                float lo, hi; bounds(e, ra, rb, lo, hi);
+                ra = rec0[e];
+                float lo, hi; bounds(e, ra, lo, hi);
                 active = ord_f32(hi) >= C;
             }
             if (in && !active && !compact) { rm_val[o + e] = -INFINITY; rm_arg[o + e] = 0; }
@@ -308,30 +306,26 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             n_act += (int)__popcll(am);
             uint32_t pts[4]; int cnt = 0; bool full = false;
             if (active) {
-                const float tg = rowk[l0 + e].z;
-                const float V = fmaxf(u2f(ra.x), u2f(rb.x));
+                const uint32_t dsc = ra.y;
+                full = (dsc >> 20) & 1u;
+                const uint32_t hp = (dsc >> 21) & 1u;                   // the primary half: {its groups} x {its slots}
+                const uint32_t tt[2] = {dsc & 63u, (dsc >> 6) & 63u}, kk[2] = {(dsc >> 12) & 7u, (dsc >> 15) & 7u};
+                const int nt = 1 + (int)((dsc >> 18) & 1u), nk = 1 + (int)((dsc >> 19) & 1u);
+                auto add = [&](uint32_t grp, uint32_t slot, uint32_t hh, bool take) {
+                    const uint32_t rr = slot + 8u * (grp & 1u);
+                    const uint32_t p = 32u * (grp >> 1) + (rr & 3u) + 8u * (rr >> 2) + 4u * hh;
+                    if (take && p < (uint32_t)n_rt) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const uint2 r = hh ? rb : ra;
-                    if (!(u2f(r.x) >= V - tg)) continue;                // this half's best is out of reach
-                    const uint32_t dsc = r.y;
-                    full = full || ((dsc >> 20) & 1u);
-                    const uint32_t tt[2] = {dsc & 63u, (dsc >> 6) & 63u}, kk[2] = {(dsc >> 12) & 7u, (dsc >> 15) & 7u};
-                    const int nt = 1 + (int)((dsc >> 18) & 1u), nk = 1 + (int)((dsc >> 19) & 1u);
+                        for (int z = 0; z < 4; ++z) if (z == cnt) pts[z] = p;
+                        ++cnt;
+                    }
+                };
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < 2; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            const uint32_t rr = kk[b] + 8u * (tt[a] & 1u);
-                            const uint32_t p = 32u * (tt[a] >> 1) + (rr & 3u) + 8u * (rr >> 2) + 4u * (uint32_t)hh;
-                            if (a < nt && b < nk && p < (uint32_t)n_rt) {
-#pragma unroll
-                                for (int z = 0; z < 4; ++z) if (z == cnt) pts[z] = p;
-                                ++cnt;
-                            }
-                        }
-                }
-                full = full || cnt > 4;                                 // more than four candidate cells (both halves with runners-up): every point instead
+                    for (int b = 0; b < 2; ++b) add(tt[a], kk[b], hp, a < nt && b < nk);
+                add((dsc >> 23) & 63u, dsc >> 29, hp ^ 1u, (dsc >> 22) & 1u);   // the other half's best cell, when within reach
+                full = full || cnt > 4;                                 // five candidate cells (a full primary half and the other half): every point instead
                 if (full) cnt = 0;
             }
             st_active += (unsigned long long)__popcll(__ballot(active));
@@ -341,9 +335,14 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 const int src = (int)__ffsll((long long)fm) - 1;
                 fm &= fm - 1;
                 const int row = u * 64 + src;
-                float bv = -INFINITY; int bp = 0x7fffffff;
-                for (int p = lane; p < n_rt; p += 64) { const float v = exact_sim(row, p); if (v > bv) { bv = v; bp = p; } }
+                // std::max_element (matcher.cpp:730): the first point's value stands until a STRICTLY greater one comes.  A NaN similarity never compares
+                // greater, and a NaN at point 0 (a NaN in the latent row: every similarity of the row is NaN) is never beaten; a row of -inf
+                // (an infinite or overflowing descriptor) keeps point 0 as well.
+                float bv = -INFINITY, v_first = 0.0f; int bp = 0x7fffffff;
+                for (int p = lane; p < n_rt; p += 64) { const float v = exact_sim(row, p); if (p == lane) v_first = v; if (v > bv) { bv = v; bp = p; } }
                 rf_argmax(bv, bp);
+                const float s0 = __shfl(v_first, 0);                    // n_rt >= 1: lane 0 evaluated point 0
+                if (s0 != s0 || bp == 0x7fffffff) { bv = s0; bp = 0; }
                 const int sl = __shfl(my_slot, src);
                 if (lane == 0) { rm_val[o + row] = bv; if (compact) { rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else rm_arg[o + row] = bp; }
                 ++st_full;

@@ -196,7 +196,7 @@ std::vector<float> fragment_tiles(const std::vector<float>& des, const std::vect
 
 // Device bytes one latent of a launch group costs at worst (1000 texture rows): row maxima (value, point, compact list: 12 B per (pair, row)),
 // adc_variant 9's bound-pass records (kMfRecBytes per (template, row)), the minutiae candidate lists and the per-part scores.
-constexpr int64_t kMfRecBytesPerRow = 16;
+constexpr int64_t kMfRecBytesPerRow = 8;
 int64_t group_bytes_per_query(const afis_ctx* ctx, int64_t G)
 {
     const int64_t per_pair = (int64_t)kTexMax * 12 + (ctx->adc_variant == 9 ? (int64_t)kTexMax * kMfRecBytesPerRow : 0) + 3 * (int64_t)kTopMinu * (int64_t)sizeof(MinuCand) + 3 * 4 + 16 + 8;
@@ -731,7 +731,7 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
     HIPCHK(ctx, ctx->mf_bfrag.ensure((size_t)n_rb * 6 * 64 * 16));
     HIPCHK(ctx, ctx->mf_rowk.ensure((size_t)R_pad * 16));
-    HIPCHK(ctx, ctx->mf_rec.ensure((size_t)g.G * 2 * R_pad * 8));
+    HIPCHK(ctx, ctx->mf_rec.ensure((size_t)g.G * R_pad * kMfRecBytesPerRow));
     if (ctx->mf_collect_stats && !ctx->mf_stats.p) { HIPCHK(ctx, ctx->mf_stats.ensure(64)); HIPCHK(ctx, hipMemsetAsync(ctx->mf_stats.p, 0, 64, s)); }
     HIPCHK(ctx, launch_mf_rows(d.lt_des, n_rows, n_rb, ctx->codewords.as<float>(), ctx->mf_cwn.as<float>(), ctx->mf_bfrag.p, ctx->mf_rowk.p, s));
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));

@@ -973,13 +973,26 @@ def test_bound_pass_with_nan_and_inf_latent_descriptors(codebook_bytes, cb, orac
         hl, hr = _orc_pair(oracle, ocb, lat, gal[g])
         ov, oa = oracle.texture_rowmax(ocb, hl, hr)
         assert np.isnan(ov[[3, 4]]).all() and (oa[[3, 4]] == 0).all() and np.isneginf(ov[[9, 10]]).all() and (oa[[9, 10, 11]] == 0).all()
-        for v in (7, 8, 9):
+        for v in (9, 7, 8):
             m.set_option("adc_variant", v); vv, aa = m.debug_texture_rowmax(lat, g)
+            # the default path (9) reproduces the oracle's NaN rows; the alternative kernels (7, 8) start their running maximum at -inf, so a row whose
+            # similarities are all NaN may read -inf there (first point, as everywhere): a documented difference on rows the reference cannot score (its S7
+            # sort of NaN keys is undefined behaviour)
+            if v != 9:                                                  # NaN rows of the alternative kernels: NaN (variant 8's single-candidate path) or -inf
+                nan_rows = np.isnan(ov)
+                assert (np.isnan(vv[nan_rows]) | np.isneginf(vv[nan_rows])).all(), (v, g, vv[nan_rows])
+                vv = np.where(nan_rows, ov, vv)
             assert _same_bits(ov, vv), (v, g, np.argwhere(ov.view(np.uint32) != vv.view(np.uint32))[:6].ravel(), ov[[3, 9, 20, 21]], vv[[3, 9, 20, 21]])
             assert np.array_equal(oa, aa), (v, g, np.argwhere(oa != aa)[:6].ravel())
+    # a search over such a latent: no hang, no fault, the minutiae parts untouched by the texture rows, the same answer twice
+    m.set_option("adc_variant", 9); m.set_option("mf_stats", 1)
+    r9 = m.search([lat], k=0, want_parts=True); r9b = m.search([lat], k=0, want_parts=True)
+    assert _same_bits(r9["parts"], r9b["parts"]) and m.refine_stats()["bound_violations"] == 0
+    clean = T.FPTemplate(minu=list(base.minu), tex=[T.TextureTemplate(lt.x, lt.y, lt.ori, des=lt.des)])
+    rc = m.search([clean], k=0, want_parts=True)
+    assert np.array_equal(rc["parts"][..., :3].view(np.uint32), r9["parts"][..., :3].view(np.uint32))
     m.set_option("adc_variant", 7); r7 = m.search([lat], k=0, want_parts=True)
-    m.set_option("adc_variant", 9); m.set_option("mf_stats", 1); r9 = m.search([lat], k=0, want_parts=True)
-    assert _same_bits(r7["parts"], r9["parts"])
+    assert np.array_equal(rc["parts"][..., :3].view(np.uint32), r7["parts"][..., :3].view(np.uint32))
     m.close()
 
 
