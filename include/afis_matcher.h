@@ -102,6 +102,9 @@ int afis_gallery_add(afis_ctx* ctx, const afis_template_view* templates, int n);
  * *load_rc receives the reference's return code (0 ok, 1 empty file, 2, 4, -1); an entry is ALWAYS appended so
  * indices stay aligned with the caller's file list (empty entry => score -1, matcher.cpp:184-187). */
 int afis_gallery_add_dat(afis_ctx* ctx, const void* bytes, size_t len, int* load_rc);
+/* n rolled .dat files in one call: parsed on the host's threads, appended in order; load_rc (optional) receives n reader codes.
+ * Nothing is appended when any file is rejected (AFIS_EINVAL, as afis_gallery_add_dat). */
+int afis_gallery_add_dat_batch(afis_ctx* ctx, const void* const* bytes, const size_t* lens, int64_t n, int* load_rc);
 /* Bulk add of n templates with exactly one minutiae and one texture template each, as concatenated arrays with
  * CSR offsets (off[n+1], in points).  A zero-length range means "template absent". */
 int afis_gallery_add_packed(afis_ctx* ctx, int64_t n,

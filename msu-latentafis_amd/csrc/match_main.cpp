@@ -35,6 +35,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/afis_matcher.h"
@@ -71,6 +72,21 @@ struct Latent {
     }
 };
 
+// Wall time of the job's stages, printed to stderr when AFIS_MATCH_TIMING is set (the reference prints only the total, matcher.cpp:209, :333):
+// scan = directory / container listing, load = reading + parsing the rolled templates, commit = SoA packing + upload to HBM,
+// latents = reading + parsing the latent files, search = afis_search (+ afis_correspondences), exchange = the multi-rank exchange step, write = the CSV files.
+struct StageClock {
+    double scan = 0, load = 0, commit = 0, latents = 0, search = 0, exchange = 0, write = 0;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now().time_since_epoch()).count(); }
+    void report(int rank, double total) const
+    {
+        if (!getenv("AFIS_MATCH_TIMING")) return;
+        fprintf(stderr, "match[rank %d] timing (ms): scan %.1f  load %.1f  commit %.1f  latents %.1f  search %.1f  exchange %.1f  write %.1f  total %.1f\n",
+                rank, scan, load, commit, latents, search, exchange, write, total);
+    }
+};
+StageClock g_clock;
+
 #define CHECK(ctx, call) do { int rc_ = (call); if (rc_ != AFIS_OK) { std::cerr << "match: " #call " failed (" << rc_ << "): " << afis_last_error(ctx) << std::endl; return 2; } } while (0)
 
 // -g is either the reference's directory of rolled .dat files or ONE packed gallery container (afis_gallery_save); the container
@@ -91,15 +107,28 @@ std::vector<fs::path> list_gallery(const std::string& g)
 int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path>& files, const std::string& pack_to, int64_t lo = 0, int64_t hi = -1)
 {
     if (hi < 0) hi = (int64_t)files.size();
+    const double t_load = StageClock::now();
     if (fs::is_regular_file(fs::path(g))) {
         CHECK(ctx, afis_gallery_load(ctx, g.c_str(), lo, hi - lo));
     } else {
-        std::vector<uint8_t> b;
-        for (int64_t i = lo; i < hi; ++i) {
-            read_file(files[(size_t)i].string(), b);
-            int load_rc = 0;
-            CHECK(ctx, afis_gallery_add_dat(ctx, b.data(), b.size(), &load_rc));
-            if (load_rc == 8) fprintf(stderr, "warning: %s: descriptor length outside 1..192, template discarded (scores -1)\n", files[(size_t)i].string().c_str());
+        // The reference re-reads every rolled file for every pair (matcher.cpp:173, :278); here each file is read and parsed ONCE, in slices of 8192 files:
+        // the reads are spread over the host's threads, the parsing is afis_gallery_add_dat_batch's (also threaded), the order is the listing's.
+        const int64_t slice = 8192;
+        const unsigned n_thr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::vector<std::vector<uint8_t>> bufs;
+        std::vector<const void*> ptrs; std::vector<size_t> lens; std::vector<int> rcs;
+        for (int64_t s0 = lo; s0 < hi; s0 += slice) {
+            const int64_t n = std::min(slice, hi - s0);
+            bufs.assign((size_t)n, {});
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < n_thr; ++t)
+                th.emplace_back([&, t]() { for (int64_t i = t; i < n; i += n_thr) read_file(files[(size_t)(s0 + i)].string(), bufs[(size_t)i]); });
+            for (std::thread& x : th) x.join();
+            ptrs.resize((size_t)n); lens.resize((size_t)n); rcs.assign((size_t)n, 0);
+            for (int64_t i = 0; i < n; ++i) { ptrs[(size_t)i] = bufs[(size_t)i].data(); lens[(size_t)i] = bufs[(size_t)i].size(); }
+            CHECK(ctx, afis_gallery_add_dat_batch(ctx, ptrs.data(), lens.data(), n, rcs.data()));
+            for (int64_t i = 0; i < n; ++i)
+                if (rcs[(size_t)i] == 8) fprintf(stderr, "warning: %s: descriptor length outside 1..192, template discarded (scores -1)\n", files[(size_t)(s0 + i)].string().c_str());
         }
     }
     if (!pack_to.empty()) {
@@ -108,7 +137,10 @@ int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path
         for (const std::string& n : names) np.push_back(n.c_str());
         CHECK(ctx, afis_gallery_save(ctx, pack_to.c_str(), np.data()));
     }
+    const double t_commit = StageClock::now();
+    g_clock.load += t_commit - t_load;
     CHECK(ctx, afis_gallery_commit(ctx, lo));
+    g_clock.commit += StageClock::now() - t_commit;
     return 0;
 }
 
@@ -233,7 +265,9 @@ int main(int argc, char** argv)
         // ---- One2List_matching, matcher.cpp:216-337 ----
         const fs::path latent_file(args.getCmdOption("-l"));
         const std::string score_file = score_path + latent_file.stem().string() + ".csv";
+        const double t_scan = StageClock::now();
         std::vector<fs::path> rolled = list_gallery(gallery_path);
+        g_clock.scan += StageClock::now() - t_scan;
         if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; return finish(-1); }
         const auto t0 = clk::now();
         std::cout << "Latent Query: " << latent_file << std::endl;
@@ -241,12 +275,16 @@ int main(int argc, char** argv)
         if ((ret = job.agree(plan_shards(job, gallery_path, rolled))) != 0) return finish(ret);
         if ((ret = check_same_gallery(job, rolled)) != 0) return finish(ret);
         if ((ret = job.agree(load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi))) != 0) return finish(ret);
+        double t_s = StageClock::now();
         Latent L; L.load(latent_file);
+        g_clock.latents += StageClock::now() - t_s;
         if (job.root() && L.view.n_minu <= 0 && L.view.n_tex <= 0) { std::ofstream out(score_file); out << 0 << std::endl; }       // :260-268
         const int k = (int)std::min<size_t>(24, rolled.size());
         constexpr int kk = 24;                                                   // fixed-size per-rank block of the exchange
         std::vector<int64_t> idx(kk); std::vector<float> sc(kk); int32_t status = 0;
+        t_s = StageClock::now();
         if ((ret = job.agree(api(afis_search(ctx, &L.view, 1, nullptr, nullptr, &status, kk, idx.data(), sc.data()), "afis_search"))) != 0) return finish(ret);   // padded with -1 beyond the shard
+        g_clock.search += StageClock::now() - t_s;
         if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; return finish(1); }
         if (job.multi) {                                                         // the exchange step: per-shard top-24 -> merged top-24
             std::vector<int64_t> all_i((size_t)job.w.world * kk); std::vector<float> all_s((size_t)job.w.world * kk);
@@ -261,7 +299,9 @@ int main(int argc, char** argv)
             std::vector<int64_t> mine; std::vector<int> pos;
             for (int j = 0; j < k; ++j) if (idx[j] >= job.lo && idx[j] < job.hi) { mine.push_back(idx[j]); pos.push_back(j); }
             std::vector<int32_t> c((size_t)mine.size() * 3 + 1); std::vector<int16_t> v((size_t)mine.size() * kXY + 1);
+            t_s = StageClock::now();
             if ((ret = job.agree(api(afis_correspondences(ctx, &L.view, mine.data(), (int)mine.size(), c.data(), v.data()), "afis_correspondences"))) != 0) return finish(ret);
+            g_clock.search += StageClock::now() - t_s;
             for (size_t a = 0; a < mine.size(); ++a) {
                 memcpy(&counts[(size_t)pos[a] * 3], &c[a * 3], 3 * sizeof(int32_t));
                 memcpy(&xy[(size_t)pos[a] * kXY], &v[a * kXY], kXY * sizeof(int16_t));
@@ -278,6 +318,7 @@ int main(int argc, char** argv)
             }
         }
         if (!job.root()) return finish(0);
+        t_s = StageClock::now();
         std::ofstream out(score_file);
         out << "filename,score" << std::endl;
         std::cout << "Match Results" << std::endl << "----------------" << std::endl << "Rank     Filename      Score" << std::endl;
@@ -293,7 +334,10 @@ int main(int argc, char** argv)
             }
             std::cout << std::to_string(j + 1) << "        " << rolled[idx[j]].filename() << "       " << sc[j] << std::endl;
         }
-        std::cout << "Total matching duration (ms): " << std::chrono::duration<double, std::milli>(clk::now() - t0).count() << std::endl;
+        g_clock.write += StageClock::now() - t_s;
+        const double total_l = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        std::cout << "Total matching duration (ms): " << total_l << std::endl;
+        g_clock.report(job.w.rank, total_l + g_clock.scan);
     } else {
         // ---- List2List_matching, matcher.cpp:96-214 ----
         std::string latent_dir;
@@ -302,11 +346,17 @@ int main(int argc, char** argv)
             std::cout << "Missing argument for latent template or directory. Assuming batch matching, using default directory from afis.config" << std::endl;
             if (!from_config("LatentTemplateDirectory", latent_dir)) return finish(2);
         }
+        const double t_scan = StageClock::now();
         std::vector<fs::path> latents = list_dat(latent_dir);
         for (const fs::path& p : latents) std::cout << "latent template file" << p << std::endl;
         if (latents.empty()) { std::cout << "No latent templates found in directory: " << latent_dir << std::endl; return finish(-1); }
         std::vector<fs::path> rolled = list_gallery(gallery_path);
-        for (const fs::path& p : rolled) std::cout << "rolled template file" << p << std::endl;
+        {   // one "rolled template file<path>" line per gallery file, as the reference prints them (matcher.cpp:127): a million lines go out in one piece
+            std::string lines;
+            for (const fs::path& p : rolled) { std::ostringstream q; q << p; lines += "rolled template file"; lines += q.str(); lines += '\n'; }
+            std::cout << lines << std::flush;
+        }
+        g_clock.scan += StageClock::now() - t_scan;
         if (rolled.empty()) { std::cout << "No rolled templates found in directory: " << gallery_path << std::endl; return finish(-1); }
         std::cout << "Gallery size: " << rolled.size() << std::endl;
         const auto t0 = clk::now();
@@ -315,24 +365,33 @@ int main(int argc, char** argv)
         if ((ret = job.agree(load_gallery(ctx, gallery_path, rolled, pack_to, job.lo, job.hi))) != 0) return finish(ret);
         const size_t G = rolled.size(), Gl = (size_t)(job.hi - job.lo), Gm = (size_t)job.g_max;
         const size_t batch = 16;
+        std::vector<std::string> quoted;                                         // the gallery paths as `operator<<(ostream&, path)` prints them (quoted, escaped) + ","
         for (size_t i0 = 0; i0 < latents.size(); i0 += batch) {
             const size_t nb = std::min(batch, latents.size() - i0);
+            double t_s = StageClock::now();
             std::vector<Latent> Ls(nb); std::vector<afis_template_view> views(nb);
             for (size_t i = 0; i < nb; ++i) { Ls[i].load(latents[i0 + i]); views[i] = Ls[i].view; }
+            g_clock.latents += StageClock::now() - t_s;
             std::vector<float> scores(nb * G); std::vector<int32_t> status(nb);
+            t_s = StageClock::now();
             if (!job.multi) {
                 if ((ret = api(afis_search(ctx, views.data(), (int)nb, scores.data(), nullptr, status.data(), 0, nullptr, nullptr), "afis_search")) != 0) return finish(ret);
+                g_clock.search += StageClock::now() - t_s;
             } else {                                                             // the exchange step: score columns of every shard
                 std::vector<float> part(nb * std::max<size_t>(Gl, 1)), block(nb * std::max<size_t>(Gm, 1), -1.0f), all((size_t)job.w.world * block.size());
                 if ((ret = job.agree(api(afis_search(ctx, views.data(), (int)nb, part.data(), nullptr, status.data(), 0, nullptr, nullptr), "afis_search"))) != 0) return finish(ret);
+                g_clock.search += StageClock::now() - t_s;
+                t_s = StageClock::now();
                 for (size_t i = 0; i < nb; ++i) memcpy(&block[i * Gm], &part[i * Gl], Gl * sizeof(float));
                 if (!xchg(block.data(), all.data(), block.size() * sizeof(float))) return finish(2);
                 for (int r = 0; r < job.w.world; ++r) {
                     const size_t lo = (size_t)job.bounds[(size_t)r].first, n = (size_t)(job.bounds[(size_t)r].second - job.bounds[(size_t)r].first);
                     for (size_t i = 0; i < nb; ++i) memcpy(&scores[i * G + lo], &all[(size_t)r * block.size() + i * Gm], n * sizeof(float));
                 }
+                g_clock.exchange += StageClock::now() - t_s;
                 if (!job.root()) continue;
             }
+            t_s = StageClock::now();
             for (size_t i = 0; i < nb; ++i) {
                 const fs::path& lf = latents[i0 + i];
                 std::cout << lf << std::endl;
@@ -345,11 +404,21 @@ int main(int argc, char** argv)
                     continue;
                 }
                 if (status[i] == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Skipping." << std::endl; continue; }   // :191-194
-                std::ofstream out(csv);
-                for (size_t j = 0; j < G; ++j) out << rolled[j] << "," << std::setprecision(3) << std::fixed << scores[i * G + j] << std::endl;   // :201-204
+                // :201-204: one `"<path>",<score %.3f>` line per gallery file.  The same bytes as `out << path << "," << setprecision(3) << fixed << score << endl`,
+                // formatted into one buffer and written once (endl flushes every line: 10^5 - 10^6 write calls per latent)
+                if (quoted.empty()) { quoted.reserve(G); for (size_t j = 0; j < G; ++j) { std::ostringstream q; q << rolled[j]; quoted.push_back(q.str() + ","); } }
+                std::string buf;
+                buf.reserve(G * (quoted.empty() ? 16 : quoted[0].size() + 12));
+                char num[64];
+                for (size_t j = 0; j < G; ++j) { buf += quoted[j]; const int n = snprintf(num, sizeof(num), "%.3f\n", (double)scores[i * G + j]); buf.append(num, (size_t)n); }
+                std::ofstream out(csv, std::ios::binary);
+                out.write(buf.data(), (std::streamsize)buf.size());
             }
+            g_clock.write += StageClock::now() - t_s;
         }
-        std::cout << "Total matching duration (ms): " << std::chrono::duration<double, std::milli>(clk::now() - t0).count() << std::endl;
+        const double total_d = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+        std::cout << "Total matching duration (ms): " << total_d << std::endl;
+        g_clock.report(job.w.rank, total_d + g_clock.scan);
     }
     return finish(ret);
 }

@@ -290,7 +290,7 @@ bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std:
 }
 
 bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
-                            std::vector<int32_t>* tex_counts, std::string& err)
+                            std::vector<int32_t>* tex_counts, std::string& err, bool load_data)
 {
     Mapped m; GalHeader h; size_t sizes[kGalSections];
     if (!m.open_file(path, err) || !check_header(m, path, h, sizes, err)) return false;
@@ -301,6 +301,7 @@ bool read_gallery_container(const std::string& path, int64_t first, int64_t coun
         if (mo[i + 1] < mo[i] || to[i + 1] < to[i] || mo[i + 1] > h.n_minu || to[i + 1] > h.n_tex || mo[0] != 0 || to[0] != 0) { err = path + ": corrupt offsets"; return false; }
     if (tex_counts) { tex_counts->resize((size_t)h.G); for (int64_t i = 0; i < h.G; ++i) (*tex_counts)[(size_t)i] = (int32_t)(to[i + 1] - to[i]); }
     const int64_t m0 = mo[first], m1 = mo[first + count], t0 = to[first], t1 = to[first + count];
+    if (load_data) {                                                       // listing the names / counts of a 5 GB container must not copy its arrays
     auto app = [&](auto& vec, int sec, int64_t a, int64_t b, size_t per) {
         typedef typename std::remove_reference<decltype(vec)>::type V;
         const typename V::value_type* src = (const typename V::value_type*)(m.p + h.off[sec]);
@@ -311,6 +312,7 @@ bool read_gallery_container(const std::string& path, int64_t first, int64_t coun
     const int64_t mb = out.minu_off.back() - m0, tb = out.tex_off.back() - t0;
     const uint8_t* emp = m.p + h.off[2];
     for (int64_t i = first; i < first + count; ++i) { out.minu_off.push_back(mo[i + 1] + mb); out.tex_off.push_back(to[i + 1] + tb); out.empty.push_back(emp[i]); }
+    }
     if (names) {
         const int64_t* no = (const int64_t*)(m.p + h.off[11]); const char* blob = (const char*)(m.p + h.off[12]);
         for (int64_t i = first; i < first + count; ++i) {

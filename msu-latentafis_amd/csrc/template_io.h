@@ -63,7 +63,7 @@ bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std:
 // appends templates [first, first+count) (count < 0: to the end) to `out`; names / tex_counts (texture points of EVERY template in
 // the file, for balanced sharding) are optional
 bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
-                            std::vector<int32_t>* tex_counts, std::string& err);
+                            std::vector<int32_t>* tex_counts, std::string& err, bool load_data = true);   // load_data false: names / counts only, the arrays are not copied
 
 // Return codes of the two parsers are the reference's: 0 ok, 1 empty file (latent: size <= 0, rolled: size <= 10),
 // 2 too many minutiae in a minutiae template, 4 ridge-flow block too large, -1 too many points in a texture template.

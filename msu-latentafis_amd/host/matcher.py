@@ -44,7 +44,7 @@ class Timing(C.Structure):
                 ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("reserved_", C.c_int32)]
 
 
-EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat",
+EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
            "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option"]
@@ -63,6 +63,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_last_error.argtypes = [vp]; lib.afis_last_error.restype = C.c_char_p
     lib.afis_gallery_add.argtypes = [vp, C.POINTER(TemplateView), C.c_int]
     lib.afis_gallery_add_dat.argtypes = [vp, C.c_char_p, C.c_size_t, i32p]
+    if hasattr(lib, "afis_gallery_add_dat_batch"):
+        lib.afis_gallery_add_dat_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int64, i32p]
     lib.afis_gallery_add_packed.argtypes = [vp, C.c_int64, i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, fp,
                                             i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, C.POINTER(C.c_uint8)]
     lib.afis_gallery_commit.argtypes = [vp, C.c_int64]
@@ -174,6 +176,15 @@ class Matcher:
         rc = C.c_int32(0)
         self._chk(self.lib.afis_gallery_add_dat(self.ctx, buf, len(buf), C.byref(rc)))
         return rc.value
+
+    def gallery_add_dat_batch(self, bufs: Sequence[bytes]) -> np.ndarray:
+        """n rolled .dat files at once (parsed on the host's threads); returns the reader's code per file."""
+        n = len(bufs)
+        arr = (C.c_char_p * max(1, n))(*bufs)
+        lens = (C.c_size_t * max(1, n))(*[len(b) for b in bufs])
+        rc = np.zeros(max(1, n), np.int32)
+        self._chk(self.lib.afis_gallery_add_dat_batch(self.ctx, arr, lens, n, _ptr(rc, C.c_int32)))
+        return rc[:n]
 
     def gallery_add_packed(self, g):
         mo = np.ascontiguousarray(g.minu_off, np.int64); to = np.ascontiguousarray(g.tex_off, np.int64)
