@@ -20,6 +20,9 @@
 // the fp16 codebook in LDS (64 KB) straight into MFMA operand layout (another 48 KB of LDS, double buffered); HBM carries 20 bytes per point.
 #include "afis_device.h"
 #include <algorithm>
+#ifndef AFIS_MF_ABLATE
+#define AFIS_MF_ABLATE 0
+#endif
 
 namespace afis {
 
@@ -60,20 +63,30 @@ __device__ __forceinline__ float med3f(float a, float b, float c) { return __bui
 // stage barrier in the middle of a step (3 % faster, 256 registers with spills: not kept); an s_sleep of 0 / 200 / 400 cycles by wave class after each
 // stage barrier, so that the three waves of a SIMD start their stages staggered (no change); fixed wave priorities 3 / 2 / 1 for the three waves of a SIMD (no change).
 // ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kM12Threads = 768, kM12RowBlocks = 24, kM12StageTiles = 6;
-struct __align__(16) M12Stage {
-    uint4 a[kM12StageTiles][12][32];
-    float nrm[kM12StageTiles][32];
-    int2 meta[kM12StageTiles];
+// NB = row blocks (of 32 latent rows) per wave.  A workgroup always covers 24 row blocks = 768 rows: 24 / NB waves.  Every thread decodes one
+// (point, 4 sub-quantizers) item per stage, so a stage is threads / 128 tiles.
+//   NB = 2: 12 waves, three per SIMD (<= 168 registers), stages of 6 tiles.  Every wave reads every operand tile from LDS itself: 10 KB per tile and wave (6 KB of
+//           A fragments + 4 KB of point terms) for 12 MFMAs — 12 waves x 10 KB = 960 LDS-cycles per tile round against 1152 matrix-pipe cycles per SIMD: the LDS return path
+//           is all but co-critical (with the tracking stubbed out AND the decode skipped the kernel still takes 0.83 of its time: profiles/r04_bound_pass_ablation.json).
+//   NB = 3:  8 waves, two per SIMD (<= 256 registers), stages of 4 tiles: the same 10 KB feed 18 MFMAs (the point terms are shared by the three row blocks), a third less
+//           LDS traffic per MFMA.
+constexpr int kM12RowBlocks = 24;
+template <int TILES> struct __align__(16) M12Stage {
+    uint4 a[TILES][12][32];
+    float nrm[TILES][32];
+    int2 meta[TILES];
 };
 
-__global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
+template <int NB>
+__global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
                                                             const int2* __restrict__ tile_meta, const int32_t* __restrict__ tile0, const uint4* __restrict__ cw16,
                                                             const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
                                                             int n_rg, int chunk, uint2* __restrict__ rec)
 {
+    constexpr int kWaves = kM12RowBlocks / NB, kThreads = 64 * kWaves, kStageTiles = kThreads / 128;
+    static_assert(kWaves * NB == kM12RowBlocks && kStageTiles * 128 == kThreads, "row blocks per wave must divide 24, and the threads must decode whole tiles");
     __shared__ uint4 s_cw[kM * kK];                                     // 64 KB
-    __shared__ M12Stage s_st[2];                                        // 2 x 37.7 KB
+    __shared__ M12Stage<kStageTiles> s_st[2];                           // 2 x 6.3 KB per tile of the stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
@@ -82,16 +95,16 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
     const int tile_lo = tile0[t_lo], tile_hi = tile0[t_hi];                // tiles of 32 rolled points; a template owns ceil(n/32) of them
     const int n_tiles = tile_hi - tile_lo;
     if (n_tiles <= 0) return;
-    const int n_stages = (n_tiles + kM12StageTiles - 1) / kM12StageTiles;
-    for (int i = tid; i < kM * kK; i += kM12Threads) s_cw[i] = cw16[i];
+    const int n_stages = (n_tiles + kStageTiles - 1) / kStageTiles;
+    for (int i = tid; i < kM * kK; i += kThreads) s_cw[i] = cw16[i];
 
     const int h = lane >> 5, col = lane & 31;
-    const int rb0 = rg * kM12RowBlocks + wave * 2;
+    const int rb0 = rg * kM12RowBlocks + wave * NB;
     const bool wave_ok = rb0 < n_rb;
-    half8 bf[2][6];
-    float Tg[2]; bool row_ok[2], force[2];
+    half8 bf[NB][6];
+    float Tg[NB]; bool force[NB];
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
+    for (int blk = 0; blk < NB; ++blk) {
         const int rb = rb0 + blk;
 #pragma unroll
         for (int kk = 0; kk < 6; ++kk) {
@@ -99,15 +112,14 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
             bf[blk][kk] = __builtin_bit_cast(half8, v);
         }
         const int row = rb * 32 + col;
-        row_ok[blk] = row < n_rows;
-        const float4 rk = row_ok[blk] ? rowk[row] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 rk = row < n_rows ? rowk[row] : make_float4(0.f, 0.f, 0.f, 0.f);
         Tg[blk] = rk.z; force[blk] = rk.w != 0.0f;
     }
-    const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;       // point in tile, sub-quantizer quad, tile of the stage (0..5)
+    const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;       // point in tile, sub-quantizer quad, tile of the stage
     const bool meta_thread = pQ == 1 && pp == 0;
     struct Pf { uint32_t code; float nrm; int2 meta; };
     auto fetch = [&](int s, Pf& f) {
-        const int tile = tile_lo + kM12StageTiles * s + pj;
+        const int tile = tile_lo + kStageTiles * s + pj;
         f.code = 0u; f.nrm = kMfNeg; f.meta = make_int2(0, 0);
         if (tile < tile_hi) {
             const size_t e = (size_t)tile * 32 + pp;
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
         uint4 w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = s_cw[(4 * pQ + i) * kK + ((f.code >> (8 * i)) & 255u)];
-        M12Stage& st = s_st[buf];
+        M12Stage<kStageTiles>& st = s_st[buf];
         st.a[pj][3 * pQ + 0][pp] = make_uint4(w[0].x, w[0].y, w[0].z, w[1].x);
         st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
         st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
@@ -134,10 +146,10 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
     fetch(1, pf_cur);
     __syncthreads();
 
-    float m[2][8], tb[2], ts[2], tu[2];
+    float m[NB][8], tb[NB], ts[NB], tu[NB];
     auto reset = [&]() {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB; ++blk) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) m[blk][k] = kMfNeg;
             tb[blk] = ts[blk] = tu[blk] = kMfNeg;
@@ -156,15 +168,15 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
         for (int k = 0; k < 8; ++k) m[blk][k] = max3f(m[blk][k], X[k], X[k + 8]);
     };
     // Per (template, row) ONE record: the two lane halves of a row (lanes col and col + 32: the points 8q + 0..3 and 8q + 4..7 of every tile) are merged before
-    // the store.  v_permlane32_swap of (block 0's, block 1's) registers hands lanes 0-31 both halves of block 0's rows and lanes 32-63 both halves of
-    // block 1's, so the merge runs once for the wave's 64 rows and the wave stores 512 contiguous bytes per template (round 3 stored 16 B per row and
-    // template, 17.9 GB per launch, and the recomputation kernel read both halves of every row).
-    const float TgM = h ? Tg[1] : Tg[0];
+    // the store.  v_permlane32_swap of (block 2p's, block 2p + 1's) registers hands lanes 0-31 both halves of block 2p's rows and lanes 32-63 both halves of
+    // block 2p + 1's, so one merge serves 64 rows and the wave stores 512 contiguous bytes per template and block pair (round 3 stored 16 B per row and
+    // template, 17.9 GB per launch, and the recomputation kernel read both halves of every row).  An unpaired last block (NB odd) is swapped with itself: both
+    // lane halves then hold its rows, the lower one stores.
     typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
     auto finish_template = [&](int tmpl) {
-        uint32_t val[2], dsc[2];
+        uint32_t val[NB], dsc[NB];
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB; ++blk) {
             float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -177,68 +189,100 @@ __global__ __launch_bounds__(kM12Threads) void k_adc_mfma(GalleryDev g, const ui
             dsc[blk] = (f2u(tb[blk]) & 63u) | ((f2u(ts[blk]) & 63u) << 6) | ((f2u(b3) & 7u) << 12) | ((f2u(s3) & 7u) << 15) |
                        ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
         }
-        const uint2v rv = __builtin_amdgcn_permlane32_swap(val[0], val[1], false, false);   // .x: half 0's record of row (block h, col), .y: half 1's
-        const uint2v rd = __builtin_amdgcn_permlane32_swap(dsc[0], dsc[1], false, false);
-        const float v0 = u2f(rv.x), v1 = u2f(rv.y);
-        const bool sw = v1 > v0;                                         // the half that holds the row's best value is the primary one (ties: half 0)
-        const float V = fmaxf(v0, v1), vo = fminf(v0, v1);
-        const uint32_t dp = sw ? rd.y : rd.x, dn = sw ? rd.x : rd.y;
-        const bool in_o = vo >= V - TgM;                                 // the other half's best is within reach of the row maximum: its best cell is a candidate too,
-        const bool o_more = (dn & (7u << 18)) != 0u;                     // and if it has runners-up of its own the row is evaluated over every point
-        const uint32_t cell = (dn & 63u) | (((dn >> 12) & 7u) << 6);
-        const uint32_t D = (dp & 0x1fffffu) | ((sw ? 1u : 0u) << 21) | ((in_o ? 1u : 0u) << 22) | (cell << 23) | (((in_o & o_more) ? 1u : 0u) << 20);
-        // padding rows of a partial row block store too (their records are never read: R_pad covers them); only a row block beyond the last is skipped
-        if (rb0 + h < n_rb) rec[(size_t)tmpl * R_pad + (size_t)(rb0 + h) * 32 + col] = make_uint2(f2u(V), D);
+#pragma unroll
+        for (int p0 = 0; p0 < NB; p0 += 2) {
+            constexpr bool kDummy = false; (void)kDummy;
+            const bool paired = p0 + 1 < NB;                             // compile-time after unrolling
+            const int p1 = paired ? p0 + 1 : p0;
+            const uint2v rv = __builtin_amdgcn_permlane32_swap(val[p0], val[p1], false, false);   // .x: half 0's record of row (block p0 + h, col), .y: half 1's
+            const uint2v rd = __builtin_amdgcn_permlane32_swap(dsc[p0], dsc[p1], false, false);
+            const float TgM = paired ? (h ? Tg[p1] : Tg[p0]) : Tg[p0];
+            const float v0 = u2f(rv.x), v1 = u2f(rv.y);
+            const bool sw = v1 > v0;                                     // the half that holds the row's best value is the primary one (ties: half 0)
+            const float V = fmaxf(v0, v1), vo = fminf(v0, v1);
+            const uint32_t dp = sw ? rd.y : rd.x, dn = sw ? rd.x : rd.y;
+            const bool in_o = vo >= V - TgM;                             // the other half's best is within reach of the row maximum: its best cell is a candidate too,
+            const bool o_more = (dn & (7u << 18)) != 0u;                 // and if it has runners-up of its own the row is evaluated over every point
+            const uint32_t cell = (dn & 63u) | (((dn >> 12) & 7u) << 6);
+            const uint32_t D = (dp & 0x1fffffu) | ((sw ? 1u : 0u) << 21) | ((in_o ? 1u : 0u) << 22) | (cell << 23) | (((in_o & o_more) ? 1u : 0u) << 20);
+            // padding rows of a partial row block store too (their records are never read: R_pad covers them); only a row block beyond the last is skipped
+            const int rbm = rb0 + p0 + (paired ? h : 0);
+            if (rbm < n_rb && (paired || h == 0)) rec[(size_t)tmpl * R_pad + (size_t)rbm * 32 + col] = make_uint2(f2u(V), D);
+        }
         reset();
     };
 
     for (int s = 0; s < n_stages; ++s) {
         fetch(s + 2, pf_nxt);
-        const M12Stage& st = s_st[s & 1];
+        const M12Stage<kStageTiles>& st = s_st[s & 1];
         if (wave_ok) {
 #pragma unroll
-            for (int j = 0; j < kM12StageTiles; ++j) {
+            for (int j = 0; j < kStageTiles; ++j) {
+#if AFIS_MF_ABLATE == 5 || AFIS_MF_ABLATE == 7          // timing experiments only: the operands are read from LDS once per stage, not per tile
+                const int jr = 0;
+#else
+                const int jr = j;
+#endif
                 floatx16 nrm;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
-                    const float4 v = *reinterpret_cast<const float4*>(&st.nrm[j][8 * q4 + 4 * h]);
+                    const float4 v = *reinterpret_cast<const float4*>(&st.nrm[jr][8 * q4 + 4 * h]);
                     nrm[4 * q4] = v.x; nrm[4 * q4 + 1] = v.y; nrm[4 * q4 + 2] = v.z; nrm[4 * q4 + 3] = v.w;
                 }
                 const int2 mv = st.meta[j];
                 half8 af[6];
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[j][2 * kk + h][col]);
-                floatx16 X0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[0][0], nrm, 0, 0, 0);
-                floatx16 X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[1][0], nrm, 0, 0, 0);
+                for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[jr][2 * kk + h][col]);
+                floatx16 X[NB];
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) X[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[blk][0], nrm, 0, 0, 0);
 #pragma unroll
                 for (int kk = 1; kk < 6; ++kk) {
-                    X0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[0][kk], X0, 0, 0, 0);
-                    X1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[1][kk], X1, 0, 0, 0);
+#pragma unroll
+                    for (int blk = 0; blk < NB; ++blk) X[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[blk][kk], X[blk], 0, 0, 0);
                 }
                 const int my = __builtin_amdgcn_readfirstlane(mv.y);
                 const uint32_t gid = (uint32_t)(2 * (my & 255));
-                track(0, X0, gid);
-                track(1, X1, gid);
+#if AFIS_MF_ABLATE == 1 || AFIS_MF_ABLATE >= 4          // timing experiments only (wrong results): no tracking
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) m[blk][0] = max3f(m[blk][0], X[blk][0], X[blk][15]);
+                (void)gid;
+#else
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk) track(blk, X[blk], gid);
+#endif
                 if (my & 256) finish_template(__builtin_amdgcn_readfirstlane(mv.x));
             }
         }
+#if AFIS_MF_ABLATE == 3 || AFIS_MF_ABLATE >= 4           // timing experiments only: the stages after the first two are not decoded (stale operands)
+        if (s + 1 < n_stages && s < 1) decode((s + 1) & 1, pf_cur);
+#else
         if (s + 1 < n_stages) decode((s + 1) & 1, pf_cur);
+#endif
         pf_cur = pf_nxt;
+#if AFIS_MF_ABLATE == 6 || AFIS_MF_ABLATE == 7           // timing experiments only: no stage barrier
+        if (s < 1) __syncthreads();
+#else
         __syncthreads();
+#endif
     }
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------------
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
-                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream)
+                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec, hipStream_t stream)
 {
     if (n_rb <= 0 || g.G <= 0) return hipSuccess;
     const int n_chunks = (g.G + chunk - 1) / chunk;
     const int n_rg = (n_rb + kM12RowBlocks - 1) / kM12RowBlocks;
     const long long blocks = (long long)n_rg * n_chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_adc_mfma, dim3((unsigned)blocks), dim3(kM12Threads), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
-                       (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
+    if (blocks_per_wave == 3)
+        hipLaunchKernelGGL(k_adc_mfma<3>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 3)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
+                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
+    else
+        hipLaunchKernelGGL(k_adc_mfma<2>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 2)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
+                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
     return hipGetLastError();
 }
 

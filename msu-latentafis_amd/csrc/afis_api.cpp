@@ -80,6 +80,7 @@ struct afis_ctx {
     DevBuf mf_cw16, mf_cwn, g_codes_p, g_nrm_p, g_tile_meta, mf_bfrag, mf_rowk, mf_rec, mf_stats;
     bool mf_cb_built = false, mf_gal_built = false;
     int mf_collect_stats = 0;
+    int mf_blocks = 2;                   // row blocks per wave of the bound pass: 2 (12 waves per workgroup) or 3 (8 waves, a third less LDS traffic per MFMA)
     DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // adc_variant 8: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step, margin), fp32 table
     DevBuf lut, rm_val, rm_arg, rm_cv, rm_n, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     std::vector<float> h_scores, h_parts;
@@ -770,7 +771,7 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
     HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
-                                ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_rec.p, s));
+                                ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_blocks, ctx->mf_rec.p, s));
     if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
     HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
                                   ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr,
@@ -1086,6 +1087,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
+    else if (n == "mf_blocks") { if (value != 2 && value != 3) return fail(ctx, AFIS_EINVAL, "mf_blocks must be 2 or 3"); ctx->mf_blocks = (int)value; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
     return AFIS_OK;

@@ -120,7 +120,7 @@ hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hi
 hipError_t launch_mf_tiles(const GalleryDev& g, const int32_t* t32_blk, const float* cwn, void* codes_p, float* nrm_p, void* tile_meta, hipStream_t stream);
 hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream);
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
-                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, void* rec, hipStream_t stream);
+                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec, hipStream_t stream);
 hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
                              float* rm_val, int32_t* rm_arg, unsigned long long* stats, float* rm_cv, int32_t* rm_n, hipStream_t stream);
 // one correspondence of a minutiae-template list (S3 output), 8 bytes
