@@ -982,6 +982,9 @@ def test_bound_pass_with_nan_and_inf_latent_descriptors(codebook_bytes, cb, orac
                 nan_rows = np.isnan(ov)
                 assert (np.isnan(vv[nan_rows]) | np.isneginf(vv[nan_rows])).all(), (v, g, vv[nan_rows])
                 vv = np.where(nan_rows, ov, vv)
+                n_pts = gal[g].tex[0].n
+                assert ((aa[nan_rows] >= 0) & (aa[nan_rows] < n_pts)).all(), (v, g, aa[nan_rows])     # a valid point (variant 8: not necessarily the first) — never an index S7 cannot follow
+                aa = np.where(nan_rows, oa, aa)
             assert _same_bits(ov, vv), (v, g, np.argwhere(ov.view(np.uint32) != vv.view(np.uint32))[:6].ravel(), ov[[3, 9, 20, 21]], vv[[3, 9, 20, 21]])
             assert np.array_equal(oa, aa), (v, g, np.argwhere(oa != aa)[:6].ravel())
     # a search over such a latent: no hang, no fault, the minutiae parts untouched by the texture rows, the same answer twice
