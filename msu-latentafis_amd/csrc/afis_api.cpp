@@ -664,11 +664,12 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
             rows[(size_t)i + 1] = rows[(size_t)i] + (has ? std::min(std::max(t.tex[0].n, 0), kTexMax) : 0);
         }
         const long long kInf = 1ll << 60;
+        const long long rg_rows = ctx->mf_blocks == 102 ? 512 : 768;
         std::vector<long long> best((size_t)n_q + 1, kInf); std::vector<int> from((size_t)n_q + 1, 0), cnt((size_t)n_q + 1, 0);
         best[0] = 0;
         for (int i = 1; i <= n_q; ++i)
             for (int j = std::max(0, i - per); j < i; ++j) {
-                const long long c = best[(size_t)j] + (rows[(size_t)i] - rows[(size_t)j] + 767) / 768;
+                const long long c = best[(size_t)j] + (rows[(size_t)i] - rows[(size_t)j] + rg_rows - 1) / rg_rows;
                 if (c < best[(size_t)i] || (c == best[(size_t)i] && cnt[(size_t)j] + 1 < cnt[(size_t)i])) { best[(size_t)i] = c; from[(size_t)i] = j; cnt[(size_t)i] = cnt[(size_t)j] + 1; }
             }
         for (int i = n_q; i > 0; i = from[(size_t)i]) cuts.push_back(i);
@@ -767,7 +768,8 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
     // workgroups = row groups x gallery chunks: about 24 per CU (a CU runs one at a time: the end of the launch idles at most ~1/24 of it),
     // a chunk never below 8 templates
-    const int n_rg = (n_rb + 23) / 24;                                 // 24 row blocks per workgroup (adc_mfma.hip)
+    const int wg_rb = ctx->mf_blocks == 102 ? 16 : 24;                 // row blocks per workgroup (adc_mfma.hip)
+    const int n_rg = (n_rb + wg_rb - 1) / wg_rb;
     const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
     HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
@@ -1087,7 +1089,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
-    else if (n == "mf_blocks") { if (value != 2 && value != 3) return fail(ctx, AFIS_EINVAL, "mf_blocks must be 2 or 3"); ctx->mf_blocks = (int)value; }
+    else if (n == "mf_blocks") { if (value != 2 && value != 3 && value != 102) return fail(ctx, AFIS_EINVAL, "mf_blocks must be 2, 3 or 102 (the software-pipelined bound pass)"); ctx->mf_blocks = (int)value; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);
     return AFIS_OK;

@@ -1043,6 +1043,32 @@ def test_bound_pass_magnitude_sweep_up_to_the_forcing_threshold(codebook_bytes, 
     m.close()
 
 
+def test_bound_pass_kernel_forms_are_bit_identical(codebook_bytes, cb, oracle, small):
+    """The matrix-core bound pass exists in three forms — two row blocks per wave (default), three (mf_blocks 3: a third less LDS operand traffic per MFMA) and the
+    two-stage software pipeline (mf_blocks 102) — which differ only in when a wave does what.  Row maxima / first arg-maxima of each against the oracle, and the
+    searches' per-part scores and rank lists against the default form's, bit for bit; workgroup chunks of 1 and 3 templates exercise the stage / template edges
+    of the 4-tile stages the two alternative forms use."""
+    lats, gal = small
+    m = _matcher(codebook_bytes, gal, taps=True)
+    ocb = oracle.codebook(codebook_bytes)
+    hl, hr = cases.to_orc(oracle, ocb, lats, gal)
+    want = m.search(lats, k=10, want_parts=True)
+    for mb in (3, 102):
+        m.set_option("mf_blocks", mb)
+        for chunk in (0, 1, 3):
+            m.set_option("chunk", chunk)
+            got = m.search(lats, k=10, want_parts=True)
+            assert np.array_equal(got["parts"].view(np.uint32), want["parts"].view(np.uint32)) and np.array_equal(got["topk_idx"], want["topk_idx"]), (mb, chunk)
+        for qi in range(len(lats)):
+            for g in (0, 4, 17, len(gal) - 1):
+                val, arg = m.debug_texture_rowmax(lats[qi], g)
+                oval, oarg = oracle.texture_rowmax(ocb, hl[qi], hr[g])
+                assert np.array_equal(val.view(np.uint32), oval.view(np.uint32)) and np.array_equal(arg, oarg), (mb, qi, g)
+    with pytest.raises(M.AfisError):
+        m.set_option("mf_blocks", 4)
+    m.close()
+
+
 def test_matrix_core_bound_pass_selection_statistics(codebook_bytes, cb, medium):
     """adc_variant 9 as the search runs it (rows that cannot reach a pair's top 200 are NOT evaluated): scores equal the direct exact kernel's
     bit for bit on 6 latents x 3000 templates, and the kernel's own counters say what it did — every exact row maximum inside the bounds the
