@@ -323,7 +323,7 @@ def main():
         hbm_achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
         variant = 9 if a.variant < 0 else a.variant
         carried = None
-        cp = os.path.join(ROOT, "profiles", "r03_adc_counters.json")
+        cp = os.path.join(ROOT, "profiles", "r04_adc_counters.json")
         if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only
             try:
                 carried = json.load(open(cp))
@@ -338,8 +338,9 @@ def main():
             roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": MFMA_F16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
                         "traffic": carried.get("traffic_bytes_per_launch") if carried else None,
-                        "traffic_source": ("profiles/r03_adc_counters.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
-                                           "calibrated in profiles/r03_fetch_calibration.json; PMC counters cannot be read inside this run)") if carried else None,
+                        "traffic_source": ("profiles/r04_adc_counters.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
+                                           "MI355X_MICROARCH.md prescribes and profiles/r03_fetch_calibration.json confirms; PMC counters cannot be read inside this run)") if carried else None,
+                        "stage_traffic": carried.get("stage_traffic") if carried else None,
                         "achieved_is": "ALGORITHMIC flops (latent texture rows of the launch x rolled texture points of the shard x 192) / average kernel duration; padding rows / points and the "
                                        "recomputation kernel's work are not counted",
                         "alg_flops_per_launch": alg_flops_launch, "avg_launch_ms": round(bound_ms_avg, 3),
@@ -347,7 +348,8 @@ def main():
                         "hbm_view": {"what": "the same stage (bound pass + recomputation) priced as north_star prices it: 24 algorithmic bytes per rolled texture point per query / stage time", "alg_bytes_per_launch": alg_bytes_launch,
                                      "achieved_GBps": round(hbm_achieved, 2), "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_achieved / HBM_PEAK_GBS, 6)},
                         "unit_fractions_from_counters": carried.get("fractions") if carried else None,
-                        "limiting_resource": "matrix pipe and vector issue in turn: the waves of a SIMD run the tile loop in step (MFMA bursts together, then tracking together), see DESIGN section 4"}
+                        "limiting_resource": "power: the chip holds 1.88 GHz under this kernel (2.34-2.38 GHz under every other kernel of the step) with the matrix pipe 0.60 busy; with its tracking "
+                                             "and decode compiled out the kernel's own MFMA loop reaches 0.60 of the nominal peak (profiles/r04_bound_pass_ablation.json), see DESIGN section 4"}
         else:
             lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
             quantised = variant == 8                                            # the 16-bit pass: 2 LDS bytes per look-up
