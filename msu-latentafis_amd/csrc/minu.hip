@@ -317,6 +317,14 @@ __device__ __forceinline__ uint32_t approx_norm_key(float sv, float rs, float cs
 }
 
 // fb[0] = number of fallback tasks, fb[1 ...] = their task indices
+#ifndef AFIS_MC_ABLATE
+#define AFIS_MC_ABLATE 0
+#endif
+#if AFIS_MC_ABLATE == 1                                                  // timing experiment only (wrong results): no workgroup barriers inside a task
+#define RT_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define RT_SYNC() __syncthreads()
+#endif
 __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, GalleryDev g, const float4* __restrict__ lat_frag,
                                                                 const float4* __restrict__ rol_frag,  // descriptors as operand fragments
                                                                 MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb)
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             }
             sm.hist[tid] = 0u;
             if (tid == 0) sm.thr_bin = -1;
-            __syncthreads();
+            RT_SYNC();
             pf_qs = -1;
             if (qs + 1 < nqs) {                                                      // uniform
                 const int nLn = q.lm_off[qs + 2] - q.lm_off[qs + 1];
@@ -441,6 +449,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 }
             }
             PHASE(16);
+#if AFIS_MC_ABLATE == 2                                                  // timing experiment only: the GEMM and its stores, no selection
+            if (tid == 0) cand_n[task] = 0;
+            __syncthreads();
+            continue;
+#endif
             // ---- S2 (:455-456): index-ascending sums; odd row stride: both walks are conflict free.  Eight reads are issued before
             // the eight dependent adds (one LDS round trip per eight elements instead of one per element).
             if (tid < nR) {
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 for (; k < nR; ++k) sacc += p[k];
                 sm.rowsum[tid - 128] = sacc;
             }
-            __syncthreads();
+            RT_SYNC();
             PHASE(17);
             // ---- S3 (:461-488): the 120 largest norm values.  The kernel is bound by VALU issue (about 2000 wave-instructions per wave
             // and task before this layout), so the selection is organised for few instructions per element: thread = (column cj, row
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                     }
                 }
             }
-            __syncthreads();
+            RT_SYNC();
             PHASE(29);
             {   // thread tid owns bin tid: suffix sums over the higher bins find the bin holding the 120th largest approximate key
                 const int own = (int)sm.hist[tid];
@@ -506,17 +519,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
                 if (lane == 0) sm.wave_tot[wave] = suf;
-                __syncthreads();
+                RT_SYNC();
                 int above = suf - own;
 #pragma unroll
                 for (int w = 0; w < kWaves; ++w) if (w > wave) above += sm.wave_tot[w];
                 if (above < kTopMinu && above + own >= kTopMinu) sm.thr_bin = tid;
                 sm.hist[tid] = (uint32_t)above;                                      // from here on: where the next candidate of this bin goes
             }
-            __syncthreads();
+            RT_SYNC();
             PHASE(30);
             const int B = sm.thr_bin;
-            if (B < 2) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
+            if (B < 2) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
             // ---- the candidates: approximate key >= edge(B) - 2E ----
             {
                 const uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
@@ -537,10 +550,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                     if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 16) | (i << 8) | cj);
                 }
             }
-            __syncthreads();
+            RT_SYNC();
             PHASE(31);
             const int n_c = (int)sm.hist[B];                                         // >= 120: group B ends the list
-            if (n_c > kCandCap) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); continue; }
+            if (n_c > kCandCap) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }
             int ci = 0, cj2 = 0, cbin = 0;
             if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
                 const uint32_t pe = sm.cand_e[tid];
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 13) | (u64)(8191 - (ci * nR + cj2));
             } else if (tid == n_c) sm.cand[tid & (kCandCap - 1)] = 0ull;             // pad of an odd list (n_c == kCandCap is even: nothing is overwritten)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the next task's tiles has landed in LDS (waited for here, before the list's stores join the counter)
-            __syncthreads();
+            RT_SYNC();
             PHASE(18);
             // ---- rank the candidates by counting (composites are unique); ranks < 120 are the list, in the reference's order.
             // Approximate and exact key differ by at most E = 8 << a bin's width (2^19), so a candidate of bin g can only be out of order
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 }
             }
             if (tid == 0) cand_n[task] = kTopMinu;
-            __syncthreads();
+            RT_SYNC();
             PHASE(20);
         }
     }
