@@ -196,16 +196,16 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
  * header) fills only the fields up to `pairs` (48 bytes, the struct of that header); the fields after it need afis_get_timing2. */
 int afis_get_timing(const afis_ctx* ctx, afis_timing* out);
 int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
-/* Tunables: "adc_variant" — every variant gives bit-identical results: 9 [default] = an fp16 matrix-core pass over all (latent row, rolled
- * point) cells bounds every row maximum and pins its candidate points; the rows that can reach a pair's top 200 then get the exact fp32
- * value of their candidates, the table entries recomputed in the reference's arithmetic and order (adc_mfma.hip) — 0.62 x the time of 8;
- * 8 = a 16-bit fixed-point LDS-table pass bounds the candidates, which are then evaluated exactly from an fp32 table in HBM/L2 (the
- * north_star's LDS-LUT design; 0.55 x the time of 7); 7 = direct exact kernel, conflict-free lane classes, 1024-thread workgroups;
- * 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as
- * references (4 and 5 were earlier forms of 6/7 and are rejected).
- * "query_batch" (latents per launch group), "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae
- * candidate kernel), "rowmax_budget_mb", "mf_stats" (adc_variant 9: collect afis_debug_refine_stats).  ("lut_dtype" accepts only 32: the opt-in 16-bit
- * tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
+/* Tunables (INTEGRATION.md section E has the table; timings in profiles/r04_tables.md).  "adc_variant" — every variant gives bit-identical results:
+ * 9 [default] = an fp16 matrix-core pass over all (latent row, rolled point) cells bounds every row maximum and pins its candidate points; the rows that can
+ * reach a pair's top 200 then get the exact fp32 value of their candidates, the table entries recomputed in the reference's arithmetic and order
+ * (adc_mfma.hip, adc_refine.hip); 8 = a 16-bit fixed-point LDS-table pass bounds the candidates, which are then evaluated exactly from an fp32 table in HBM/L2
+ * (the north_star's LDS-LUT design; 1.6 x the time of 9); 7 = direct exact kernel, conflict-free lane classes, 1024-thread workgroups (2.9 x); 6 = the same with 512;
+ * 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
+ * "mf_blocks" (form of variant 9's bound pass: 2 [default] / 3 row blocks per wave, 102 = software-pipelined; bit-identical), "query_batch" (latents per launch group),
+ * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "rowmax_budget_mb" (device memory of a launch group's per-pair
+ * buffers; default 60 % of the free memory), "mf_stats" (adc_variant 9: collect the counters the parity tap afis_debug_refine_stats reads).  ("lut_dtype" accepts only 32: the
+ * opt-in 16-bit tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
 
