@@ -240,6 +240,11 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
     c->device = device_id;
 #define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); afis_destroy(c); return AFIS_EDEVICE; } } while (0)
     CRCHK(hipSetDevice(device_id));
+    if (const char* cm = getenv("AFIS_CU_MASK")) {                           // experiment knob: comma-separated hex words of a CU mask for the context's stream
+        std::vector<uint32_t> words;
+        for (const char* p = cm; *p;) { words.push_back((uint32_t)strtoul(p, nullptr, 16)); const char* q = strchr(p, ','); if (!q) break; p = q + 1; }
+        CRCHK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words.size(), words.data()));
+    } else
     CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     std::vector<float> cw(codewords, codewords + (size_t)M * K * dsub);
     CRCHK(upload(c->codewords, cw, c->stream));
