@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--query-batch", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tile-share", type=int, default=0)
+    ap.add_argument("--bound-cus", type=int, default=-1, help="CUs the bound pass is confined to, the minutiae stage running beside it on the others (-1 = the library's default, 128; 0 = one stream, kernels back to back)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (a few atomics per pair; not for timed runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
@@ -252,6 +253,8 @@ def main():
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)
     if a.tile_share > 0: m.set_option("tile_share", a.tile_share)
+    if a.bound_cus >= 0: m.set_option("bound_cus", a.bound_cus)
+    bound_cus = m.get_option("bound_cus") if (a.variant < 0 or a.variant == 9) else 0
     if a.refine_stats: m.set_option("mf_stats", 1)
     t_up = time.perf_counter()
     m.gallery_add_packed(gal)
@@ -324,7 +327,7 @@ def main():
         variant = 9 if a.variant < 0 else a.variant
         carried = None
         cp = os.path.join(ROOT, "profiles", "r04_adc_counters.json")
-        if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only
+        if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only (PMC passes with the kernels back to back, --bound-cus 0: a kernel's traffic does not depend on what runs beside it)
             try:
                 carried = json.load(open(cp))
             except Exception:
@@ -335,11 +338,16 @@ def main():
             alg_flops_launch = rows_per_step * a.steps / launches * shard_tex_points * 192.0
             bound_ms_avg = tm_acc["adc_bound_ms"] / launches
             tflops = alg_flops_launch / (bound_ms_avg * 1e-3) / 1e12 if bound_ms_avg > 0 else 0.0
-            roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": MFMA_F16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
+            share = (bound_cus / 256.0) if bound_cus > 0 else 1.0                   # the kernel is confined to this share of the chip's CUs (the rest runs the minutiae stage beside it)
+            roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": round(MFMA_F16_PEAK_TFLOPS * share, 1),
+                        "unit": "TFLOP/s", "frac": round(tflops / (MFMA_F16_PEAK_TFLOPS * share), 5),
+                        "cus_used": bound_cus if bound_cus > 0 else 256, "chip_peak": MFMA_F16_PEAK_TFLOPS, "frac_of_chip_peak": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
+                        "peak_is": ("the fp16 matrix peak of the CUs the kernel runs on: it is confined to %d of the 256 CUs (hipExtStreamCreateWithCUMask) and the minutiae stage runs beside it on the others; "
+                                    "frac_of_chip_peak prices the same duration against the whole chip (with --bound-cus 0 the kernel has the chip to itself: frac 0.47)" % bound_cus) if bound_cus > 0 else
+                                   "the chip's fp16 matrix peak (the kernel has every CU)",
                         "traffic": carried.get("traffic_bytes_per_launch") if carried else None,
                         "traffic_source": ("profiles/r04_adc_counters.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
-                                           "MI355X_MICROARCH.md prescribes and profiles/r03_fetch_calibration.json confirms; PMC counters cannot be read inside this run)") if carried else None,
+                                           "MI355X_MICROARCH.md prescribes and profiles/r03_fetch_calibration.json confirms; collected with the kernels back to back, --bound-cus 0; PMC counters cannot be read inside this run)") if carried else None,
                         "stage_traffic": carried.get("stage_traffic") if carried else None,
                         "achieved_is": "ALGORITHMIC flops (latent texture rows of the launch x rolled texture points of the shard x 192) / average kernel duration; padding rows / points and the "
                                        "recomputation kernel's work are not counted",
@@ -371,7 +379,9 @@ def main():
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
-                       "adc_variant": variant, "bound_pass_dtype": ("f16 operands, f32 accumulation on the matrix cores: used for BOUNDS only, every score is the reference's f32 arithmetic" if variant == 9 else
+                       "adc_variant": variant, "bound_cus": bound_cus,
+                       "schedule": ("bound pass on %d CUs, minutiae stage (candidates + lists) beside it on the other %d, then recomputation + texture lists on the whole chip; stage times overlap: their sum exceeds ms_per_step" % (bound_cus, 256 - bound_cus))
+                                   if bound_cus > 0 else "one stream, the kernels of a launch group back to back", "bound_pass_dtype": ("f16 operands, f32 accumulation on the matrix cores: used for BOUNDS only, every score is the reference's f32 arithmetic" if variant == 9 else
                                                                    "u16 fixed point in LDS: used for BOUNDS only" if variant == 8 else "none"), "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
             "roofline": dict(roofline, pipeline_achieved_GBps=round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 3)),

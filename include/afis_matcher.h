@@ -202,12 +202,16 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * (adc_mfma.hip, adc_refine.hip); 8 = a 16-bit fixed-point LDS-table pass bounds the candidates, which are then evaluated exactly from an fp32 table in HBM/L2
  * (the north_star's LDS-LUT design; 1.6 x the time of 9); 7 = direct exact kernel, conflict-free lane classes, 1024-thread workgroups (2.9 x); 6 = the same with 512;
  * 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
- * "mf_blocks" (form of variant 9's bound pass: 2 [default] / 3 row blocks per wave, 102 = software-pipelined; bit-identical), "query_batch" (latents per launch group),
+ * "mf_blocks" (form of variant 9's bound pass: 2 [default] / 3 row blocks per wave, 102 = software-pipelined; bit-identical), "bound_cus" (below), "query_batch" (latents per launch group),
  * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "rowmax_budget_mb" (device memory of a launch group's per-pair
  * buffers; default 60 % of the free memory), "mf_stats" (adc_variant 9: collect the counters the parity tap afis_debug_refine_stats reads).  ("lut_dtype" accepts only 32: the
  * opt-in 16-bit tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
+/* The value an option has now (0 = automatic where the table says so).  "bound_cus": 128 by default — the bound pass runs on a stream confined to half of the chip's CUs
+ * (hipExtStreamCreateWithCUMask) with the minutiae stage beside it on the other half: the pass is power-limited, half the CUs deliver 0.64 of its throughput;
+ * 0 = one stream, kernels back to back; 32 ... 224 in steps of 32; the environment variable AFIS_BOUND_CUS sets the initial value. */
+int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value);
 
 /* The parity-test taps (stage intermediates: afis_debug_*) are NOT part of this library: they are declared in
  * include/afis_matcher_taps.h and exported only by libafis_hip_test.so (the same objects with afis_api.cpp built -DAFIS_PARITY_TAPS),

@@ -60,7 +60,10 @@ struct afis_queries {
 struct afis_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> evpool;      // 8 per query group + 2: the groups of a search run back to back, timings are read at the end
+    hipStream_t stream_hi = nullptr;     // option bound_cus: the complement of stream_lo's CUs, for the minutiae stage while the bound pass runs
+    hipStream_t stream_lo = nullptr;     // option bound_cus: a stream confined to the low N CUs (N / 8 of every XCD) for the power-limited bound pass; the rest of a launch group runs beside it
+    int bound_cus = 0;                   // 0 = off: one stream, the kernels of a group back to back
+    std::vector<hipEvent_t> evpool;      // 10 per query group + 2: the groups of a search run back to back, timings are read at the end
     std::string err;
     DevBuf codewords, table;
     HostGallery hg;
@@ -258,6 +261,13 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
     CRCHK(hipStreamSynchronize(c->stream));
 #undef CRCHK
     *out = c;
+    // The default schedule: the power-limited bound pass on half of the chip's CUs, the minutiae stage beside it on the other half (afis_search_resident; -7.6 % per step at 100k
+    // templates, profiles/r04_overlap_ab.json).  AFIS_BOUND_CUS overrides (0 = one stream, the kernels back to back).  A runtime that refuses CU masks leaves it off.
+    {
+        const char* e = getenv("AFIS_BOUND_CUS");
+        const int64_t n = e ? atoll(e) : 128;
+        if (afis_set_option(c, "bound_cus", n) != AFIS_OK) { c->bound_cus = 0; c->err.clear(); }
+    }
     return AFIS_OK;
 }
 
@@ -273,6 +283,7 @@ void afis_destroy(afis_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipStream_t* ps : {&c->stream_lo, &c->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release(); c->rm_cv.release(); c->rm_n.release();
     c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
@@ -744,12 +755,14 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
 
 // S4-S6 (+ the row selection of S7) of adc_variant 9 for one query group: row constants, matrix-core bound pass, selection by bounds and exact
 // recomputation.  all_rows: every row is evaluated exactly (parity taps); otherwise rows that cannot reach the pair's top 200 get -inf.
-static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr, bool compact = false)
+// sb: the stream of the row constants and the bound pass (the context's stream, or the CU-masked one); refine_now false: the caller launches the selection / recomputation kernel itself (adc_refine_mfma)
+static int adc_refine_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, bool compact);
+static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr, bool compact = false, hipStream_t sb = nullptr, bool refine_now = true)
 {
     const QueryDev& d = grp.dev;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = sb ? sb : ctx->stream;
     const GalleryDev& g = ctx->gal;
-    if (grp.n_lt_rows <= 0 || g.G <= 0) { if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s)); return AFIS_OK; }
+    if (grp.n_lt_rows <= 0 || g.G <= 0) { if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s)); if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s)); return AFIS_OK; }
     if (!ctx->mf_cb_built) {
         HIPCHK(ctx, ctx->mf_cw16.ensure((size_t)kM * kK * 16));
         HIPCHK(ctx, ctx->mf_cwn.ensure((size_t)kM * kK * 4));
@@ -780,9 +793,16 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
                                 ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_blocks, ctx->mf_rec.p, s));
     if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
-    HIPCHK(ctx, launch_tex_refine(d, g, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
+    return refine_now ? adc_refine_mfma(ctx, grp, all_rows, compact) : AFIS_OK;
+}
+
+static int adc_refine_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, bool compact)
+{
+    if (grp.n_lt_rows <= 0 || ctx->gal.G <= 0) return AFIS_OK;
+    const int R_pad = (grp.n_lt_rows + 31) / 32 * 32;
+    HIPCHK(ctx, launch_tex_refine(grp.dev, ctx->gal, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
                                   ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr,
-                                  compact ? ctx->rm_cv.as<float>() : nullptr, compact ? ctx->rm_n.as<int32_t>() : nullptr, s));
+                                  compact ? ctx->rm_cv.as<float>() : nullptr, compact ? ctx->rm_n.as<int32_t>() : nullptr, ctx->stream));
     return AFIS_OK;
 }
 
@@ -805,14 +825,14 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     // The groups run back to back on the stream: no host round trip between them.  Scores of ALL queries stay on the device
     // ([n_q][G]) for the rank-list kernel; they cross PCIe only when the caller asks for them.
     const size_t n_groups = q->groups.size();
-    while (ctx->evpool.size() < n_groups * 8 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
+    while (ctx->evpool.size() < n_groups * 10 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
     if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
     int q0 = 0;
     size_t gi = 0;
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
-        hipEvent_t* ev = &ctx->evpool[gi * 8];
+        hipEvent_t* ev = &ctx->evpool[gi * 10];
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
@@ -840,6 +860,47 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const long long n_chunks_auto = ((G + 639) / 640 + cmul - 1) / cmul * cmul;
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
+            // (a launch of fewer than 2^16 pairs — a single latent against 10k templates — is tail-bound, not power-bound: the side streams only add their hand-overs: 4.40 vs 4.54 ms)
+            const bool overlap = ctx->adc_variant == 9 && ctx->stream_lo != nullptr && n_pairs >= 65536;
+            const bool compact9 = ctx->adc_variant == 9;                  // the recomputation kernel's compact list of the rows that matter (S7 reads a third of the rows)
+            auto minutiae_stage = [&]() -> int {
+                HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
+                HIPCHK(ctx, hipEventRecord(ev[7], s));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
+                return AFIS_OK;
+            };
+            if (overlap) {
+                // The bound pass is power-limited: half of the chip's CUs deliver 0.64 of the whole chip's matrix throughput (profiles/r04_cu_mask_probe.json).  It runs on a
+                // stream confined to the low `bound_cus` CUs; the minutiae stage — candidates, then lists: independent of the texture path — runs beside it on a stream
+                // confined to the OTHER CUs (an unconfined stream's persistent workgroups would take every CU and the bound pass, whose workgroup needs a whole CU's LDS,
+                // would wait for them to leave).  When the bound pass is done the context's stream joins the list kernel (a second instance drawing from the same counter),
+                // then runs recomputation and texture lists on the whole chip.
+                hipStream_t sl = ctx->stream_lo, sh = ctx->stream_hi;
+                HIPCHK(ctx, hipStreamWaitEvent(sl, ev[0], 0));                             // everything of the previous group (this stream's order) is done
+                HIPCHK(ctx, hipStreamWaitEvent(sh, ev[0], 0));
+                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true, sl, false);
+                if (rc9 != AFIS_OK) return rc9;
+                HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), sh));
+                HIPCHK(ctx, hipMemsetAsync(g.task_ctr + 1, 0, 4, sh));                     // the list counter both instances of the list kernel draw from: reset BEFORE either may start
+                HIPCHK(ctx, hipEventRecord(ev[7], sh));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, sh, true));
+                HIPCHK(ctx, hipEventRecord(ev[4], sh));
+                HIPCHK(ctx, hipStreamWaitEvent(s, ev[6], 0));
+                HIPCHK(ctx, hipEventRecord(ev[8], s));                                     // the bound pass is done
+                rc9 = adc_refine_mfma(ctx, grp, false, true);
+                if (rc9 != AFIS_OK) return rc9;
+                HIPCHK(ctx, hipEventRecord(ev[2], s));
+                HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
+                HIPCHK(ctx, hipEventRecord(ev[3], s));
+                HIPCHK(ctx, hipStreamWaitEvent(s, ev[7], 0));                              // every candidate list exists: help with whatever lists are left
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s, true));
+                HIPCHK(ctx, hipStreamWaitEvent(s, ev[4], 0));
+                // The host waits for the two side streams here (the context's stream has its whole share of the group queued and keeps the chip busy meanwhile).  Without
+                // it the run hangs: waiting on the context's stream alone — or on an event of a side stream — never returns although every stream drains at once when it
+                // is synchronised itself (observed with ROCm 7.2; hipStreamQuery does not help).
+                HIPCHK(ctx, hipStreamSynchronize(sl));
+                HIPCHK(ctx, hipStreamSynchronize(sh));
+            } else {
             if (ctx->adc_variant == 9) {                                    // fp16 matrix-core bound pass + exact recomputation
                 int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true);
                 if (rc9 != AFIS_OK) return rc9;
@@ -853,14 +914,13 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, launch_adc_rowmax(d, g, ctx->lut.as<float>(), chunk, ctx->adc_variant, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             }
             HIPCHK(ctx, hipEventRecord(ev[2], s));
-            const bool compact9 = ctx->adc_variant == 9;                  // the recomputation kernel's compact list of the rows that matter (S7 reads a third of the rows)
             HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), compact9 ? ctx->rm_cv.as<float>() : nullptr,
                                              compact9 ? ctx->rm_n.as<int32_t>() : nullptr, ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
-            HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
-            HIPCHK(ctx, hipEventRecord(ev[7], s));
-            HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
+            { int rcm = minutiae_stage(); if (rcm != AFIS_OK) return rcm; }
             HIPCHK(ctx, hipEventRecord(ev[4], s));
+            }
+            HIPCHK(ctx, hipEventRecord(ev[9], s));
             HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), grp_scores, s));
             HIPCHK(ctx, hipEventRecord(ev[5], s));
             // per-part scores only on request (tests, the all-templates mode); stream order keeps the buffer intact until the copy is done
@@ -877,7 +937,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     }
     // ---- rank lists (matcher.cpp:306-309; ties by ascending index) ----
     const bool dev_topk = k > 0 && k <= kDeviceTopK && G > 0 && nq_all > 0;
-    hipEvent_t* evk = &ctx->evpool[n_groups * 8];
+    hipEvent_t* evk = &ctx->evpool[n_groups * 10];
     if (dev_topk) {
         HIPCHK(ctx, ctx->topk_idx.ensure((size_t)nq_all * k * 8));
         HIPCHK(ctx, ctx->topk_score.ensure((size_t)nq_all * k * 4));
@@ -896,17 +956,22 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (G > 0) {
         for (size_t i = 0; i < n_groups; ++i) {
-            hipEvent_t* ev = &ctx->evpool[i * 8];
-            float ms[5] = {0, 0, 0, 0, 0}, tot = 0;
-            for (int j = 0; j < 5; ++j) HIPCHK(ctx, hipEventElapsedTime(&ms[j], ev[j], ev[j + 1]));
-            HIPCHK(ctx, hipEventElapsedTime(&tot, ev[0], ev[5]));
-            if (ctx->adc_variant == 9 && q->groups[i].n_lt_rows > 0) {
-                float tb_ = 0, tr_ = 0;
-                HIPCHK(ctx, hipEventElapsedTime(&tb_, ev[1], ev[6])); HIPCHK(ctx, hipEventElapsedTime(&tr_, ev[6], ev[2]));
-                tm.adc_bound_ms += tb_; tm.adc_refine_ms += tr_;
-            } else tm.adc_bound_ms += ms[1];
-            { float tc_ = 0, tg_ = 0; HIPCHK(ctx, hipEventElapsedTime(&tc_, ev[3], ev[7])); HIPCHK(ctx, hipEventElapsedTime(&tg_, ev[7], ev[4])); tm.cands_ms += tc_; tm.minu_graph_ms += tg_; }
-            tm.lut_ms += ms[0]; tm.adc_ms += ms[1]; tm.tex_tail_ms += ms[2]; tm.minu_ms += ms[3]; tm.fuse_ms += ms[4]; tm.total_ms += tot;
+            hipEvent_t* ev = &ctx->evpool[i * 10];
+            float tot = 0;
+            auto el = [&](int a, int b, float& out) -> int { out = 0; HIPCHK(ctx, hipEventElapsedTime(&out, ev[a], ev[b])); return AFIS_OK; };
+            const bool ov = ctx->adc_variant == 9 && ctx->stream_lo != nullptr && (size_t)q->groups[i].nq * (size_t)G >= 65536;
+            float t_lut = 0, t_adc = 0, t_tex = 0, t_minu = 0, t_fuse = 0, t_bound = 0, t_ref = 0, t_c = 0, t_g = 0;
+            if (el(0, 5, tot)) return AFIS_EDEVICE;
+            if (ov) {                                                          // overlapped form: the bound pass's time is its own stream's, the minutiae stage ran beside it; the stage times overlap (their sum exceeds total_ms)
+                if (el(0, 1, t_lut) || el(1, 6, t_bound) || el(8, 2, t_ref) || el(2, 3, t_tex) || el(0, 7, t_c) || el(7, 4, t_g) || el(9, 5, t_fuse)) return AFIS_EDEVICE;
+                t_adc = t_bound + t_ref; t_minu = t_c + t_g;
+            } else {
+                if (el(0, 1, t_lut) || el(1, 2, t_adc) || el(2, 3, t_tex) || el(3, 4, t_minu) || el(9, 5, t_fuse) || el(3, 7, t_c) || el(7, 4, t_g)) return AFIS_EDEVICE;
+                if (ctx->adc_variant == 9 && q->groups[i].n_lt_rows > 0) { if (el(1, 6, t_bound) || el(6, 2, t_ref)) return AFIS_EDEVICE; }
+                else t_bound = t_adc;
+            }
+            tm.adc_bound_ms += t_bound; tm.adc_refine_ms += t_ref; tm.cands_ms += t_c; tm.minu_graph_ms += t_g;
+            tm.lut_ms += t_lut; tm.adc_ms += t_adc; tm.tex_tail_ms += t_tex; tm.minu_ms += t_minu; tm.fuse_ms += t_fuse; tm.total_ms += tot;
         }
         if (dev_topk) { float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, evk[0], evk[1])); tm.topk_ms = t; tm.total_ms += t; }
     }
@@ -1083,6 +1148,24 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size)
     return AFIS_OK;
 }
 
+int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
+{
+    if (!ctx || !name || !value) return AFIS_EINVAL;
+    const std::string n(name);
+    if (n == "adc_variant") *value = ctx->adc_variant;
+    else if (n == "bound_cus") *value = ctx->stream_lo ? ctx->bound_cus : 0;
+    else if (n == "mf_blocks") *value = ctx->mf_blocks;
+    else if (n == "query_batch") *value = ctx->query_batch;
+    else if (n == "chunk") *value = ctx->chunk;
+    else if (n == "tile_share") *value = ctx->tile_share;
+    else if (n == "minu_generic") *value = ctx->minu_generic;
+    else if (n == "mf_stats") *value = ctx->mf_collect_stats;
+    else if (n == "rowmax_budget_mb") *value = ctx->rowmax_budget_bytes >> 20;
+    else if (n == "lut_dtype") *value = 32;
+    else return AFIS_EINVAL;
+    return AFIS_OK;
+}
+
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
 {
     if (!ctx || !name) return AFIS_EINVAL;
@@ -1094,6 +1177,23 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
+    else if (n == "bound_cus") {                                           // 0 = off; 32..224 in steps of 32: the bound pass on a stream confined to that many CUs (value / 8 of every XCD), the minutiae stage beside it on the others
+        if (value < 0 || value > 224 || (value & 31)) return fail(ctx, AFIS_EINVAL, "bound_cus must be 0 (off), 32, 64, ... 224 (the runtime honours CU masks in steps of 32 CUs: 4 per XCD)");
+        if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AFIS_EDEVICE, "bound_cus: hipSetDevice failed");
+        for (hipStream_t* ps : {&ctx->stream_lo, &ctx->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
+        ctx->bound_cus = (int)value;
+        if (value > 0) {
+            uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the runtime deals the mask's bits round-robin over the XCDs: the low N bits are N / 8 CUs of each
+            for (int b = 0; b < 256; ++b) (b < (int)value ? lo : hi)[b >> 5] |= 1u << (b & 31);
+            hipError_t e = hipExtStreamCreateWithCUMask(&ctx->stream_lo, 8, lo);
+            if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->stream_hi, 8, hi);
+            if (e != hipSuccess) {
+                for (hipStream_t* ps : {&ctx->stream_lo, &ctx->stream_hi}) if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
+                ctx->bound_cus = 0;
+                return fail(ctx, AFIS_EDEVICE, std::string("bound_cus: hipExtStreamCreateWithCUMask: ") + hipGetErrorString(e));
+            }
+        }
+    }
     else if (n == "mf_blocks") { if (value != 2 && value != 3 && value != 102) return fail(ctx, AFIS_EINVAL, "mf_blocks must be 2, 3 or 102 (the software-pipelined bound pass)"); ctx->mf_blocks = (int)value; }
     else if (n == "rowmax_budget_mb") { if (value < 1) return fail(ctx, AFIS_EINVAL, "rowmax_budget_mb must be positive"); ctx->rowmax_budget_bytes = value << 20; }
     else return fail(ctx, AFIS_EINVAL, "unknown option: " + n);

@@ -36,7 +36,7 @@ struct GalleryDev {
                                             // lane class and half-period shifted for the conflict-free ADC kernel (adc.hip)
     const int32_t* tex_cf_blk = nullptr;    // [G+1] offset of each template's stream in tex_codes_cf, in 64-entry blocks
     const uint8_t* empty = nullptr;      // [G] 1 = rolled template has neither minutiae nor texture (score -1)
-    int32_t* task_ctr = nullptr;         // [3] next-task counters of the graph kernels (texture, minutiae) and the refine kernel: zeroed by their launchers
+    int32_t* task_ctr = nullptr;         // [4] next-task counters of the graph kernels (texture, minutiae), the refine kernel and the candidate kernel: zeroed by their launchers
 };
 
 // A group of latents resident on the device (selected minutiae templates 26, 2, 11 + texture template 0).
@@ -136,7 +136,7 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
                              int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback, hipStream_t stream);
 // S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
-                                 float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
+                                 float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream, bool join = false);
 // S10: fusion -> scores[q*G+g]
 hipError_t launch_fuse(const QueryDev& q, const GalleryDev& g, const float* parts, float* scores, hipStream_t stream);
 

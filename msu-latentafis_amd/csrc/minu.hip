@@ -327,7 +327,7 @@ __device__ __forceinline__ uint32_t approx_norm_key(float sv, float rs, float cs
 #endif
 __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, GalleryDev g, const float4* __restrict__ lat_frag,
                                                                 const float4* __restrict__ rol_frag,  // descriptors as operand fragments
-                                                                MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb)
+                                                                MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb, int32_t* __restrict__ next_rolled)
 {
     __shared__ RtSmem sm;
     PHASE_DECL();
@@ -337,7 +337,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
     const int li = lane & 15, lg = lane >> 4;
     const int nqs = q.nq * 3;
     auto to_fallback = [&](long long task) { const int p = atomicAdd(&fb[0], 1); fb[1 + p] = (int32_t)task; };
-    for (int gi = blockIdx.x; gi < g.G; gi += gridDim.x) {
+    // Rolled templates are DRAWN from a counter, not dealt by stride: the kernel may start on the part of the chip the (CU-masked) bound pass leaves free and spread
+    // over the rest when that finishes (afis_api.cpp, option bound_cus): workgroups that start late must not find a fixed share of the work waiting for them.
+    __shared__ int s_ticket;
+    for (;;) {
+        if (tid == 0) s_ticket = atomicAdd(next_rolled, 1);
+        __syncthreads();
+        const int gi = s_ticket;
+        __syncthreads();                                                            // everyone has read the ticket before thread 0 draws the next one
+        if (gi >= g.G) break;
         const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
         if (nR <= 0 || nR > kFastR) {                                               // no rolled minutiae (matcher.cpp:400-404) / too many for this kernel
             for (int qs = tid; qs < nqs; qs += kThreads) {
@@ -598,8 +606,11 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
     if (!force_generic) {
         e = hipMemsetAsync(fallback, 0, sizeof(int32_t), stream);
         if (e != hipSuccess) return e;
-        const int grid = g.G < 1024 ? g.G : 1024;                                 // 4 workgroups per CU, persistent over rolled templates
-        hipLaunchKernelGGL(k_minu_cands_rt, dim3(grid), dim3(kThreads), 0, stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback);
+        if (!g.task_ctr) return hipErrorInvalidValue;
+        e = hipMemsetAsync(g.task_ctr + 3, 0, sizeof(int32_t), stream);
+        if (e != hipSuccess) return e;
+        const int grid = g.G < 1024 ? g.G : 1024;                                 // 4 workgroups per CU, persistent: rolled templates are drawn from g.task_ctr[3]
+        hipLaunchKernelGGL(k_minu_cands_rt, dim3(grid), dim3(kThreads), 0, stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, g.task_ctr + 3);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

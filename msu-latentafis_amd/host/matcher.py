@@ -47,7 +47,7 @@ class Timing(C.Structure):
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
-           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option"]
+           "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option", "afis_get_option"]
 # include/afis_matcher_taps.h: exported by libafis_hip_test.so only
 TAP_EXPORTS = ["afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles", "afis_debug_atan2_grid", "afis_debug_graph_arith", "afis_debug_refine_stats"]
 
@@ -86,6 +86,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     if hasattr(lib, "afis_get_timing2"):                                # absent from older builds compared by tools/lib_ab.py
         lib.afis_get_timing2.argtypes = [vp, C.POINTER(Timing), C.c_size_t]
     lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    if hasattr(lib, "afis_get_option"):
+        lib.afis_get_option.argtypes = [vp, C.c_char_p, i64p]
     if hasattr(lib, "afis_debug_stage_list"):                           # the parity taps: libafis_hip_test.so (and older builds) only
         lib.afis_debug_stage_list.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, fp, i32p, i32p, i32p]
         lib.afis_debug_lut.argtypes = [vp, C.POINTER(TemplateView), fp, i32p]
@@ -234,6 +236,13 @@ class Matcher:
 
     def set_option(self, name: str, value: int):
         self._chk(self.lib.afis_set_option(self.ctx, name.encode(), value))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        if not hasattr(self.lib, "afis_get_option"):
+            return 0
+        self._chk(self.lib.afis_get_option(self.ctx, name.encode(), C.byref(v)))
+        return int(v.value)
 
     # ---- search -----------------------------------------------------------------------------------------------
     def _alloc(self, nq, k, want_scores, want_parts):
