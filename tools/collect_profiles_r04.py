@@ -12,6 +12,9 @@ bench = last(f"{src}/bench.json"); prof = last(f"{src}/bench_profiled.json")
 shutil.copy(f"{src}/bench.json", f"profiles/{pre}_bench_100x100k.json")
 open(f"profiles/{pre}_bench_100x100k_under_rocprof.json", "w").write(json.dumps(prof) + "\n")
 shutil.copy(f"{src}/kernel_stats.csv", f"profiles/{pre}_kernel_stats.csv")
+shutil.copy(f"{src}/kernel_stats_back_to_back.csv", f"profiles/{pre}_kernel_stats_back_to_back.csv")
+b2b = last(f"{src}/bench_back_to_back.json")
+open(f"profiles/{pre}_bench_100x100k_back_to_back.json", "w").write(json.dumps(b2b) + "\n")
 shutil.copy(f"{src}/pmc_sq_summary.txt", f"profiles/{pre}_pmc_sq_summary.txt")
 shutil.copy(f"{src}/pmc_hbm_summary.txt", f"profiles/{pre}_pmc_hbm_summary.txt")
 rstats = last(f"{src}/bench_refine_stats.json")
@@ -49,7 +52,8 @@ def resources(key):
     for k, v in res.items():
         if tagk in k: return v
     return {"vgpr": -1, "scratch": -1, "occupancy": -1, "lds": -1}
-ks = {r["kernel"].split("(")[0].replace("void ", ""): r for r in csv.DictReader(open(f"{src}/kernel_stats.csv"))}
+ks = {r["kernel"].split("(")[0].replace("void ", ""): r for r in csv.DictReader(open(f"{src}/kernel_stats_back_to_back.csv"))}     # the counter passes' schedule: kernels alone
+ks_def = {r["kernel"].split("(")[0].replace("void ", ""): r for r in csv.DictReader(open(f"{src}/kernel_stats.csv"))}                # the default schedule: bound pass on half the CUs, minutiae stage beside it
 KERNELS = [("k_adc_mfma", "S5-S6 bound pass (fp16 matrix cores)"), ("k_tex_refine", "S5-S7 selection by bounds + exact recomputation"), ("k_graph_texture", "S7-S9 texture lists"),
            ("k_minu_cands_rt", "S1-S3 minutiae candidates"), ("k_graph_minutiae", "S8a + S9 minutiae lists")]
 launches = bench["stage_ms_per_step"] and int(round(bench["launch_groups_per_step"]))
@@ -67,7 +71,8 @@ for key, what in KERNELS:
     ms = float(k["avg_ms"])
     n_valu = sq["SQ_INSTS_VALU"] - sq.get("SQ_INSTS_MFMA", 0.0)
     rr_ = resources(key)
-    units[key] = {"what": what, "avg_launch_ms": round(ms, 2), "calls": int(k["calls"]), "vgpr": rr_["vgpr"], "scratch": rr_["scratch"], "lds_bytes": rr_["lds"], "waves_per_simd_by_registers": rr_["occupancy"],
+    n_groups_def = int(pick(ks_def, "k_adc_mfma")["calls"])               # the list kernel runs twice per group in the default schedule (helper + joining instance): total time per group, not per call
+    units[key] = {"what": what, "avg_launch_ms": round(ms, 2), "avg_launch_ms_default_schedule": round(float(pick(ks_def, key)["total_ms"]) / n_groups_def, 2), "calls": int(k["calls"]), "vgpr": rr_["vgpr"], "scratch": rr_["scratch"], "lds_bytes": rr_["lds"], "waves_per_simd_by_registers": rr_["occupancy"],
                   "clock_ghz": round(xcd / (ms * 1e-3) / 1e9, 3), "mfma_pipe_busy": round(sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd, 4),
                   "valu_instructions_per_launch": n_valu, "valu_instructions_per_simd_cycle": round(n_valu / simd, 4),
                   "lds_array_busy": round(sq["SQ_LDS_IDX_ACTIVE"] / cu, 4), "lds_bank_conflict_share_of_lds_cycles": round(sq["SQ_LDS_BANK_CONFLICT"] / max(1.0, sq["SQ_LDS_IDX_ACTIVE"]), 4),
@@ -78,8 +83,11 @@ xcd = sq["GRBM_GUI_ACTIVE"] / 8
 fetch_b = 2 * b["fetch_KB_raw"] * 1024; write_b = b["write_KB_raw"] * 1024
 r_fetch_lo = r["fetch_KB_raw"] * 1024; r_fetch_hi = 2 * r_fetch_lo; r_write = r["write_KB_raw"] * 1024
 alg_bytes = bench["roofline"]["hbm_view"]["alg_bytes_per_launch"]
+bound_cus = bench["config"].get("bound_cus", 0)
 out = {
     "round": "round 4", "kernel": "afis::k_adc_mfma<2> (adc_variant 9, default)",
+    "schedule_of_these_counters": "one stream, the kernels of a launch group back to back (bench.py --bound-cus 0): every kernel is characterised ALONE; in the default schedule the bound pass runs on "
+                                  f"{bound_cus} of the 256 CUs with the minutiae stage beside it (kernels[...].avg_launch_ms_default_schedule)",
     "workload": f"bench.py default: 100 latents x 100k gallery, launch groups cut by latent texture rows ({launches} launches per step, {q_per_launch:.1f} latents per launch on average)",
     "avg_launch_ms_rocprof_stats": b["avg_launch_ms"], "launches_profiled": b["calls"], "sq_counters_per_launch": sq,
     "FETCH_SIZE_KB_per_launch_raw": b["fetch_KB_raw"], "WRITE_SIZE_KB_per_launch_raw": b["write_KB_raw"],
@@ -126,19 +134,25 @@ L.append(f"Workload: bench.py default = {bench['config']['queries']} latents x {
          f"({bench['config']['mean_latent_tex_rows']:.0f} latent texture rows, {bench['config']['mean_rolled_tex_points']:.0f} rolled texture points, {bench['config']['mean_rolled_minutiae']:.0f} rolled minutiae per template).\n")
 L.append("## Step\n")
 L.append("| quantity | value |\n|---|---|")
-L.append(f"| queries/s | {bench['value']:.2f} |\n| ms per step (100 latents) | {bench['ms_per_step']:.1f} |\n| latency per latent (ms per step / 100) | {bench['ms_per_step'] / 100:.2f} |")
-for k_, lab in (("adc_bound_ms", "bound pass"), ("adc_refine_ms", "selection + recomputation"), ("tex_tail_ms", "texture lists (S7-S9)"), ("cands_ms", "minutiae candidates (S1-S3)"),
-                ("minu_graph_ms", "minutiae lists (S8a, S9)"), ("lut_ms", "row constants"), ("fuse_ms", "fusion"), ("topk_ms", "rank lists")):
-    L.append(f"| {lab}: ms per step / share | {st[k_]:.1f} / {100 * st[k_] / st['total_ms']:.1f} % |")
-L.append(f"| roofline.frac (bound pass, algorithmic flops / 2.5 PFLOP/s) | {bench['roofline']['frac']:.3f} at {bench['roofline']['avg_launch_ms']:.1f} ms per launch |")
-L.append(f"| hbm_view.frac (bound + recomputation, 24 algorithmic B per rolled point per query / 8 TB/s) | {bench['roofline']['hbm_view']['frac']:.4f} |")
+L.append(f"| queries/s (default schedule: bound pass on {bound_cus} CUs, minutiae stage beside it) | **{bench['value']:.2f}** |\n| ms per step (100 latents) | {bench['ms_per_step']:.1f} |\n| latency per latent (ms per step / 100) | {bench['ms_per_step'] / 100:.2f} |")
+L.append(f"| queries/s, one stream / kernels back to back (`--bound-cus 0`, same box) | {b2b['value']:.2f} ({b2b['ms_per_step']:.1f} ms per step) |")
+L.append("| stage times below: default schedule — they OVERLAP (the bound pass's is its own stream's, the minutiae stage's is what it took beside it): their sum exceeds the step | |")
+for k_, lab in (("adc_bound_ms", "bound pass (on its CUs)"), ("adc_refine_ms", "selection + recomputation"), ("tex_tail_ms", "texture lists (S7-S9)"), ("cands_ms", "minutiae candidates (S1-S3), beside the bound pass"),
+                ("minu_graph_ms", "minutiae lists (S8a, S9), beside the bound pass and after it"), ("lut_ms", "row constants"), ("fuse_ms", "fusion"), ("topk_ms", "rank lists")):
+    L.append(f"| {lab}: ms per step, default schedule | {st[k_]:.1f} |")
+sb = b2b["stage_ms_per_step"]
+for k_, lab in (("adc_bound_ms", "bound pass"), ("adc_refine_ms", "selection + recomputation"), ("tex_tail_ms", "texture lists"), ("cands_ms", "minutiae candidates"), ("minu_graph_ms", "minutiae lists")):
+    L.append(f"| {lab}: ms per step / share, kernels back to back | {sb[k_]:.1f} / {100 * sb[k_] / sb['total_ms']:.1f} % |")
+L.append(f"| roofline (bound pass, default schedule): algorithmic flops / peak of the {bench['roofline'].get('cus_used', 256)} CUs it runs on | {bench['roofline']['frac']:.3f} ({bench['roofline']['achieved']:.0f} of {bench['roofline']['peak']:.0f} TFLOP/s) at {bench['roofline']['avg_launch_ms']:.1f} ms per launch; {bench['roofline'].get('frac_of_chip_peak', bench['roofline']['frac']):.3f} of the whole chip's 2 500 |")
+L.append(f"| roofline (bound pass alone on the whole chip, `--bound-cus 0`) | {b2b['roofline']['frac']:.3f} ({b2b['roofline']['achieved']:.0f} TFLOP/s) at {b2b['roofline']['avg_launch_ms']:.1f} ms per launch |")
+L.append(f"| hbm_view.frac (bound + recomputation, 24 algorithmic B per rolled point per query / 8 TB/s), kernels back to back | {b2b['roofline']['hbm_view']['frac']:.4f} ({bench['roofline']['hbm_view']['frac']:.4f} in the default schedule, where the bound pass has half the chip) |")
 L.append(f"| CPU baseline (oracle, {bench['cpu_baseline']['threads']} threads, {bench['cpu_baseline']['sample']}) | {bench['cpu_baseline']['pairs_per_s']:.0f} pairs/s = {bench['cpu_baseline']['value']:.4f} queries/s |")
 L.append(f"| reference-faithful CPU loop (8 threads, static 16, re-parse per pair) | {bench['cpu_baseline']['reference_faithful_8_threads_static16_reparse_per_pair_queries_per_s']:.4f} queries/s |\n")
-L.append(f"## Kernels (rocprofv3 --kernel-trace --stats and --pmc passes of the same command; per launch group of {q_per_launch:.1f} latents)\n")
-L.append("| kernel | avg launch ms | clock GHz | VGPR / scratch B / LDS B | MFMA pipe busy | vector issue (wave64 instructions x 4 cycles / SIMD-cycles) | LDS busy (conflict share) | wave-cycles waiting |\n|---|---|---|---|---|---|---|---|")
+L.append(f"## Kernels (rocprofv3 --kernel-trace --stats and --pmc passes of `bench.py --bound-cus 0`: every kernel alone on the chip; per launch group of {q_per_launch:.1f} latents)\n")
+L.append("| kernel | avg launch ms alone (in the default schedule) | clock GHz | VGPR / scratch B / LDS B | MFMA pipe busy | vector issue (wave64 instructions x 4 cycles / SIMD-cycles) | LDS busy (conflict share) | wave-cycles waiting |\n|---|---|---|---|---|---|---|---|")
 for key, what in KERNELS:
     u = units[key]
-    L.append(f"| `{key}` ({what}) | {u['avg_launch_ms']:.1f} | {u['clock_ghz']:.2f} | {u['vgpr']} / {u['scratch']} / {u['lds_bytes']} | {u['mfma_pipe_busy']:.2f} | {4 * u['valu_instructions_per_simd_cycle']:.2f} | "
+    L.append(f"| `{key}` ({what}) | {u['avg_launch_ms']:.1f} ({u['avg_launch_ms_default_schedule']:.1f}) | {u['clock_ghz']:.2f} | {u['vgpr']} / {u['scratch']} / {u['lds_bytes']} | {u['mfma_pipe_busy']:.2f} | {4 * u['valu_instructions_per_simd_cycle']:.2f} | "
              f"{u['lds_array_busy']:.2f} ({u['lds_bank_conflict_share_of_lds_cycles']:.2f}) | {u['wave_cycles_waiting']:.2f} |")
 s_ = out["stage_traffic"]
 L.append(f"\n## HBM-side traffic of the ADC stage per launch (PMC passes; bound pass FETCH_SIZE x 2)\n")
