@@ -1043,6 +1043,35 @@ def test_bound_pass_magnitude_sweep_up_to_the_forcing_threshold(codebook_bytes, 
     m.close()
 
 
+def test_results_do_not_depend_on_the_schedule(codebook_bytes, cb, medium):
+    """The default schedule runs the bound pass on a stream confined to 128 CUs with the minutiae stage beside it on the other 128 (option bound_cus; launches of at least 2^16
+    pairs: 24 latents x 3000 templates here).  bound_cus 0 (one stream, kernels back to back), 64, 128 (default) and 192 give the same bits in scores, per-part scores and rank lists;
+    the option reads back; values off the 32-CU grid are refused; back to back afis_timing's total is the sum of its stages."""
+    lats, gal, planted = medium
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add_packed(gal); m.gallery_commit(0)
+    many = list(lats) * 4
+    assert len(many) * gal.G >= 65536
+    assert m.get_option("bound_cus") == 128 and m.get_option("adc_variant") == 9
+    want = None
+    for bc in (0, 64, 128, 192):
+        m.set_option("bound_cus", bc)
+        assert m.get_option("bound_cus") == bc
+        got = m.search(many, k=24, want_parts=True)
+        tm = m.timing()
+        assert tm["total_ms"] > 0 and tm["adc_bound_ms"] > 0 and tm["cands_ms"] > 0 and tm["minu_graph_ms"] > 0
+        if bc == 0:
+            assert abs(tm["total_ms"] - (tm["lut_ms"] + tm["adc_ms"] + tm["tex_tail_ms"] + tm["minu_ms"] + tm["fuse_ms"] + tm["topk_ms"])) < 0.05 * tm["total_ms"]
+        if want is None: want = got
+        for key in ("scores", "parts", "topk_idx", "topk_score"):
+            assert np.array_equal(np.asarray(got[key]).view(np.uint8), np.asarray(want[key]).view(np.uint8)), (bc, key)
+    for bad in (8, 100, 256, -32):
+        with pytest.raises(M.AfisError):
+            m.set_option("bound_cus", bad)
+    assert m.get_option("bound_cus") == 192
+    m.close()
+
+
 def test_bound_pass_kernel_forms_are_bit_identical(codebook_bytes, cb, oracle, small):
     """The matrix-core bound pass exists in three forms — two row blocks per wave (default), three (mf_blocks 3: a third less LDS operand traffic per MFMA) and the
     two-stage software pipeline (mf_blocks 102) — which differ only in when a wave does what.  Row maxima / first arg-maxima of each against the oracle, and the
