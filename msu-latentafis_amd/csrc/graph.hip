@@ -607,6 +607,13 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
     static_assert(kValN * NMAX * 4 + kIdxN * NMAX <= (int)sizeof(sm.x.stash), "index lists + value stash exceed the stash space");
     float* const vst = sm.x.stash;
     unsigned char* const idx8 = reinterpret_cast<unsigned char*>(sm.x.stash + kValN * NMAX);
+#ifndef AFIS_MINU_REGN
+#define AFIS_MINU_REGN 0
+#endif
+    // minutiae lists only: the values of a row's first kRegN neighbours stay in REGISTERS from iteration 0 on (statically indexed: the first kRegN steps of every loop are unrolled)
+    constexpr int kRegN = kFlat ? 0 : AFIS_MINU_REGN;
+    static_assert(kRegN <= kIdxN, "cached values need their neighbour indices");
+    float hreg[U][kRegN > 0 ? kRegN : 1];
     int cur_w[U]; uint32_t cur_bits[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) { cur_w[u] = 0; cur_bits[u] = 0u; }
@@ -626,7 +633,21 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
                 if (t >= 0) {                                                // lanes beyond the list sit the pass out: ONE divergent region, not one per step
                     int w = 0;
                     uint32_t bits = hrow[0];
-                    for (int n = 0; n < trip[u]; ++n) {                      // uniform
+#pragma unroll
+                    for (int r = 0; r < kRegN; ++r) {                        // the first kRegN steps, unrolled: their values go to registers
+                        if (r < trip[u]) {                                   // uniform
+                            while (bits == 0u && w + 1 < Wn) { ++w; bits = hrow[w]; }
+                            const bool have = bits != 0u;
+                            const int k = (w * 32 + __ffs(bits) - 1) & 255;
+                            bits &= bits - 1;
+                            const float h = value(mine[u], k);
+                            idx8[r * NMAX + t] = (unsigned char)k;
+                            hreg[u][r] = h;
+                            const float p = h * sm.b[k];
+                            acc += have ? p : 0.0f;
+                        }
+                    }
+                    for (int n = kRegN; n < trip[u]; ++n) {                  // uniform
                         if (n == kIdxN) { cur_w[u] = w; cur_bits[u] = bits; }    // uniform condition
                         while (bits == 0u && w + 1 < Wn) { ++w; bits = hrow[w]; }   // next non-empty word of this lane's row
                         const bool have = bits != 0u;                        // an ended row notes a stale index (never read: n >= its length) and adds +0.0f
@@ -649,7 +670,15 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
                     const float p = vst[n * NMAX + tt] * sm.b[k];
                     acc += n < rlen[u] ? p : 0.0f;
                 }
-                for (int n = nV; n < nA; ++n) {
+#pragma unroll
+                for (int r = 0; r < kRegN; ++r) {
+                    if (r < nA) {                                            // uniform
+                        const int k = idx8[r * NMAX + tt];
+                        const float p = hreg[u][r] * sm.b[k];
+                        acc += r < rlen[u] ? p : 0.0f;
+                    }
+                }
+                for (int n = max(nV, kRegN); n < nA; ++n) {
                     const int k = idx8[n * NMAX + tt];
                     const float p = value(mine[u], k) * sm.b[k];
                     acc += n < rlen[u] ? p : 0.0f;
