@@ -313,6 +313,20 @@ def main():
     # ---- rank-list sanity: the planted true mate must be rank 1 ------------------------------------------------------
     hits = sum(1 for q in range(Q) if int(idx[q, 0]) == planted[q][0][0])
 
+    # ---- outside the timed region: the same step with the kernels back to back on one stream, so that the line also carries the bound pass's duration when it
+    # has the whole chip (the roofline of the kernel by itself) and the per-stage times without overlap.  Two steps after one warm-up step; rank lists must not change.
+    alone = None
+    if bound_cus > 0 and world == 1:
+        m.set_option("bound_cus", 0)
+        m.search_resident(qh, k=a.k)
+        acc = None
+        for _ in range(2):
+            r_ = m.search_resident(qh, k=a.k); t_ = m.timing()
+            acc = t_ if acc is None else {k_: acc[k_] + v for k_, v in t_.items()}
+        assert np.array_equal(r_["topk_idx"], np.asarray(idx)) or use_dist, "the schedule changed a rank list"
+        alone = {k_: (v / 2 if k_.endswith("_ms") else v) for k_, v in acc.items()}
+        m.set_option("bound_cus", bound_cus)
+
     out = None
     if rank == 0 and a.dump_ranks:
         np.savez(a.dump_ranks, idx=np.asarray(idx), score=np.asarray(sc))
@@ -342,6 +356,10 @@ def main():
             roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": round(MFMA_F16_PEAK_TFLOPS * share, 1),
                         "unit": "TFLOP/s", "frac": round(tflops / (MFMA_F16_PEAK_TFLOPS * share), 5),
                         "cus_used": bound_cus if bound_cus > 0 else 256, "chip_peak": MFMA_F16_PEAK_TFLOPS, "frac_of_chip_peak": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
+                        "alone_on_the_chip": ({"what": "the same kernel in the same process with the kernels back to back on one stream (bound_cus 0), two steps outside the timed region: its roofline when it has all 256 CUs",
+                                               "avg_launch_ms": round(alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2), 3),
+                                               "achieved": round(alg_flops_launch / (alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2) * 1e-3) / 1e12, 2), "peak": MFMA_F16_PEAK_TFLOPS,
+                                               "frac": round(alg_flops_launch / (alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2) * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 5)} if alone else None),
                         "peak_is": ("the fp16 matrix peak of the CUs the kernel runs on: it is confined to %d of the 256 CUs (hipExtStreamCreateWithCUMask) and the minutiae stage runs beside it on the others; "
                                     "frac_of_chip_peak prices the same duration against the whole chip (with --bound-cus 0 the kernel has the chip to itself: frac 0.47)" % bound_cus) if bound_cus > 0 else
                                    "the chip's fp16 matrix peak (the kernel has every CU)",
@@ -386,6 +404,7 @@ def main():
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
             "roofline": dict(roofline, pipeline_achieved_GBps=round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 3)),
             "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "cands_ms", "minu_graph_ms", "fuse_ms", "topk_ms", "total_ms")},
+            "stage_ms_per_step_back_to_back": ({k_: round(alone[k_], 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "cands_ms", "minu_graph_ms", "fuse_ms", "topk_ms", "total_ms")} if alone else None),
             "refine_stats": m.refine_stats() if a.refine_stats else None,
             "per_rank_ms_per_step": {"search": {"min": round(float(pr_min[0]), 3), "max": round(float(pr_max[0]), 3)},
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},
