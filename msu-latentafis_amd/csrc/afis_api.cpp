@@ -516,16 +516,18 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     for (int64_t i = 0; i <= G; ++i) { mo[i] = (int32_t)hg.minu_off[i]; to[i] = (int32_t)hg.tex_off[i]; }
     for (int64_t i = 0; i < G; ++i) max_nR = std::max(max_nR, mo[i + 1] - mo[i]);
     std::vector<short2> mxy(hg.mx.size()), txy(hg.tx.size());
-    for (size_t i = 0; i < mxy.size(); ++i) mxy[i] = make_short2(hg.mx[i], hg.my[i]);
-    for (size_t i = 0; i < txy.size(); ++i) txy[i] = make_short2(hg.tx[i], hg.ty[i]);
+    parallel_for((int64_t)mxy.size(), [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) mxy[(size_t)i] = make_short2(hg.mx[(size_t)i], hg.my[(size_t)i]); });
+    parallel_for((int64_t)txy.size(), [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) txy[(size_t)i] = make_short2(hg.tx[(size_t)i], hg.ty[(size_t)i]); });
     HIPCHK(ctx, upload(ctx->g_minu_off, mo, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_xy, mxy, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_ori, hg.mori, ctx->stream));
     HIPCHK(ctx, upload(ctx->g_minu_des, hg.mdes, ctx->stream));
-    {
-        std::vector<int32_t> toff;
-        const std::vector<float> p = fragment_tiles(hg.mdes, hg.minu_off, toff);
-        HIPCHK(ctx, upload(ctx->g_minu_frag, p, ctx->stream)); HIPCHK(ctx, upload(ctx->g_minu_tile_off, toff, ctx->stream));
+    {   // the descriptors as MFMA operand fragments: laid out on the device from the descriptors just uploaded (round 3 transposed them on the host and uploaded another 34 KB per template)
+        std::vector<int32_t> toff((size_t)G + 1, 0);
+        for (int64_t t = 0; t < G; ++t) toff[(size_t)t + 1] = toff[(size_t)t] + (mo[t + 1] - mo[t] + 15) / 16;
+        HIPCHK(ctx, upload(ctx->g_minu_tile_off, toff, ctx->stream));
+        HIPCHK(ctx, ctx->g_minu_frag.ensure(std::max<size_t>((size_t)toff[(size_t)G] * 6 * 64 * 16, 16)));
+        HIPCHK(ctx, launch_fragment_tiles(ctx->g_minu_des.as<float>(), ctx->g_minu_off.as<int32_t>(), ctx->g_minu_tile_off.as<int32_t>(), (int)G, ctx->g_minu_frag.p, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
     HIPCHK(ctx, upload(ctx->g_tex_off, to, ctx->stream));

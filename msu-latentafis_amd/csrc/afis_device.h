@@ -146,6 +146,8 @@ hipError_t launch_topk(const float* scores, int n_q, int G, int k, long long ind
 
 // optional in-kernel phase timers (build with PHASE_TIMING=1); zeros otherwise
 hipError_t launch_pq_encode(const float* des, long long n, const float* codewords, uint8_t* codes, hipStream_t stream);
+// descriptors -> MFMA operand fragment tiles on the device (pq_encode.hip); off / tile_off: [n_templates + 1] device arrays
+hipError_t launch_fragment_tiles(const float* des, const int32_t* off, const int32_t* tile_off, int n_templates, void* frag, hipStream_t stream);
 hipError_t read_phase_cycles(unsigned long long* out32, bool reset);
 hipError_t read_graph_phase_cycles(unsigned long long* out16, bool reset);
 

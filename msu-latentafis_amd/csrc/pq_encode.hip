@@ -69,4 +69,31 @@ hipError_t launch_pq_encode(const float* des, long long n, const float* codeword
     return hipGetLastError();
 }
 
+// Descriptors re-laid on the device as operand fragments of v_mfma_f32_16x16x4_f32 (minu.hip; layout: afis_api.cpp::fragment_tiles, which still does the latents' on the host):
+// template t (rows off[t] .. off[t+1]) becomes ceil(n/16) tiles of 6 x 64 float4; lane l of load v holds des[16*tile + (l&15)][4*(4v + c) + (l>>4)], c = 0..3; rows past the
+// template's end are zero.  One workgroup per template; the gallery's fragments (34 KB per template) no longer cross PCIe at commit.
+__global__ __launch_bounds__(256) void k_fragment_tiles(const float* __restrict__ des, const int32_t* __restrict__ off, const int32_t* __restrict__ tile_off, float4* __restrict__ frag)
+{
+    const int t = blockIdx.x;
+    const int r0 = off[t], n = off[t + 1] - r0;
+    const int t0 = tile_off[t], nt = tile_off[t + 1] - t0;
+    for (int e = threadIdx.x; e < nt * 6 * 64; e += 256) {                // one float4 of the output per thread and step
+        const int tile = e / (6 * 64), r = e - tile * (6 * 64), v = r >> 6, l = r & 63;
+        const int row = tile * 16 + (l & 15), lg = l >> 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n) {
+            const float* src = des + (size_t)(r0 + row) * kDes + lg;
+            x = make_float4(src[4 * (4 * v + 0)], src[4 * (4 * v + 1)], src[4 * (4 * v + 2)], src[4 * (4 * v + 3)]);
+        }
+        frag[(size_t)(t0 + tile) * (6 * 64) + r] = x;
+    }
+}
+
+hipError_t launch_fragment_tiles(const float* des, const int32_t* off, const int32_t* tile_off, int n_templates, void* frag, hipStream_t stream)
+{
+    if (n_templates <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fragment_tiles, dim3(n_templates), dim3(256), 0, stream, des, off, tile_off, (float4*)frag);
+    return hipGetLastError();
+}
+
 }  // namespace afis
