@@ -63,6 +63,7 @@ struct afis_ctx {
     hipStream_t stream_hi = nullptr;     // option bound_cus: the complement of stream_lo's CUs, for the minutiae stage while the bound pass runs
     hipStream_t stream_lo = nullptr;     // option bound_cus: a stream confined to the low N CUs (N / 8 of every XCD) for the power-limited bound pass; the rest of a launch group runs beside it
     int bound_cus = 0;                   // 0 = off: one stream, the kernels of a group back to back
+    int n_cus = 0;                       // compute units of the device (hipDeviceProp_t::multiProcessorCount): the CU masks are built for this many
     std::vector<hipEvent_t> evpool;      // 10 per query group + 2: the groups of a search run back to back, timings are read at the end
     std::string err;
     DevBuf codewords, table;
@@ -241,6 +242,7 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
         return fail(nullptr, AFIS_EDEVICE, std::string("afis_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
     afis_ctx* c = new afis_ctx();
     c->device = device_id;
+    c->n_cus = prop.multiProcessorCount;
 #define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); afis_destroy(c); return AFIS_EDEVICE; } } while (0)
     CRCHK(hipSetDevice(device_id));
     if (const char* cm = getenv("AFIS_CU_MASK")) {                           // experiment knob: comma-separated hex words of a CU mask for the context's stream
@@ -265,7 +267,7 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
     // templates, profiles/r04_overlap_ab.json).  AFIS_BOUND_CUS overrides (0 = one stream, the kernels back to back).  A runtime that refuses CU masks leaves it off.
     {
         const char* e = getenv("AFIS_BOUND_CUS");
-        const int64_t n = e ? atoll(e) : 128;
+        const int64_t n = e ? atoll(e) : (c->n_cus == 256 ? 128 : 0);          // measured on the whole MI355X (256 CUs); a partitioned device keeps the single stream unless told otherwise
         if (afis_set_option(c, "bound_cus", n) != AFIS_OK) { c->bound_cus = 0; c->err.clear(); }
     }
     return AFIS_OK;
@@ -1181,12 +1183,13 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
     else if (n == "bound_cus") {                                           // 0 = off; 32..224 in steps of 32: the bound pass on a stream confined to that many CUs (value / 8 of every XCD), the minutiae stage beside it on the others
         if (value < 0 || value > 224 || (value & 31)) return fail(ctx, AFIS_EINVAL, "bound_cus must be 0 (off), 32, 64, ... 224 (the runtime honours CU masks in steps of 32 CUs: 4 per XCD)");
+        if (value > 0 && value + 32 > ctx->n_cus) return fail(ctx, AFIS_EINVAL, "bound_cus must leave at least 32 of the device's CUs to the other stream");
         if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AFIS_EDEVICE, "bound_cus: hipSetDevice failed");
         for (hipStream_t* ps : {&ctx->stream_lo, &ctx->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
         ctx->bound_cus = (int)value;
         if (value > 0) {
             uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the runtime deals the mask's bits round-robin over the XCDs: the low N bits are N / 8 CUs of each
-            for (int b = 0; b < 256; ++b) (b < (int)value ? lo : hi)[b >> 5] |= 1u << (b & 31);
+            for (int b = 0; b < std::min(256, ctx->n_cus); ++b) (b < (int)value ? lo : hi)[b >> 5] |= 1u << (b & 31);
             hipError_t e = hipExtStreamCreateWithCUMask(&ctx->stream_lo, 8, lo);
             if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->stream_hi, 8, hi);
             if (e != hipSuccess) {
