@@ -195,6 +195,7 @@ def main():
     ap.add_argument("--tile-share", type=int, default=0)
     ap.add_argument("--bound-cus", type=int, default=-1, help="CUs the bound pass is confined to, the minutiae stage running beside it on the others (-1 = the library's default, 128; 0 = one stream, kernels back to back)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the extra back-to-back steps after the timed region (roofline.alone_on_the_chip): for profiler runs, whose per-kernel averages they would mix into")
     ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (a few atomics per pair; not for timed runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "cpp"], help="the rank-list exchange step: torch = torch.distributed all_gather (host/sharding.py); "
@@ -316,7 +317,7 @@ def main():
     # ---- outside the timed region: the same step with the kernels back to back on one stream, so that the line also carries the bound pass's duration when it
     # has the whole chip (the roofline of the kernel by itself) and the per-stage times without overlap.  Two steps after one warm-up step; rank lists must not change.
     alone = None
-    if bound_cus > 0 and world == 1:
+    if bound_cus > 0 and world == 1 and not a.no_alone:
         m.set_option("bound_cus", 0)
         m.search_resident(qh, k=a.k)
         acc = None

@@ -15,7 +15,7 @@ for g in 12500 25000 50000; do python bench.py --steps 3 --warmup 1 --gallery $g
 python bench.py --queries 1 --gallery 10000 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/latency_1x10k.json 2> $OUT/latency_1x10k.err
 python bench.py --queries 1 --gallery 100000 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/latency_1x100k.json 2> $OUT/latency_1x100k.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alone > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 python $REPO/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats.csv
 rocprofv3 --kernel-trace --stats -d $OUT/stats0 -o stats -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --bound-cus 0 > $OUT/bench_profiled_b2b.json 2> $OUT/bench_profiled_b2b.err
 python $REPO/tools/rocprof_summary.py $(find $OUT/stats0 -name "*.db" | head -1) $OUT/kernel_stats_back_to_back.csv
