@@ -227,11 +227,12 @@ def main():
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":       # RCCL's version banner goes to stdout; keep stdout to the one JSON line
             del os.environ["NCCL_DEBUG"]
-        torch.cuda.set_device(gpu)
         if a.backend == "nccl":
+            torch.cuda.set_device(gpu)
             dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
-        else:
+        else:                                                           # gloo (tests): rendezvous first — nothing a rank can fail on sits between the test hook above and the point where the ranks wait for each other
             dist.init_process_group(a.backend)
+            torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu) if a.backend == "nccl" else torch.device("cpu")
 
     with open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb") as f:

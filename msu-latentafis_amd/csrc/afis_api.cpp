@@ -108,8 +108,8 @@ int fail(afis_ctx* ctx, int code, const std::string& msg)
     do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                          \
         return fail(ctx, AFIS_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
-template <class T>
-hipError_t upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
+template <class T, class A>
+hipError_t upload(DevBuf& b, const std::vector<T, A>& v, hipStream_t s)
 {
     hipError_t e = b.ensure(std::max<size_t>(v.size() * sizeof(T), 16));
     if (e != hipSuccess) return e;

@@ -36,6 +36,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "../../include/afis_matcher.h"
@@ -366,6 +367,8 @@ int main(int argc, char** argv)
         const size_t G = rolled.size(), Gl = (size_t)(job.hi - job.lo), Gm = (size_t)job.g_max;
         const size_t batch = 16;
         std::vector<std::string> quoted;                                         // the gallery paths as `operator<<(ostream&, path)` prints them (quoted, escaped) + ","
+        struct Joined { std::thread t; ~Joined() { if (t.joinable()) t.join(); } } writer_;   // formats and writes the previous batch's score files (declared after what it reads)
+        std::thread& writer = writer_.t;
         for (size_t i0 = 0; i0 < latents.size(); i0 += batch) {
             const size_t nb = std::min(batch, latents.size() - i0);
             double t_s = StageClock::now();
@@ -392,6 +395,8 @@ int main(int argc, char** argv)
                 if (!job.root()) continue;
             }
             t_s = StageClock::now();
+            if (quoted.empty()) { quoted.reserve(G); for (size_t j = 0; j < G; ++j) { std::ostringstream q; q << rolled[j]; quoted.push_back(q.str() + ","); } }
+            std::vector<std::pair<std::string, size_t>> files;                   // (csv path, row of `scores`) of this batch's score files
             for (size_t i = 0; i < nb; ++i) {
                 const fs::path& lf = latents[i0 + i];
                 std::cout << lf << std::endl;
@@ -404,18 +409,36 @@ int main(int argc, char** argv)
                     continue;
                 }
                 if (status[i] == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Skipping." << std::endl; continue; }   // :191-194
-                // :201-204: one `"<path>",<score %.3f>` line per gallery file.  The same bytes as `out << path << "," << setprecision(3) << fixed << score << endl`,
-                // formatted into one buffer and written once (endl flushes every line: 10^5 - 10^6 write calls per latent)
-                if (quoted.empty()) { quoted.reserve(G); for (size_t j = 0; j < G; ++j) { std::ostringstream q; q << rolled[j]; quoted.push_back(q.str() + ","); } }
-                std::string buf;
-                buf.reserve(G * (quoted.empty() ? 16 : quoted[0].size() + 12));
-                char num[64];
-                for (size_t j = 0; j < G; ++j) { buf += quoted[j]; const int n = snprintf(num, sizeof(num), "%.3f\n", (double)scores[i * G + j]); buf.append(num, (size_t)n); }
-                std::ofstream out(csv, std::ios::binary);
-                out.write(buf.data(), (std::streamsize)buf.size());
+                files.emplace_back(csv, i);
             }
+            // :201-204: one `"<path>",<score %.3f>` line per gallery file.  The same bytes as `out << path << "," << setprecision(3) << fixed << score << endl`,
+            // formatted into one buffer per file and written once (endl flushes every line: 10^5 - 10^6 write calls per latent).  The files of a batch are
+            // independent: they are formatted and written by a few threads while the next batch is searched; the previous batch's writer is joined first.
+            if (writer.joinable()) writer.join();
+            writer = std::thread([files = std::move(files), scores = std::move(scores), &quoted, G]() {
+                std::atomic<size_t> next{0};
+                auto work = [&]() {
+                    char num[64];
+                    for (size_t f = next.fetch_add(1); f < files.size(); f = next.fetch_add(1)) {
+                        const float* row = &scores[files[f].second * G];
+                        std::string buf;
+                        buf.reserve(G * (quoted.empty() ? 16 : quoted[0].size() + 12));
+                        for (size_t j = 0; j < G; ++j) { buf += quoted[j]; const int n = snprintf(num, sizeof(num), "%.3f\n", (double)row[j]); buf.append(num, (size_t)n); }
+                        std::ofstream out(files[f].first, std::ios::binary);
+                        out.write(buf.data(), (std::streamsize)buf.size());
+                    }
+                };
+                const size_t n_thr = std::min<size_t>(files.size(), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+                std::vector<std::thread> th;
+                for (size_t t = 1; t < n_thr; ++t) th.emplace_back(work);
+                work();
+                for (std::thread& x : th) x.join();
+            });
             g_clock.write += StageClock::now() - t_s;
         }
+        const double t_w = StageClock::now();
+        if (writer.joinable()) writer.join();
+        g_clock.write += StageClock::now() - t_w;
         const double total_d = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
         std::cout << "Total matching duration (ms): " << total_d << std::endl;
         g_clock.report(job.w.rank, total_d + g_clock.scan);

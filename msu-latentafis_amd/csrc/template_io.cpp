@@ -1,5 +1,8 @@
 #include "template_io.h"
 
+#include <algorithm>
+#include <thread>
+#include <atomic>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -302,13 +305,31 @@ bool read_gallery_container(const std::string& path, int64_t first, int64_t coun
     if (tex_counts) { tex_counts->resize((size_t)h.G); for (int64_t i = 0; i < h.G; ++i) (*tex_counts)[(size_t)i] = (int32_t)(to[i + 1] - to[i]); }
     const int64_t m0 = mo[first], m1 = mo[first + count], t0 = to[first], t1 = to[first + count];
     if (load_data) {                                                       // listing the names / counts of a 5 GB container must not copy its arrays
+    // The arrays are grown without a zero-fill (BulkVec) and filled by a few threads: a shard of 100 000 templates is 5 GB, and one thread
+    // faulting in and copying that much is a second per container (the page cache delivers several times that to parallel readers).
+    struct Job { uint8_t* dst; const uint8_t* src; size_t bytes; };
+    std::vector<Job> jobs;
     auto app = [&](auto& vec, int sec, int64_t a, int64_t b, size_t per) {
         typedef typename std::remove_reference<decltype(vec)>::type V;
-        const typename V::value_type* src = (const typename V::value_type*)(m.p + h.off[sec]);
-        vec.insert(vec.end(), src + (size_t)a * per, src + (size_t)b * per);
+        typedef typename V::value_type T;
+        const size_t old = vec.size(), n = (size_t)(b - a) * per;
+        vec.resize(old + n);
+        const uint8_t* src = m.p + h.off[sec] + (size_t)a * per * sizeof(T);
+        uint8_t* dst = (uint8_t*)(vec.data() + old);
+        const size_t chunk = (size_t)8 << 20;
+        for (size_t o = 0; o < n * sizeof(T); o += chunk) jobs.push_back({dst + o, src + o, std::min(chunk, n * sizeof(T) - o)});
     };
     app(out.mx, 3, m0, m1, 1); app(out.my, 4, m0, m1, 1); app(out.mori, 5, m0, m1, 1); app(out.mdes, 6, m0, m1, 96);
     app(out.tx, 7, t0, t1, 1); app(out.ty, 8, t0, t1, 1); app(out.tori, 9, t0, t1, 1); app(out.tcodes, 10, t0, t1, 16);
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t j = next.fetch_add(1); j < jobs.size(); j = next.fetch_add(1)) memcpy(jobs[j].dst, jobs[j].src, jobs[j].bytes); };
+        const size_t n_thr = std::min<size_t>(std::max<size_t>(jobs.size(), 1), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n_thr; ++t) th.emplace_back(work);
+        work();
+        for (std::thread& x : th) x.join();
+    }
     const int64_t mb = out.minu_off.back() - m0, tb = out.tex_off.back() - t0;
     const uint8_t* emp = m.p + h.off[2];
     for (int64_t i = first; i < first + count; ++i) { out.minu_off.push_back(mo[i + 1] + mb); out.tex_off.push_back(to[i + 1] + tb); out.empty.push_back(emp[i]); }
