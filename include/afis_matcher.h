@@ -105,6 +105,10 @@ int afis_gallery_add_dat(afis_ctx* ctx, const void* bytes, size_t len, int* load
 /* n rolled .dat files in one call: parsed on the host's threads, appended in order; load_rc (optional) receives n reader codes.
  * Nothing is appended when any file is rejected (AFIS_EINVAL, as afis_gallery_add_dat). */
 int afis_gallery_add_dat_batch(afis_ctx* ctx, const void* const* bytes, const size_t* lens, int64_t n, int* load_rc);
+/* Hint: the staged gallery will grow to about n_templates templates.  The host arrays reserve address space for them pro rata (from what is
+ * staged so far; 80 minutiae and 800 texture points per template if nothing is), so that a gallery added in many slices is not re-copied every
+ * time an array outgrows its allocation (a 100 000-file directory: 5 GB staged, 6 GB of re-copying without the hint).  Never required. */
+int afis_gallery_reserve(afis_ctx* ctx, int64_t n_templates);
 /* Bulk add of n templates with exactly one minutiae and one texture template each, as concatenated arrays with
  * CSR offsets (off[n+1], in points).  A zero-length range means "template absent". */
 int afis_gallery_add_packed(afis_ctx* ctx, int64_t n,
@@ -152,7 +156,11 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q);
  * 100k-1M template gallery is loaded — whole, or one contiguous shard per GPU — without touching 100k-1M small files.
  * afis_gallery_save   writes the templates staged so far (before afis_gallery_commit); names[i] (optional) = the path template
  *                     i was read from, kept for the score files.
- * afis_gallery_load   appends templates [first, first+count) of the file (count < 0: to the end) to the staged gallery.
+ * afis_gallery_load   appends templates [first, first+count) of the file (count < 0: to the end) to the staged gallery.  Into an EMPTY staging
+ *                     area (the usual case: one container, or one shard of it per rank) the file is validated and kept mapped, and
+ *                     afis_gallery_commit uploads the range straight from the mapping (no host copy of its 50 KB per template): the
+ *                     file must not be truncated or rewritten between the two calls.  Any other staging call in between first copies
+ *                     the range into host memory, as every load into a non-empty staging area does.
  * afis_gallery_file_info  template / point totals, and (optional) the texture point count of every template, the quantity shards
  *                     are balanced by.
  * afis_gallery_file_names  the names of a range as consecutive NUL-terminated strings; buf == NULL only reports *need. */

@@ -9,11 +9,15 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
+#include <sys/mman.h>
 
 #include "afis_device.h"
 #include "template_io.h"
@@ -29,9 +33,16 @@ struct DevBuf {
     hipError_t ensure(size_t n)
     {
         if (n <= bytes) return hipSuccess;
+        static const bool trace = getenv("AFIS_ALLOC_TRACE") != nullptr;   // development aid: every (re)allocation of 64 MB or more, with the time it took, on stderr
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t was = bytes;
         if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        const auto t1 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, n);
         if (e == hipSuccess) bytes = n;
+        if (trace && n >= ((size_t)64 << 20))
+            fprintf(stderr, "alloc: %.3f GB (was %.3f): hipFree %.1f ms, hipMalloc %.1f ms\n", n / 1e9, was / 1e9, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
@@ -68,6 +79,11 @@ struct afis_ctx {
     std::string err;
     DevBuf codewords, table;
     HostGallery hg;
+    // afis_gallery_load into an empty staging area keeps the container MAPPED instead of copying its 50 KB per template into hg: the commit uploads the shard
+    // [pend_first, pend_first + pend_count) straight from the mapping.  Anything else that touches the staged gallery first copies it into hg (materialise()).
+    std::unique_ptr<GalleryMapping> pend;
+    int64_t pend_first = 0, pend_count = 0;
+    std::thread staging_reaper;          // returns the staged arrays to the system after the commit (0.5 s per 5 GB), off the caller's path; joined in afis_destroy
     bool committed = false;
     int64_t index_base = 0;
     GalleryDev gal;
@@ -103,6 +119,18 @@ int fail(afis_ctx* ctx, int code, const std::string& msg)
 {
     if (ctx) ctx->err = msg; else g_create_error = msg;
     return code;
+}
+
+// the staged gallery as host arrays: a container that afis_gallery_load only mapped is copied into ctx->hg now
+int materialise(afis_ctx* ctx)
+{
+    if (!ctx->pend) return AFIS_OK;
+    std::string err;
+    HostGallery add;
+    if (!read_gallery_container(ctx->pend->path, ctx->pend_first, ctx->pend_count, add, nullptr, nullptr, err)) return fail(ctx, AFIS_EFORMAT, "gallery container: " + err);
+    ctx->hg = std::move(add);
+    ctx->pend.reset(); ctx->pend_first = ctx->pend_count = 0;
+    return AFIS_OK;
 }
 #define HIPCHK(ctx, call)                                                                                       \
     do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                          \
@@ -292,6 +320,7 @@ void afis_destroy(afis_ctx* c)
     c->mf_cw16.release(); c->mf_cwn.release(); c->mf_bfrag.release(); c->mf_rowk.release(); c->mf_rec.release(); c->mf_stats.release();
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->staging_reaper.joinable()) c->staging_reaper.join();
     delete c;
 }
 
@@ -301,6 +330,7 @@ int afis_gallery_add(afis_ctx* ctx, const afis_template_view* t, int n)
 {
     if (!ctx || (n > 0 && !t)) return fail(ctx, AFIS_EINVAL, "afis_gallery_add: null argument");
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add: gallery already committed");
+    if (int rc_ = materialise(ctx)) return rc_;
     for (int i = 0; i < n; ++i) { int rc = check_rolled(ctx, t[i]); if (rc) return rc; }
     std::vector<uint8_t> enc;
     for (int i = 0; i < n; ++i) {
@@ -365,6 +395,7 @@ int afis_gallery_add_dat(afis_ctx* ctx, const void* bytes, size_t len, int* load
 {
     if (!ctx) return AFIS_EINVAL;
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add_dat: gallery already committed");
+    if (int rc_ = materialise(ctx)) return rc_;
     HostTemplate t;
     int rc = parse_rolled_dat(bytes, len, t);
     // matcher.cpp:173-177: a negative code discards the template.  Code 8 (a descriptor length outside 1..192, where the reference overruns a
@@ -384,6 +415,7 @@ int afis_gallery_add_dat_batch(afis_ctx* ctx, const void* const* bytes, const si
 {
     if (!ctx || n < 0 || (n > 0 && (!bytes || !lens))) return fail(ctx, AFIS_EINVAL, "afis_gallery_add_dat_batch: bad argument");
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add_dat_batch: gallery already committed");
+    if (int rc_ = materialise(ctx)) return rc_;
     std::vector<HostTemplate> ts((size_t)n);
     std::vector<int> rcs((size_t)n, 0);
     parallel_for(n, [&](int64_t lo, int64_t hi) {
@@ -398,12 +430,62 @@ int afis_gallery_add_dat_batch(afis_ctx* ctx, const void* const* bytes, const si
         views_of(ts[(size_t)i], mv, tv, v);
         int ok = check_rolled(ctx, v);
         if (ok != AFIS_OK) return ok;
+        if (v.n_tex > 0 && !v.tex[0].codes) return fail(ctx, AFIS_EFORMAT, "afis_gallery_add_dat_batch: rolled texture template without PQ codes");
     }
+    // append_entry for all of them at once: the slots follow from the counts, the staged arrays grow once (without a zero-fill) and the templates
+    // are copied to their slots by the host's threads (appending one by one was a serial pass over 50 KB per template)
+    HostGallery& hg = ctx->hg;
+    std::vector<int64_t> mo((size_t)n + 1), to((size_t)n + 1);
+    mo[0] = (int64_t)hg.mx.size(); to[0] = (int64_t)hg.tx.size();
     for (int64_t i = 0; i < n; ++i) {
-        views_of(ts[(size_t)i], mv, tv, v);
-        append_entry(ctx->hg, v.n_minu > 0 ? &v.minu[0] : nullptr, v.n_tex > 0 ? &v.tex[0] : nullptr);
+        const HostTemplate& t = ts[(size_t)i];
+        mo[(size_t)i + 1] = mo[(size_t)i] + (t.minu.empty() ? 0 : t.minu[0].n());
+        to[(size_t)i + 1] = to[(size_t)i] + (t.tex.empty() ? 0 : std::min(t.tex[0].n(), kTexMax));          // matcher.cpp:546-547
+    }
+    const size_t M = (size_t)mo[(size_t)n], X = (size_t)to[(size_t)n];
+    hg.mx.resize(M); hg.my.resize(M); hg.mori.resize(M); hg.mdes.resize(M * kDes);
+    hg.tx.resize(X); hg.ty.resize(X); hg.tori.resize(X); hg.tcodes.resize(X * kM);
+    parallel_for(n, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const HostTemplate& t = ts[(size_t)i];
+            const size_t a = (size_t)mo[(size_t)i], nm = (size_t)(mo[(size_t)i + 1] - mo[(size_t)i]);
+            if (nm) {
+                const HostMinutiae& m = t.minu[0];
+                memcpy(&hg.mx[a], m.x.data(), nm * 2); memcpy(&hg.my[a], m.y.data(), nm * 2); memcpy(&hg.mori[a], m.ori.data(), nm * 4);
+                memcpy(&hg.mdes[a * kDes], m.des.data(), nm * kDes * 4);
+            }
+            const size_t b = (size_t)to[(size_t)i], nt = (size_t)(to[(size_t)i + 1] - to[(size_t)i]);
+            if (nt) {
+                const HostTexture& x = t.tex[0];
+                memcpy(&hg.tx[b], x.x.data(), nt * 2); memcpy(&hg.ty[b], x.y.data(), nt * 2); memcpy(&hg.tori[b], x.ori.data(), nt * 4);
+                memcpy(&hg.tcodes[b * kM], x.codes.data(), nt * kM);
+            }
+        }
+    });
+    for (int64_t i = 0; i < n; ++i) {
+        hg.minu_off.push_back(mo[(size_t)i + 1]); hg.tex_off.push_back(to[(size_t)i + 1]);
+        hg.empty.push_back(mo[(size_t)i + 1] == mo[(size_t)i] && to[(size_t)i + 1] == to[(size_t)i] ? 1 : 0);
         if (load_rc) load_rc[i] = rcs[(size_t)i];
     }
+    return AFIS_OK;
+}
+
+int afis_gallery_reserve(afis_ctx* ctx, int64_t n_templates)
+{
+    if (!ctx || n_templates < 0) return fail(ctx, AFIS_EINVAL, "afis_gallery_reserve: bad argument");
+    if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_reserve: gallery already committed");
+    if (ctx->pend) return AFIS_OK;                                          // a mapped container is not staged in host arrays at all
+    HostGallery& hg = ctx->hg;
+    const double have = (double)hg.size();
+    if ((double)n_templates <= have) return AFIS_OK;
+    const double scale = have > 0 ? (double)n_templates / have * 1.02 : 0;  // 2 % headroom over the running average
+    const size_t nm = have > 0 ? (size_t)((double)hg.mx.size() * scale) : (size_t)n_templates * 80;
+    const size_t nt = have > 0 ? (size_t)((double)hg.tx.size() * scale) : (size_t)n_templates * 800;
+    try {
+        hg.mx.reserve(nm); hg.my.reserve(nm); hg.mori.reserve(nm); hg.mdes.reserve(nm * kDes);
+        hg.tx.reserve(nt); hg.ty.reserve(nt); hg.tori.reserve(nt); hg.tcodes.reserve(nt * kM);
+        hg.minu_off.reserve((size_t)n_templates + 1); hg.tex_off.reserve((size_t)n_templates + 1); hg.empty.reserve((size_t)n_templates);
+    } catch (const std::bad_alloc&) { return fail(ctx, AFIS_EINVAL, "afis_gallery_reserve: out of host memory"); }
     return AFIS_OK;
 }
 
@@ -413,6 +495,7 @@ int afis_gallery_add_packed(afis_ctx* ctx, int64_t n, const int64_t* minu_off, c
 {
     if (!ctx || n < 0 || !minu_off || !tex_off) return fail(ctx, AFIS_EINVAL, "afis_gallery_add_packed: null argument");
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_add_packed: gallery already committed");
+    if (int rc_ = materialise(ctx)) return rc_;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t nm = minu_off[i + 1] - minu_off[i], nt = tex_off[i + 1] - tex_off[i];
         if (nm < 0 || nm > 2000 || nt < 0 || nt > 2000) return fail(ctx, AFIS_EINVAL, "afis_gallery_add_packed: template point count must be 0..2000");
@@ -441,6 +524,7 @@ int afis_gallery_save(afis_ctx* ctx, const char* path, const char* const* names)
 {
     if (!ctx || !path) return fail(ctx, AFIS_EINVAL, "afis_gallery_save: null argument");
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_save: the host staging copy is released at commit; save before afis_gallery_commit");
+    if (int rc_ = materialise(ctx)) return rc_;
     std::vector<std::string> nm;
     if (names) for (int64_t i = 0; i < ctx->hg.size(); ++i) nm.emplace_back(names[i] ? names[i] : "");
     std::string err;
@@ -453,6 +537,19 @@ int afis_gallery_load(afis_ctx* ctx, const char* path, int64_t first, int64_t co
     if (!ctx || !path) return fail(ctx, AFIS_EINVAL, "afis_gallery_load: null argument");
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_load: gallery already committed");
     std::string err;
+    if (ctx->hg.size() == 0 && !ctx->pend) {                               // the usual case (one container, or one shard of it): map it, validate it, read it at the commit
+        std::unique_ptr<GalleryMapping> gm = map_gallery_container(path, err);
+        if (!gm) return fail(ctx, AFIS_EFORMAT, "afis_gallery_load: " + err);
+        if (count < 0) count = gm->G - first;
+        if (first < 0 || count < 0 || first + count > gm->G) return fail(ctx, AFIS_EFORMAT, std::string("afis_gallery_load: ") + path + ": template range outside the container");
+        for (int64_t i = first; i < first + count; ++i) {
+            const int64_t nm = gm->minu_off[i + 1] - gm->minu_off[i], nt = gm->tex_off[i + 1] - gm->tex_off[i];
+            if (nm > 2000 || nt > kTexMax || (gm->empty[i] != 0) != (nm == 0 && nt == 0)) return fail(ctx, AFIS_EFORMAT, "afis_gallery_load: template counts out of range");
+        }
+        ctx->pend = std::move(gm); ctx->pend_first = first; ctx->pend_count = count;
+        return AFIS_OK;
+    }
+    if (int rc_ = materialise(ctx)) return rc_;
     HostGallery add;                                                       // parsed aside so a bad file leaves the staged gallery untouched
     if (!read_gallery_container(path, first, count, add, nullptr, nullptr, err)) return fail(ctx, AFIS_EFORMAT, "afis_gallery_load: " + err);
     const int64_t n = add.size();
@@ -461,7 +558,7 @@ int afis_gallery_load(afis_ctx* ctx, const char* path, int64_t first, int64_t co
         if (nm > 2000 || nt > kTexMax || (add.empty[i] != 0) != (nm == 0 && nt == 0)) return fail(ctx, AFIS_EFORMAT, "afis_gallery_load: template counts out of range");
     }
     HostGallery& hg = ctx->hg;
-    if (hg.size() == 0) { hg = std::move(add); return AFIS_OK; }           // the usual case (one container, or one shard of it): no second copy of its 50 KB per template
+    if (hg.size() == 0) { hg = std::move(add); return AFIS_OK; }
     const int64_t mb = hg.minu_off.back(), tb = hg.tex_off.back();
     hg.mx.insert(hg.mx.end(), add.mx.begin(), add.mx.end()); hg.my.insert(hg.my.end(), add.my.begin(), add.my.end());
     hg.mori.insert(hg.mori.end(), add.mori.begin(), add.mori.end()); hg.mdes.insert(hg.mdes.end(), add.mdes.begin(), add.mdes.end());
@@ -504,44 +601,102 @@ int afis_gallery_file_names(const char* path, int64_t first, int64_t count, char
     return AFIS_OK;
 }
 
+// The arrays of a shard are 50 KB per template (5 GB per 100 000): a pageable hipMemcpy moves them at 8-11 GB/s through the runtime's one staging thread.
+// Here they go through two pinned 64 MB buffers: the host's threads fill one (from the staged arrays or straight from a mapped container: that is where
+// the page cache is read) while the DMA engine empties the other.
+struct PinnedPipe {
+    static constexpr size_t kCap = (size_t)64 << 20;
+    void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; int k = 0;
+    hipError_t init()
+    {
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipHostMalloc(&buf[i], kCap, hipHostMallocDefault); if (e != hipSuccess) return e;
+            e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming); if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    ~PinnedPipe() { for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (buf[i]) (void)hipHostFree(buf[i]); } }
+};
+
+static hipError_t upload_bulk(PinnedPipe& pp, DevBuf& b, const void* src, size_t bytes, hipStream_t s)
+{
+    hipError_t e = b.ensure(std::max<size_t>(bytes, 16));
+    if (e != hipSuccess || bytes == 0) return e;
+    if (bytes < ((size_t)4 << 20)) return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, s);
+    for (size_t off = 0; off < bytes; off += PinnedPipe::kCap) {
+        const size_t n = std::min(PinnedPipe::kCap, bytes - off);
+        const int slot = pp.k & 1;
+        if (pp.used[slot]) { e = hipEventSynchronize(pp.ev[slot]); if (e != hipSuccess) return e; }
+        const uint8_t* from = (const uint8_t*)src + off; uint8_t* to = (uint8_t*)pp.buf[slot];
+        parallel_for((int64_t)((n + 4095) / 4096), [&](int64_t lo, int64_t hi) { const size_t a = (size_t)lo * 4096, z = std::min(n, (size_t)hi * 4096); memcpy(to + a, from + a, z - a); });
+        e = hipMemcpyAsync((uint8_t*)b.p + off, pp.buf[slot], n, hipMemcpyHostToDevice, s); if (e != hipSuccess) return e;
+        e = hipEventRecord(pp.ev[slot], s); if (e != hipSuccess) return e;
+        pp.used[slot] = true; ++pp.k;
+    }
+    return hipSuccess;
+}
+
 int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
 {
     if (!ctx) return AFIS_EINVAL;
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_commit: already committed");
+    // The staged shard as plain arrays: ctx->hg, or the mapped container's range (offsets rebased to the shard's first point).
     HostGallery& hg = ctx->hg;
-    const int64_t G = hg.size();
-    if (G > 0x7fffffff / 8 || hg.mx.size() > 0x7fffffffull || hg.tx.size() > 0x7fffffffull)
+    const GalleryMapping* gm = ctx->pend.get();
+    const int64_t G = gm ? ctx->pend_count : hg.size();
+    const int64_t* src_mo = gm ? gm->minu_off + ctx->pend_first : hg.minu_off.data();
+    const int64_t* src_to = gm ? gm->tex_off + ctx->pend_first : hg.tex_off.data();
+    const int64_t m0 = src_mo[0], t0 = src_to[0];
+    const size_t NM = (size_t)(src_mo[G] - m0), NT = (size_t)(src_to[G] - t0);
+    const int16_t* s_mx = gm ? gm->mx + m0 : hg.mx.data(); const int16_t* s_my = gm ? gm->my + m0 : hg.my.data();
+    const float* s_mori = gm ? gm->mori + m0 : hg.mori.data(); const float* s_mdes = gm ? gm->mdes + (size_t)m0 * kDes : hg.mdes.data();
+    const int16_t* s_tx = gm ? gm->tx + t0 : hg.tx.data(); const int16_t* s_ty = gm ? gm->ty + t0 : hg.ty.data();
+    const float* s_tori = gm ? gm->tori + t0 : hg.tori.data(); const uint8_t* s_tcodes = gm ? gm->tcodes + (size_t)t0 * kM : hg.tcodes.data();
+    const uint8_t* s_empty = gm ? gm->empty + ctx->pend_first : hg.empty.data();
+    if (G > 0x7fffffff / 8 || NM > 0x7fffffffull || NT > 0x7fffffffull)
         return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for 32-bit point offsets; split the gallery into more shards");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool clock_it = getenv("AFIS_COMMIT_TIMING") != nullptr;           // development aid: where the commit's time goes, on stderr
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) { if (clock_it) { (void)hipStreamSynchronize(ctx->stream); const double t = now(); fprintf(stderr, "commit: %-28s %8.1f ms\n", what, t - t_prev); t_prev = t; } };
+    PinnedPipe pp;
+    HIPCHK(ctx, pp.init());
+    lap("pinned buffers");
     std::vector<int32_t> mo(G + 1), to(G + 1);
     int max_nR = 0;
-    for (int64_t i = 0; i <= G; ++i) { mo[i] = (int32_t)hg.minu_off[i]; to[i] = (int32_t)hg.tex_off[i]; }
+    for (int64_t i = 0; i <= G; ++i) { mo[i] = (int32_t)(src_mo[i] - m0); to[i] = (int32_t)(src_to[i] - t0); }
     for (int64_t i = 0; i < G; ++i) max_nR = std::max(max_nR, mo[i + 1] - mo[i]);
-    std::vector<short2> mxy(hg.mx.size()), txy(hg.tx.size());
-    parallel_for((int64_t)mxy.size(), [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) mxy[(size_t)i] = make_short2(hg.mx[(size_t)i], hg.my[(size_t)i]); });
-    parallel_for((int64_t)txy.size(), [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) txy[(size_t)i] = make_short2(hg.tx[(size_t)i], hg.ty[(size_t)i]); });
+    HIPCHK(ctx, upload_bulk(pp, ctx->g_minu_des, s_mdes, NM * kDes * sizeof(float), ctx->stream));     // the big one first: the fragment kernel below runs while the rest is uploaded
+    lap("minutiae descriptors");
     HIPCHK(ctx, upload(ctx->g_minu_off, mo, ctx->stream));
-    HIPCHK(ctx, upload(ctx->g_minu_xy, mxy, ctx->stream));
-    HIPCHK(ctx, upload(ctx->g_minu_ori, hg.mori, ctx->stream));
-    HIPCHK(ctx, upload(ctx->g_minu_des, hg.mdes, ctx->stream));
+    std::vector<int32_t> toff((size_t)G + 1, 0);
     {   // the descriptors as MFMA operand fragments: laid out on the device from the descriptors just uploaded (round 3 transposed them on the host and uploaded another 34 KB per template)
-        std::vector<int32_t> toff((size_t)G + 1, 0);
         for (int64_t t = 0; t < G; ++t) toff[(size_t)t + 1] = toff[(size_t)t] + (mo[t + 1] - mo[t] + 15) / 16;
         HIPCHK(ctx, upload(ctx->g_minu_tile_off, toff, ctx->stream));
         HIPCHK(ctx, ctx->g_minu_frag.ensure(std::max<size_t>((size_t)toff[(size_t)G] * 6 * 64 * 16, 16)));
         HIPCHK(ctx, launch_fragment_tiles(ctx->g_minu_des.as<float>(), ctx->g_minu_off.as<int32_t>(), ctx->g_minu_tile_off.as<int32_t>(), (int)G, ctx->g_minu_frag.p, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
+    lap("fragment tiles");
+    std::vector<short2> mxy(NM), txy(NT);
+    parallel_for((int64_t)NM, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) mxy[(size_t)i] = make_short2(s_mx[i], s_my[i]); });
+    parallel_for((int64_t)NT, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) txy[(size_t)i] = make_short2(s_tx[i], s_ty[i]); });
+    lap("xy packing");
+    HIPCHK(ctx, upload_bulk(pp, ctx->g_minu_xy, mxy.data(), NM * sizeof(short2), ctx->stream));
+    HIPCHK(ctx, upload_bulk(pp, ctx->g_minu_ori, s_mori, NM * sizeof(float), ctx->stream));
     HIPCHK(ctx, upload(ctx->g_tex_off, to, ctx->stream));
-    HIPCHK(ctx, upload(ctx->g_tex_xy, txy, ctx->stream));
-    HIPCHK(ctx, upload(ctx->g_tex_ori, hg.tori, ctx->stream));
-    HIPCHK(ctx, upload(ctx->g_tex_codes, hg.tcodes, ctx->stream));
+    HIPCHK(ctx, upload_bulk(pp, ctx->g_tex_xy, txy.data(), NT * sizeof(short2), ctx->stream));
+    HIPCHK(ctx, upload_bulk(pp, ctx->g_tex_ori, s_tori, NT * sizeof(float), ctx->stream));
+    lap("small arrays");
+    HIPCHK(ctx, upload_bulk(pp, ctx->g_tex_codes, s_tcodes, NT * kM, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    lap("texture codes");
     {   // block offsets of the direct conflict-free kernel's code stream (variants 6 / 7): (blocks + 1) x 64 entries per template.  The stream
         // itself — a full copy of the PQ codes — is laid out on the device at the first use of those variants (k_codes_cf); the default path
         // never builds it.
         std::vector<int32_t> cfb(G + 1);
         int64_t nblk = 0;
-        for (int64_t t = 0; t < G; ++t) { cfb[t] = (int32_t)nblk; const int64_t n = hg.tex_off[t + 1] - hg.tex_off[t]; nblk += n > 0 ? (n + 63) / 64 + 1 : 0; }
+        for (int64_t t = 0; t < G; ++t) { cfb[t] = (int32_t)nblk; const int64_t n = (int64_t)(to[t + 1] - to[t]); nblk += n > 0 ? (n + 63) / 64 + 1 : 0; }
         cfb[G] = (int32_t)nblk;
         if (nblk > 0x7fffffff / 64) return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for the ADC code stream; split the gallery into more shards");
         ctx->cf_blocks = nblk; ctx->codes_cf_built = false;
@@ -551,7 +706,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     {   // block offsets of the quantised path's code stream (ceil(n/64) blocks per template); the stream itself is made on first use
         std::vector<int32_t> qb(G + 1);
         int64_t nb = 0;
-        for (int64_t t = 0; t < G; ++t) { qb[t] = (int32_t)nb; nb += (hg.tex_off[t + 1] - hg.tex_off[t] + 63) / 64; }
+        for (int64_t t = 0; t < G; ++t) { qb[t] = (int32_t)nb; nb += ((int64_t)(to[t + 1] - to[t]) + 63) / 64; }
         qb[G] = (int32_t)nb;
         ctx->q_blocks = nb;
         HIPCHK(ctx, upload(ctx->g_tex_q_blk, qb, ctx->stream));
@@ -559,13 +714,13 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     {   // tile offsets of the matrix-core bound pass's stream (ceil(n/32) tiles of 32 points per template); the stream itself is made on first use
         std::vector<int32_t> tb(G + 1);
         int64_t nt = 0;
-        for (int64_t t = 0; t < G; ++t) { tb[t] = (int32_t)nt; nt += (hg.tex_off[t + 1] - hg.tex_off[t] + 31) / 32; }
+        for (int64_t t = 0; t < G; ++t) { tb[t] = (int32_t)nt; nt += ((int64_t)(to[t + 1] - to[t]) + 31) / 32; }
         tb[G] = (int32_t)nt;
         if (nt > 0x7fffffff / 32) return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for the bound pass's code stream; split the gallery into more shards");
         ctx->t32_tiles = nt;
         HIPCHK(ctx, upload(ctx->g_tex_t32_blk, tb, ctx->stream));
     }
-    HIPCHK(ctx, upload(ctx->g_empty, hg.empty, ctx->stream));
+    { DevBuf& eb = ctx->g_empty; HIPCHK(ctx, eb.ensure(std::max<size_t>((size_t)G, 16))); if (G) HIPCHK(ctx, hipMemcpyAsync(eb.p, s_empty, (size_t)G, hipMemcpyHostToDevice, ctx->stream)); }
     HIPCHK(ctx, ctx->g_task_ctr.ensure(64));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     GalleryDev& g = ctx->gal;
@@ -575,17 +730,33 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = nullptr; g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
     g.task_ctr = ctx->g_task_ctr.as<int32_t>();
     ctx->max_nR = max_nR;
-    ctx->total_tex_points = (int64_t)hg.tx.size();
+    ctx->total_tex_points = (int64_t)NT;
     ctx->index_base = index_base;
     ctx->committed = true;
     // the host staging copy is no longer needed
-    HostGallery keep; keep.empty = hg.empty; keep.minu_off.clear(); keep.tex_off.clear();
-    std::vector<uint8_t> e = hg.empty;
+    std::vector<uint8_t> e(s_empty, s_empty + G);
+    if (hg.mdes.capacity() > ((size_t)16 << 20)) {                           // a large staging copy is released by a thread of its own
+        // The pages go back in 32 MB pieces (madvise takes the address-space lock shared and briefly); one munmap of 3 GB holds it exclusively for
+        // a third of a second, and every allocation the caller makes next — the commit's own clean-up, the first search — would wait for it.
+        HostGallery* old = new HostGallery(std::move(ctx->hg));
+        ctx->staging_reaper = std::thread([old]() {
+            auto drop = [](void* p, size_t bytes) {
+                const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, z = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+                for (uintptr_t q = a; q < z; q += (uintptr_t)32 << 20) (void)madvise((void*)q, (size_t)std::min<uintptr_t>((uintptr_t)32 << 20, z - q), MADV_DONTNEED);
+            };
+            drop(old->mdes.data(), old->mdes.capacity() * sizeof(float)); drop(old->tcodes.data(), old->tcodes.capacity());
+            drop(old->mori.data(), old->mori.capacity() * 4); drop(old->tori.data(), old->tori.capacity() * 4);
+            delete old;
+        });
+    }
+    lap("offset tables");
     ctx->hg = HostGallery(); ctx->hg.empty = std::move(e);
+    ctx->pend.reset(); ctx->pend_first = ctx->pend_count = 0;
+    lap("staging released");
     return AFIS_OK;
 }
 
-int64_t afis_gallery_size(const afis_ctx* ctx) { return ctx ? (int64_t)ctx->hg.empty.size() : 0; }
+int64_t afis_gallery_size(const afis_ctx* ctx) { return !ctx ? 0 : ctx->pend ? ctx->pend_count : (int64_t)ctx->hg.empty.size(); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 static const int kSelected[3] = {27 - 1, 3 - 1, 12 - 1};                   // matcher.cpp:380
@@ -782,9 +953,12 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
         ctx->mf_gal_built = true;
     }
     const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
-    HIPCHK(ctx, ctx->mf_bfrag.ensure((size_t)n_rb * 6 * 64 * 16));
-    HIPCHK(ctx, ctx->mf_rowk.ensure((size_t)R_pad * 16));
-    HIPCHK(ctx, ctx->mf_rec.ensure((size_t)g.G * R_pad * kMfRecBytesPerRow));
+    // The per-row buffers are sized for the group's WORST case (every latent with kTexMax rows), as afis_search_resident has already done before queuing anything: these
+    // calls find them large enough (a hipMalloc behind queued work was seen to take 0.5-0.8 s; see there).  Callers outside a search (the parity taps) allocate here.
+    const size_t R_cap = std::max<size_t>((size_t)R_pad, ((size_t)grp.nq * kTexMax + 31) / 32 * 32);
+    HIPCHK(ctx, ctx->mf_bfrag.ensure(R_cap / 32 * 6 * 64 * 16));
+    HIPCHK(ctx, ctx->mf_rowk.ensure(R_cap * 16));
+    HIPCHK(ctx, ctx->mf_rec.ensure((size_t)g.G * R_cap * kMfRecBytesPerRow));
     if (ctx->mf_collect_stats && !ctx->mf_stats.p) { HIPCHK(ctx, ctx->mf_stats.ensure(64)); HIPCHK(ctx, hipMemsetAsync(ctx->mf_stats.p, 0, 64, s)); }
     HIPCHK(ctx, launch_mf_rows(d.lt_des, n_rows, n_rb, ctx->codewords.as<float>(), ctx->mf_cwn.as<float>(), ctx->mf_bfrag.p, ctx->mf_rowk.p, s));
     if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s));
@@ -831,6 +1005,43 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     const size_t n_groups = q->groups.size();
     while (ctx->evpool.size() < n_groups * 10 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
     if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
+    // Every buffer of the launch groups is brought to its size HERE, while the device is idle and before anything of this search is queued: for the largest group of
+    // the search and for its worst case (every latent with kTexMax texture rows — what group_bytes_per_query budgets), so that the calls further down never
+    // re-allocate.  A hipMalloc of 6-13 GB takes 0.3 ms on an idle device; issued behind queued work (the row records used to be allocated inside adc_stage_mfma, after
+    // the group's first kernels) it took 510-790 ms in three runs of ten (match -ldir: one search call in seven; profiles/r04_alloc_trace.txt).
+    if (G > 0) {
+        int nq_max = 0, nL_max = 1, lt_pad_max = 0;
+        for (const QueryGroup& grp : q->groups) { nq_max = std::max(nq_max, grp.nq); nL_max = std::max(nL_max, grp.max_nL); lt_pad_max = std::max(lt_pad_max, grp.dev.lt_pad); }
+        const size_t n_pairs = (size_t)nq_max * G;
+        const size_t lt_cap = std::max<size_t>((size_t)lt_pad_max, ((size_t)kTexMax + kTileRows - 1) / kTileRows * kTileRows);
+        if (n_pairs > 0) {
+            HIPCHK(ctx, ctx->rm_val.ensure(n_pairs * lt_cap * 4));
+            HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * lt_cap * 4));
+            HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
+            HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
+            HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
+            HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
+            {   // the generic candidate kernel's scratch (sized as in the loop below, for the longest latent minutiae template of the search)
+                const size_t per_wg = 2 * (((size_t)nL_max * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+                int n_wg = 1024;
+                while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
+                HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
+            }
+            if (ctx->adc_variant == 9) {
+                HIPCHK(ctx, ctx->rm_cv.ensure(n_pairs * lt_cap * 4)); HIPCHK(ctx, ctx->rm_n.ensure(n_pairs * 4));
+                const size_t R_cap = ((size_t)nq_max * kTexMax + 31) / 32 * 32;
+                HIPCHK(ctx, ctx->mf_bfrag.ensure(R_cap / 32 * 6 * 64 * 16));
+                HIPCHK(ctx, ctx->mf_rowk.ensure(R_cap * 16));
+                HIPCHK(ctx, ctx->mf_rec.ensure((size_t)G * R_cap * kMfRecBytesPerRow));
+                if (!ctx->mf_gal_built) {                                  // first search: the bound pass's copy of the gallery codes (adc_stage_mfma fills it)
+                    const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
+                    HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
+                    HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
+                    HIPCHK(ctx, ctx->g_tile_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
+                }
+            }
+        }
+    }
     int q0 = 0;
     size_t gi = 0;
     for (QueryGroup& grp : q->groups) {
@@ -840,9 +1051,10 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
-            HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
-            HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16)));
-            if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * d.lt_pad * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
+            const size_t lt_cap = std::max<size_t>((size_t)d.lt_pad, ((size_t)kTexMax + kTileRows - 1) / kTileRows * kTileRows);    // worst case, as budgeted: no re-allocation when a later group's longest latent is longer (adc_stage_mfma)
+            HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
+            HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
+            if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
             HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
             // minutiae scratch per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs the fast kernel cannot take use it)
             size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;

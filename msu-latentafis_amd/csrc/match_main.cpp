@@ -78,12 +78,25 @@ struct Latent {
 // latents = reading + parsing the latent files, search = afis_search (+ afis_correspondences), exchange = the multi-rank exchange step, write = the CSV files.
 struct StageClock {
     double scan = 0, load = 0, commit = 0, latents = 0, search = 0, exchange = 0, write = 0;
+    double device = 0, dev_bound = 0, dev_minu = 0;     // of `search`: the device's own clock over the searches' launch groups (afis_timing.total_ms), its bound pass and its minutiae stage
+    void add_device(const afis_ctx* ctx)
+    {
+        if (!getenv("AFIS_MATCH_TIMING")) return;
+        afis_timing t; memset(&t, 0, sizeof(t));
+        if (afis_get_timing2(ctx, &t, sizeof(t)) == AFIS_OK) {
+            device += t.total_ms; dev_bound += t.adc_bound_ms; dev_minu += t.minu_ms;
+            if (getenv("AFIS_MATCH_TIMING")[0] == '2')
+                fprintf(stderr, "match: search call on the device's clock (ms): total %.1f  bound %.1f  refine %.1f  texture_lists %.1f  candidates %.1f  minutiae_lists %.1f  (minutiae stage %.1f)\n",
+                        t.total_ms, t.adc_bound_ms, t.adc_refine_ms, t.tex_tail_ms, t.cands_ms, t.minu_graph_ms, t.minu_ms);
+        }
+    }
     static double now() { return std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now().time_since_epoch()).count(); }
     void report(int rank, double total) const
     {
         if (!getenv("AFIS_MATCH_TIMING")) return;
         fprintf(stderr, "match[rank %d] timing (ms): scan %.1f  load %.1f  commit %.1f  latents %.1f  search %.1f  exchange %.1f  write %.1f  total %.1f\n",
                 rank, scan, load, commit, latents, search, exchange, write, total);
+        fprintf(stderr, "match[rank %d] of search, on the device's clock (ms): groups %.1f  bound_pass %.1f  minutiae_stage %.1f\n", rank, device, dev_bound, dev_minu);
     }
 };
 StageClock g_clock;
@@ -114,22 +127,33 @@ int load_gallery(afis_ctx* ctx, const std::string& g, const std::vector<fs::path
     } else {
         // The reference re-reads every rolled file for every pair (matcher.cpp:173, :278); here each file is read and parsed ONCE, in slices of 8192 files:
         // the reads are spread over the host's threads, the parsing is afis_gallery_add_dat_batch's (also threaded), the order is the listing's.
+        // While one slice is parsed and appended, the next one is read.
         const int64_t slice = 8192;
         const unsigned n_thr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        std::vector<std::vector<uint8_t>> bufs;
-        std::vector<const void*> ptrs; std::vector<size_t> lens; std::vector<int> rcs;
-        for (int64_t s0 = lo; s0 < hi; s0 += slice) {
+        typedef std::vector<std::vector<uint8_t>> Bufs;
+        Bufs cur, nxt;
+        auto read_slice = [&](int64_t s0, Bufs& bufs) {
             const int64_t n = std::min(slice, hi - s0);
             bufs.assign((size_t)n, {});
             std::vector<std::thread> th;
             for (unsigned t = 0; t < n_thr; ++t)
                 th.emplace_back([&, t]() { for (int64_t i = t; i < n; i += n_thr) read_file(files[(size_t)(s0 + i)].string(), bufs[(size_t)i]); });
             for (std::thread& x : th) x.join();
+        };
+        std::vector<const void*> ptrs; std::vector<size_t> lens; std::vector<int> rcs;
+        if (lo < hi) read_slice(lo, cur);
+        for (int64_t s0 = lo; s0 < hi; s0 += slice) {
+            const int64_t n = std::min(slice, hi - s0);
+            struct Joined { std::thread t; ~Joined() { if (t.joinable()) t.join(); } } ahead;     // joined on every way out of the iteration
+            if (s0 + slice < hi) ahead.t = std::thread(read_slice, s0 + slice, std::ref(nxt));
             ptrs.resize((size_t)n); lens.resize((size_t)n); rcs.assign((size_t)n, 0);
-            for (int64_t i = 0; i < n; ++i) { ptrs[(size_t)i] = bufs[(size_t)i].data(); lens[(size_t)i] = bufs[(size_t)i].size(); }
+            for (int64_t i = 0; i < n; ++i) { ptrs[(size_t)i] = cur[(size_t)i].data(); lens[(size_t)i] = cur[(size_t)i].size(); }
             CHECK(ctx, afis_gallery_add_dat_batch(ctx, ptrs.data(), lens.data(), n, rcs.data()));
+            if (s0 == lo) CHECK(ctx, afis_gallery_reserve(ctx, hi - lo));          // the first slice says how large a template is: room for the rest, once
             for (int64_t i = 0; i < n; ++i)
                 if (rcs[(size_t)i] == 8) fprintf(stderr, "warning: %s: descriptor length outside 1..192, template discarded (scores -1)\n", files[(size_t)(s0 + i)].string().c_str());
+            if (ahead.t.joinable()) ahead.t.join();
+            cur.swap(nxt);
         }
     }
     if (!pack_to.empty()) {
@@ -379,11 +403,11 @@ int main(int argc, char** argv)
             t_s = StageClock::now();
             if (!job.multi) {
                 if ((ret = api(afis_search(ctx, views.data(), (int)nb, scores.data(), nullptr, status.data(), 0, nullptr, nullptr), "afis_search")) != 0) return finish(ret);
-                g_clock.search += StageClock::now() - t_s;
+                g_clock.search += StageClock::now() - t_s; g_clock.add_device(ctx);
             } else {                                                             // the exchange step: score columns of every shard
                 std::vector<float> part(nb * std::max<size_t>(Gl, 1)), block(nb * std::max<size_t>(Gm, 1), -1.0f), all((size_t)job.w.world * block.size());
                 if ((ret = job.agree(api(afis_search(ctx, views.data(), (int)nb, part.data(), nullptr, status.data(), 0, nullptr, nullptr), "afis_search"))) != 0) return finish(ret);
-                g_clock.search += StageClock::now() - t_s;
+                g_clock.search += StageClock::now() - t_s; g_clock.add_device(ctx);
                 t_s = StageClock::now();
                 for (size_t i = 0; i < nb; ++i) memcpy(&block[i * Gm], &part[i * Gl], Gl * sizeof(float));
                 if (!xchg(block.data(), all.data(), block.size() * sizeof(float))) return finish(2);

@@ -292,6 +292,26 @@ bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std:
     return true;
 }
 
+GalleryMapping::~GalleryMapping() { if (base_) munmap(base_, len_); if (fd_ >= 0) ::close(fd_); }
+
+std::unique_ptr<GalleryMapping> map_gallery_container(const std::string& path, std::string& err)
+{
+    Mapped m; GalHeader h; size_t sizes[kGalSections];
+    if (!m.open_file(path, err) || !check_header(m, path, h, sizes, err)) return nullptr;
+    const int64_t* mo = (const int64_t*)(m.p + h.off[0]); const int64_t* to = (const int64_t*)(m.p + h.off[1]);
+    if (mo[0] != 0 || to[0] != 0) { err = path + ": corrupt offsets"; return nullptr; }
+    for (int64_t i = 0; i < h.G; ++i)
+        if (mo[i + 1] < mo[i] || to[i + 1] < to[i] || mo[i + 1] > h.n_minu || to[i + 1] > h.n_tex) { err = path + ": corrupt offsets"; return nullptr; }
+    std::unique_ptr<GalleryMapping> g(new GalleryMapping);
+    g->G = h.G; g->n_minu = h.n_minu; g->n_tex = h.n_tex; g->path = path;
+    g->minu_off = mo; g->tex_off = to; g->empty = m.p + h.off[2];
+    g->mx = (const int16_t*)(m.p + h.off[3]); g->my = (const int16_t*)(m.p + h.off[4]); g->mori = (const float*)(m.p + h.off[5]); g->mdes = (const float*)(m.p + h.off[6]);
+    g->tx = (const int16_t*)(m.p + h.off[7]); g->ty = (const int16_t*)(m.p + h.off[8]); g->tori = (const float*)(m.p + h.off[9]); g->tcodes = m.p + h.off[10];
+    g->base_ = (void*)m.p; g->len_ = m.len; g->fd_ = m.fd;
+    m.p = nullptr; m.fd = -1;                                              // the mapping now belongs to *g
+    return g;
+}
+
 bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
                             std::vector<int32_t>* tex_counts, std::string& err, bool load_data)
 {

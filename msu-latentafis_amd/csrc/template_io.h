@@ -75,6 +75,22 @@ bool write_gallery_container(const std::string& path, const HostGallery& g, cons
 bool gallery_container_info(const std::string& path, GalleryFileInfo& info, std::string& err);
 // appends templates [first, first+count) (count < 0: to the end) to `out`; names / tex_counts (texture points of EVERY template in
 // the file, for balanced sharding) are optional
+// A validated container read IN PLACE (mmap): what afis_gallery_load keeps until the commit, which uploads the shard's arrays straight from the
+// mapping instead of copying them into a HostGallery first.  Pointers are to the whole file's arrays; offsets are the file's (not rebased).
+struct GalleryMapping {
+    int64_t G = 0, n_minu = 0, n_tex = 0;
+    const int64_t* minu_off = nullptr; const int64_t* tex_off = nullptr; const uint8_t* empty = nullptr;
+    const int16_t *mx = nullptr, *my = nullptr, *tx = nullptr, *ty = nullptr;
+    const float *mori = nullptr, *mdes = nullptr, *tori = nullptr;
+    const uint8_t* tcodes = nullptr;
+    std::string path;
+    GalleryMapping() = default;
+    GalleryMapping(const GalleryMapping&) = delete;
+    GalleryMapping& operator=(const GalleryMapping&) = delete;
+    ~GalleryMapping();
+    void* base_ = nullptr; size_t len_ = 0; int fd_ = -1;
+};
+std::unique_ptr<GalleryMapping> map_gallery_container(const std::string& path, std::string& err);   // header, section sizes and offsets checked; null on error
 bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
                             std::vector<int32_t>* tex_counts, std::string& err, bool load_data = true);   // load_data false: names / counts only, the arrays are not copied
 

@@ -44,7 +44,7 @@ class Timing(C.Structure):
                 ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("reserved_", C.c_int32)]
 
 
-EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch",
+EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch", "afis_gallery_reserve",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
            "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option", "afis_get_option"]
@@ -63,6 +63,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_last_error.argtypes = [vp]; lib.afis_last_error.restype = C.c_char_p
     lib.afis_gallery_add.argtypes = [vp, C.POINTER(TemplateView), C.c_int]
     lib.afis_gallery_add_dat.argtypes = [vp, C.c_char_p, C.c_size_t, i32p]
+    lib.afis_gallery_reserve.argtypes = [vp, C.c_int64]
     if hasattr(lib, "afis_gallery_add_dat_batch"):
         lib.afis_gallery_add_dat_batch.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int64, i32p]
     lib.afis_gallery_add_packed.argtypes = [vp, C.c_int64, i64p, C.POINTER(C.c_int16), C.POINTER(C.c_int16), fp, fp,
@@ -226,6 +227,10 @@ class Matcher:
         if self.lib.afis_gallery_file_names(path.encode(), first, count, buf, need.value, C.byref(need)) != 0:
             raise AfisError(self.lib.afis_last_error(None).decode())
         return [b.decode() for b in buf.raw[:need.value].split(b"\0")[:-1]] if need.value else []
+
+    def gallery_reserve(self, n_templates: int):
+        """Hint: the staged gallery will grow to about n_templates templates (host arrays reserve room once)."""
+        self._chk(self.lib.afis_gallery_reserve(self.ctx, n_templates))
 
     def gallery_commit(self, index_base: int = 0):
         self._chk(self.lib.afis_gallery_commit(self.ctx, index_base))

@@ -186,8 +186,10 @@ def test_gallery_container_equals_directory(codebook_bytes, cb, small, tmp_path)
         p = tmp_path / "gal" / f"R{j:03d}.dat"; p.write_bytes(T.write_rolled(g)); files.append(str(p))
     p = tmp_path / "gal" / "R_empty.dat"; p.write_bytes(b""); files.append(str(p))
     m = M.Matcher(codebook_bytes)
-    for f in files:
+    m.gallery_reserve(len(files))                                   # a hint; changes nothing that can be observed
+    for i, f in enumerate(files):
         m.gallery_add_dat(open(f, "rb").read())
+        if i == 2: m.gallery_reserve(len(files))
     box = str(tmp_path / "g.afisgal")
     m.gallery_save(box, files)
     m.gallery_commit(0)
@@ -207,6 +209,24 @@ def test_gallery_container_equals_directory(codebook_bytes, cb, small, tmp_path)
     assert np.array_equal(np.concatenate([p["scores"] for p in parts], axis=1), want["scores"])
     with pytest.raises(M.AfisError):
         m1.gallery_load(box)                                        # committed
+    # a load into an empty staging area only MAPS the file (the commit uploads from the mapping); anything staged after it first copies the mapped range
+    # into host arrays.  Both routes, and two loads in a row, give the gallery the files give.
+    m3 = M.Matcher(codebook_bytes); m3.gallery_load(box, 0, 5)
+    assert m3.gallery_size == 5
+    m3.gallery_load(box, 5, 4)
+    for f in files[9:]:
+        m3.gallery_add_dat(open(f, "rb").read())
+    assert m3.gallery_size == 13
+    box3 = str(tmp_path / "again.afisgal"); m3.gallery_save(box3, files)
+    assert open(box3, "rb").read() == open(box, "rb").read()
+    m3.gallery_commit(0)
+    got = m3.search(lats[:2], k=5)
+    assert np.array_equal(got["scores"], want["scores"]) and np.array_equal(got["topk_idx"], want["topk_idx"])
+    m3.close()
+    m4 = M.Matcher(codebook_bytes); m4.gallery_load(box, 12, 1); assert m4.gallery_size == 1; m4.gallery_commit(12)      # a shard of one empty template, straight from the mapping
+    got = m4.search(lats[:2], k=1)
+    assert np.array_equal(got["scores"], want["scores"][:, 12:13]); m4.close()
+    m4 = M.Matcher(codebook_bytes); m4.gallery_load(box, 3, 0); assert m4.gallery_size == 0; m4.gallery_commit(3); m4.close()   # an empty shard
     m2 = M.Matcher(codebook_bytes)
     with pytest.raises(M.AfisError):
         m2.gallery_load(box, 10, 9)                                 # range outside the file

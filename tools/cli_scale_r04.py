@@ -50,9 +50,14 @@ def run(tag, args):
     if line:
         w = line[-1].split("timing (ms):")[1].split()
         stages = {w[i]: float(w[i + 1]) for i in range(0, len(w), 2)}
+    dline = [l for l in r.stderr.splitlines() if "on the device's clock (ms):" in l]
+    if dline:
+        w = dline[-1].split("(ms):")[1].split()
+        stages.update({"device_" + w[i]: float(w[i + 1]) for i in range(0, len(w), 2)})
     files = os.listdir(out)
     total = [l for l in open(os.path.join(work, tag + ".stdout")) if l.startswith("Total matching duration")]
     return {"rc": r.returncode, "wall_s": round(wall, 2), "stages_ms": stages, "reported_total_ms": float(total[-1].split(":")[1]) if total else None,
+            "commit_laps": [l.strip() for l in r.stderr.splitlines() if l.startswith("commit:")],          # only with AFIS_COMMIT_TIMING=1 in the environment
             "files_written": len(files), "bytes_written": sum(os.path.getsize(os.path.join(out, f)) for f in files), "stderr_tail": r.stderr[-300:] if r.returncode else ""}, out
 
 runs = {}
@@ -77,5 +82,5 @@ cpu = bench.cpu_baseline(cbb, lats, gal, 0, pairs_per_thread=400)
 doc["cpu_reference_faithful_pairs_per_s_8_threads"] = round(cpu["pairs_per_s_reference_faithful"], 1)
 doc["cpu_compute_only_best_pairs_per_s"] = cpu["pairs_per_s"]; doc["cpu_threads_best"] = cpu["threads"]; doc["cpu_limits"] = cpu["limits"]
 doc["cpu_reference_faithful_extrapolated_s_for_this_job"] = round(Q * G / cpu["pairs_per_s_reference_faithful"], 0)
-shutil.rmtree(work, ignore_errors=True)
+if not os.environ.get("AFIS_CLI_KEEP"): shutil.rmtree(work, ignore_errors=True)       # AFIS_CLI_KEEP=1: leave the gallery for tools/ldir_repeat.sh
 print(json.dumps(doc, indent=1))
