@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -23,7 +24,8 @@ int main(int argc, char** argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: tio_check latent|rolled|codebook|roundtrip-latent|roundtrip-rolled <file>\n"
                                     "       tio_check gallery-pack <out container> <rolled .dat>...\n"
-                                    "       tio_check gallery-dump <container> [first count]\n"); return 2; }
+                                    "       tio_check gallery-dump <container> [first count]\n"
+                                    "       tio_check gallery-map <container> [first count]\n"); return 2; }
     const std::string mode = argv[1];
     if (mode == "gallery-pack") {                        // the host half of `match -pack`: rolled .dat files -> one container
         HostGallery g; std::vector<std::string> names; std::vector<uint8_t> fb;
@@ -54,6 +56,26 @@ int main(int argc, char** argv)
         printf("names hash=%016llx\n", h);
         h = fnv(tc.data(), tc.size() * 4);
         printf("tex_counts hash=%016llx\n", h);
+        return 0;
+    }
+    if (mode == "gallery-map") {                         // the same hashes as gallery-dump, read IN PLACE through map_gallery_container (what afis_gallery_load keeps and afis_gallery_commit uploads from)
+        long long first = argc > 4 ? atoll(argv[3]) : 0, count = argc > 4 ? atoll(argv[4]) : -1;
+        std::string err;
+        std::unique_ptr<GalleryMapping> gm = map_gallery_container(argv[2], err);
+        if (!gm) { printf("error=%s\n", err.c_str()); return 1; }
+        if (count < 0) count = gm->G - first;
+        if (first < 0 || count < 0 || first + count > gm->G) { printf("error=range outside the container\n"); return 1; }
+        const int64_t m0 = gm->minu_off[first], m1 = gm->minu_off[first + count], t0 = gm->tex_off[first], t1 = gm->tex_off[first + count];
+        std::vector<int64_t> mo, to;
+        for (long long i = first; i <= first + count; ++i) { mo.push_back(gm->minu_off[i] - m0); to.push_back(gm->tex_off[i] - t0); }
+        printf("G=%lld n_minu=%lld n_tex=%lld range=%lld\n", (long long)gm->G, (long long)gm->n_minu, (long long)gm->n_tex, count);
+        unsigned long long h = fnv(mo.data(), mo.size() * 8); h = fnv(to.data(), to.size() * 8, h); h = fnv(gm->empty + first, (size_t)count, h);
+        printf("offsets hash=%016llx\n", h);
+        const size_t nm = (size_t)(m1 - m0), nt = (size_t)(t1 - t0);
+        h = fnv(gm->mx + m0, nm * 2); h = fnv(gm->my + m0, nm * 2, h); h = fnv(gm->mori + m0, nm * 4, h); h = fnv(gm->mdes + (size_t)m0 * 96, nm * 96 * 4, h);
+        printf("minutiae hash=%016llx\n", h);
+        h = fnv(gm->tx + t0, nt * 2); h = fnv(gm->ty + t0, nt * 2, h); h = fnv(gm->tori + t0, nt * 4, h); h = fnv(gm->tcodes + (size_t)t0 * 16, nt * 16, h);
+        printf("texture hash=%016llx\n", h);
         return 0;
     }
     std::vector<uint8_t> b;

@@ -250,11 +250,19 @@ def test_gallery_container_cpp_and_python_agree(cb, tio, tmp_path):
     sub, sub_names, _ = CT.read_container(str(py), first, count)
     assert np.array_equal(sub.minu_des, _pack(ts[first:first + count]).minu_des)
     assert _dump_hashes(out) == _want_hashes(sub, sub_names, tex_counts)
+    # the container read in place (what afis_gallery_load keeps mapped and afis_gallery_commit uploads from): the same arrays, whole and as a shard
+    for args, gg in (([], g), ([str(first), str(count)], sub)):
+        out = subprocess.run([tio, "gallery-map", str(py)] + args, capture_output=True, text=True, check=True).stdout
+        want = _want_hashes(gg, [], [])
+        assert _dump_hashes(out) == {k: want[k] for k in ("offsets", "minutiae", "texture")}, out
+    assert "error=" in subprocess.run([tio, "gallery-map", str(py), "5", "9"], capture_output=True, text=True).stdout
     # damaged files are rejected, not read past their end
     bad = tmp_path / "bad.afisgal"; bad.write_bytes(py.read_bytes()[:-100])
     assert "error=" in subprocess.run([tio, "gallery-dump", str(bad)], capture_output=True, text=True).stdout
+    assert "error=" in subprocess.run([tio, "gallery-map", str(bad)], capture_output=True, text=True).stdout
     bad.write_bytes(b"NOTAGAL1" + py.read_bytes()[8:])
     assert "error=" in subprocess.run([tio, "gallery-dump", str(bad)], capture_output=True, text=True).stdout
+    assert "error=" in subprocess.run([tio, "gallery-map", str(bad)], capture_output=True, text=True).stdout
     out = subprocess.run([tio, "gallery-dump", str(py), "5", "9"], capture_output=True, text=True).stdout
     assert "error=" in out and "range" in out
     with pytest.raises(ValueError):
@@ -299,8 +307,9 @@ def test_readers_survive_damaged_files(cb, tio, tmp_path):
             for pos in rng.integers(8, 160, 2):
                 b[pos] = int(rng.integers(0, 256))
         p = tmp_path / f"c{i}.afisgal"; p.write_bytes(bytes(b))
-        r = subprocess.run([tio, "gallery-dump", str(p)], capture_output=True, text=True, timeout=20)
-        assert r.returncode in (0, 1) and (r.stdout.startswith("G=") or r.stdout.startswith("error=")), (i, r.returncode, r.stdout[:100], r.stderr[:200])
+        for mode in ("gallery-dump", "gallery-map"):                  # copied into host arrays / read in place: both reject or read, neither crashes
+            r = subprocess.run([tio, mode, str(p)], capture_output=True, text=True, timeout=20)
+            assert r.returncode in (0, 1) and (r.stdout.startswith("G=") or r.stdout.startswith("error=")), (mode, i, r.returncode, r.stdout[:100], r.stderr[:200])
 
 
 def test_device_atan2f_restatement_equals_libm_on_the_host(tmp_path):
