@@ -175,7 +175,7 @@ for s3 in proj["shards"]:
     L.append(f"| {s3['n_gpus']} | {s3['shard_templates']} | {s3['ms_per_step']:.1f} | {s3['projected_queries_per_s']:.1f} | {s3['projected_efficiency_vs_linear']:.3f} |")
 if os.path.exists("profiles/r04_cli_scale.json"):
     c = json.load(open("profiles/r04_cli_scale.json"))
-    L.append(f"\n## `match` end to end, {c['Q']} latents x {c['G']} templates (tools/cli_scale_r04.py; wall seconds, stages from the process's own clock)\n")
+    L.append(f"\n## `match` end to end, {c['Q']} latents x {c['G']} templates (tools/cli_scale_r04.py; wall seconds, stages from the process's own clock; measured at the end of the round, after the host-side staging / allocation work — the kernels are the bundle's)\n")
     L.append("| run | wall s | scan | load + parse | commit + upload | latents | search | write |\n|---|---|---|---|---|---|---|---|")
     for name, rr in c["runs"].items():
         sm = rr["stages_ms"]
