@@ -636,6 +636,8 @@ static hipError_t upload_bulk(PinnedPipe& pp, DevBuf& b, const void* src, size_t
     return hipSuccess;
 }
 
+static int ensure_mf_gallery(afis_ctx* ctx, hipStream_t s);
+
 int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
 {
     if (!ctx) return AFIS_EINVAL;
@@ -733,6 +735,12 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     ctx->total_tex_points = (int64_t)NT;
     ctx->index_base = index_base;
     ctx->committed = true;
+    if (ctx->adc_variant == 9 && G > 0) {                                    // the default path's derived streams belong to the resident gallery: built here, not by the first search
+        int rcg = ensure_mf_gallery(ctx, ctx->stream);
+        if (rcg != AFIS_OK) { ctx->committed = false; return rcg; }
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        lap("bound pass's code stream");
+    }
     // the host staging copy is no longer needed
     std::vector<uint8_t> e(s_empty, s_empty + G);
     if (hg.mdes.capacity() > ((size_t)16 << 20)) {                           // a large staging copy is released by a thread of its own
@@ -928,6 +936,28 @@ static int adc_stage_q(afis_ctx* ctx, QueryGroup& grp, int chunk, bool exact, hi
     return AFIS_OK;
 }
 
+// adc_variant 9's derived data: the codebook in fp16 with its squared norms (once per context) and the gallery's PQ codes as tiles of 32 points with their point terms
+// (once per committed gallery).  Built by afis_gallery_commit when variant 9 is selected then — a resident gallery includes them — and on first use otherwise.
+static int ensure_mf_gallery(afis_ctx* ctx, hipStream_t s)
+{
+    const GalleryDev& g = ctx->gal;
+    if (!ctx->mf_cb_built) {
+        HIPCHK(ctx, ctx->mf_cw16.ensure((size_t)kM * kK * 16));
+        HIPCHK(ctx, ctx->mf_cwn.ensure((size_t)kM * kK * 4));
+        HIPCHK(ctx, launch_mf_codebook(ctx->codewords.as<float>(), ctx->mf_cw16.p, ctx->mf_cwn.as<float>(), s));
+        ctx->mf_cb_built = true;
+    }
+    if (!ctx->mf_gal_built && g.G > 0) {
+        const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
+        HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
+        HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
+        HIPCHK(ctx, ctx->g_tile_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
+        HIPCHK(ctx, launch_mf_tiles(g, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, s));
+        ctx->mf_gal_built = true;
+    }
+    return AFIS_OK;
+}
+
 // S4-S6 (+ the row selection of S7) of adc_variant 9 for one query group: row constants, matrix-core bound pass, selection by bounds and exact
 // recomputation.  all_rows: every row is evaluated exactly (parity taps); otherwise rows that cannot reach the pair's top 200 get -inf.
 // sb: the stream of the row constants and the bound pass (the context's stream, or the CU-masked one); refine_now false: the caller launches the selection / recomputation kernel itself (adc_refine_mfma)
@@ -938,20 +968,7 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     hipStream_t s = sb ? sb : ctx->stream;
     const GalleryDev& g = ctx->gal;
     if (grp.n_lt_rows <= 0 || g.G <= 0) { if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s)); if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s)); return AFIS_OK; }
-    if (!ctx->mf_cb_built) {
-        HIPCHK(ctx, ctx->mf_cw16.ensure((size_t)kM * kK * 16));
-        HIPCHK(ctx, ctx->mf_cwn.ensure((size_t)kM * kK * 4));
-        HIPCHK(ctx, launch_mf_codebook(ctx->codewords.as<float>(), ctx->mf_cw16.p, ctx->mf_cwn.as<float>(), s));
-        ctx->mf_cb_built = true;
-    }
-    if (!ctx->mf_gal_built) {
-        const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
-        HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
-        HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
-        HIPCHK(ctx, ctx->g_tile_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
-        HIPCHK(ctx, launch_mf_tiles(g, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cwn.as<float>(), ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, s));
-        ctx->mf_gal_built = true;
-    }
+    { int rcg = ensure_mf_gallery(ctx, s); if (rcg != AFIS_OK) return rcg; }
     const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
     // The per-row buffers are sized for the group's WORST case (every latent with kTexMax rows), as afis_search_resident has already done before queuing anything: these
     // calls find them large enough (a hipMalloc behind queued work was seen to take 0.5-0.8 s; see there).  Callers outside a search (the parity taps) allocate here.
