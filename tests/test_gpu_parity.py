@@ -1215,3 +1215,43 @@ def test_minutiae_coordinates_beyond_the_packed_path(codebook_bytes, cb, oracle)
         if ci == 0:
             assert want_sc[0] > 10
         m.close()
+
+
+def test_a_search_allocates_before_it_queues_and_never_again(codebook_bytes, tmp_path):
+    """The allocation rule: the buffers of a search's launch groups are sized for the largest group's worst case (every latent with 1000
+    texture rows) and allocated before anything is queued — a hipMalloc behind queued work was seen to take 0.5-0.8 s (profiles/r04_alloc_trace.txt).
+    Observable through AFIS_ALLOC_TRACE=1: searching 8 short latents and then 8 of the longest latents against the same gallery (re)allocates nothing of
+    64 MB or more during the second search, in either schedule; fewer latents per search never allocate; more latents per search do (once)."""
+    import subprocess, sys, textwrap
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import importlib, sys
+        sys.path.insert(0, {root!r})
+        import numpy as np
+        T = importlib.import_module("msu-latentafis_amd.host.templates"); S = importlib.import_module("msu-latentafis_amd.host.synth"); M = importlib.import_module("msu-latentafis_amd.host.matcher")
+        cbb = open({str(cbp)!r}, "rb").read(); cb = T.Codebook.from_bytes(cbb)
+        rng = np.random.default_rng(5)
+        short = [S.make_latent(rng, n_tex_lo=400, n_tex_hi=420) for _ in range(8)]
+        long_ = [S.make_latent(rng, n_tex_lo=990, n_tex_hi=1000) for _ in range(8)]
+        gal = S.make_packed_gallery(5, 9000, cb)
+        m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0)
+        def mark(s): sys.stderr.write("mark: " + s + "\\n"); sys.stderr.flush()
+        mark("short"); a = m.search(short, k=4)
+        mark("long"); b = m.search(long_, k=4)
+        mark("fewer"); m.search(long_[:3], k=4)
+        m.set_option("bound_cus", 0)
+        mark("back to back"); c = m.search(long_, k=4)
+        assert np.array_equal(b["scores"], c["scores"])
+        mark("more"); m.search(short + long_, k=4)
+        mark("end"); m.close()
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, AFIS_ALLOC_TRACE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    allocs, where = {}, None
+    for line in r.stderr.splitlines():
+        if line.startswith("mark: "): where = line[6:]; allocs[where] = []
+        elif line.startswith("alloc: ") and where is not None: allocs[where].append(line)
+    assert len(allocs["short"]) >= 4, allocs                       # the first search of a context allocates (row maxima x 3, records, candidate lists ...)
+    assert allocs["long"] == [] and allocs["fewer"] == [] and allocs["back to back"] == [], allocs
+    assert len(allocs["more"]) >= 4, allocs                        # 16 latents per search: larger buffers, once
