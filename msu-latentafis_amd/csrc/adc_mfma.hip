@@ -77,6 +77,24 @@ template <int TILES> struct __align__(16) M12Stage {
     int2 meta[TILES];
 };
 
+// The records are written once and read ~100 ms later by the recomputation kernel: 9 GB per launch that no cache can hold.  AFIS_MF_NT_STORE (experiment) marks the stores
+// non-temporal so that they do not displace what the kernels running beside the pass keep in the L2 (the candidate kernel's latent fragments).
+// Measured (tools/lib_ab.py, 20 latents x 100 000, default schedule): 426.6 against 427.3 ms per group, candidates 173.8 against 174.1 — nothing; the candidate kernel beside
+// the pass takes 2.05 x its time alone on the chip, i.e. what half the CUs cost.  Not shipped.
+#ifndef AFIS_MF_NT_STORE
+#define AFIS_MF_NT_STORE 0
+#endif
+__device__ __forceinline__ void store_rec(uint2* p, uint32_t a, uint32_t b)
+{
+#if AFIS_MF_NT_STORE
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v; v.x = a; v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+#else
+    *p = make_uint2(a, b);
+#endif
+}
+
 template <int NB>
 __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
                                                             const int2* __restrict__ tile_meta, const int32_t* __restrict__ tile0, const uint4* __restrict__ cw16,
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
             const uint32_t D = (dp & 0x1fffffu) | ((sw ? 1u : 0u) << 21) | ((in_o ? 1u : 0u) << 22) | (cell << 23) | (((in_o & o_more) ? 1u : 0u) << 20);
             // padding rows of a partial row block store too (their records are never read: R_pad covers them); only a row block beyond the last is skipped
             const int rbm = rb0 + p0 + (paired ? h : 0);
-            if (rbm < n_rb && (paired || h == 0)) rec[(size_t)tmpl * R_pad + (size_t)rbm * 32 + col] = make_uint2(f2u(V), D);
+            if (rbm < n_rb && (paired || h == 0)) store_rec(&rec[(size_t)tmpl * R_pad + (size_t)rbm * 32 + col], f2u(V), D);
         }
         reset();
     };
