@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--gallery", type=int, default=100000)
     ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--workload", default="headline", choices=sorted(S.WORKLOADS), help="headline = BASELINE.json's shapes (rolled minutiae clip(N(80, 15), 20, 200), latent U{20..60}); "
+                    "wide = the shapes the reference's reader also accepts but the synthetic envelope never produced (rolled clip(N(130, 40), 20, 400), latent U{20..150}): not the headline")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--k", type=int, default=24)
     ap.add_argument("--variant", type=int, default=-1)
@@ -242,11 +244,12 @@ def main():
 
     # ---- synthetic workload (seeded; every rank generates only its own shard) -------------------------------------
     t_gen = time.perf_counter()
-    nm_all, nt_all = S.gallery_counts(a.seed, G)
+    wl = S.WORKLOADS[a.workload]
+    nm_all, nt_all = S.gallery_counts(a.seed, G, **wl["gallery"])
     bounds = SH.shard_bounds(nt_all, world)                # balanced by rolled texture points, the cost driver
     lo, hi = bounds[rank]
-    lats = S.make_latents(a.seed, Q)
-    gal = S.make_packed_gallery(a.seed, G, cb, lo, hi)
+    lats = S.make_latents(a.seed, Q, **wl["latent"])
+    gal = S.make_packed_gallery(a.seed, G, cb, lo, hi, **wl["gallery"])
     planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
     t_gen = time.perf_counter() - t_gen
 
@@ -326,7 +329,7 @@ def main():
             r_ = m.search_resident(qh, k=a.k); t_ = m.timing()
             acc = t_ if acc is None else {k_: acc[k_] + v for k_, v in t_.items()}
         assert np.array_equal(r_["topk_idx"], np.asarray(idx)) or use_dist, "the schedule changed a rank list"
-        alone = {k_: (v / 2 if k_.endswith("_ms") else v) for k_, v in acc.items()}
+        alone = {k_: (v / 2 if (k_.endswith("_ms") or k_.endswith("_ghz")) else v) for k_, v in acc.items()}
         m.set_option("bound_cus", bound_cus)
 
     out = None
@@ -348,6 +351,9 @@ def main():
                 carried = json.load(open(cp))
             except Exception:
                 carried = None
+        clock = {"bound_pass_ghz": round(tm_acc.get("bound_clock_ghz", 0.0) / a.steps, 4), "candidate_kernel_ghz": round(tm_acc.get("cands_clock_ghz", 0.0) / a.steps, 4),
+                 "how": "in-kernel, this run: one lane of sampled workgroups (every 64th of the bound pass, the first 8 of the candidate kernel) reads s_memtime (shader cycles) and "
+                        "s_memrealtime (100 MHz) at its first and last instruction; clock = sum of cycle differences / sum of tick differences x 0.1 GHz, averaged over the timed steps"}
         if variant == 9:
             # k_adc_mfma: every (latent texture row, rolled texture point) cell is a 96-long fp16 dot product on the matrix cores: 192 flop
             rows_per_step = sum(min(L.tex[0].n, 1000) if L.tex else 0 for L in lats)
@@ -355,18 +361,26 @@ def main():
             bound_ms_avg = tm_acc["adc_bound_ms"] / launches
             tflops = alg_flops_launch / (bound_ms_avg * 1e-3) / 1e12 if bound_ms_avg > 0 else 0.0
             share = (bound_cus / 256.0) if bound_cus > 0 else 1.0                   # the kernel is confined to this share of the chip's CUs (the rest runs the minutiae stage beside it)
-            roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": round(MFMA_F16_PEAK_TFLOPS * share, 1),
-                        "unit": "TFLOP/s", "frac": round(tflops / (MFMA_F16_PEAK_TFLOPS * share), 5),
-                        "cus_used": bound_cus if bound_cus > 0 else 256, "chip_peak": MFMA_F16_PEAK_TFLOPS, "frac_of_chip_peak": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
+            alone_ms = (alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2)) if alone else None
+            alone_tf = (alg_flops_launch / (alone_ms * 1e-3) / 1e12) if alone else None
+            ck_b, ck_c = clock["bound_pass_ghz"], clock["candidate_kernel_ghz"]
+            if alone and alone.get("bound_clock_ghz", 0) > 0:
+                limiting = ("measured in this run: alone on the chip the bound pass holds %.2f GHz against %.2f GHz under the candidate kernel (ratio %.2f) — the chip lowers its clock under this kernel's matrix work; "
+                            "in the timed schedule (%s) it holds %.2f GHz. What the kernel's own loop can reach with tracking / decode compiled out is a row of profiles/r04_bound_pass_ablation.json (not re-measured here)"
+                            % (alone["bound_clock_ghz"], alone["cands_clock_ghz"], alone["bound_clock_ghz"] / max(1e-9, alone["cands_clock_ghz"]),
+                               ("confined to %d CUs" % bound_cus) if bound_cus > 0 else "all CUs", ck_b))
+            else:
+                limiting = "measured in this run: %.2f GHz under the bound pass, %.2f GHz under the candidate kernel" % (ck_b, ck_c)
+            roofline = {"bound": "mfma", "kernel": "k_adc_mfma (fp16 matrix-core bound pass over every cell; adc_variant 9)", "achieved": round(tflops, 2), "peak": MFMA_F16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 5),
+                        "frac_is": "achieved / the WHOLE chip's fp16 matrix peak (2.5 PFLOP/s), whatever share of the CUs the kernel was given: one series with rounds 1-3 (round 4's line divided by the peak of the CUs used; that figure is frac_of_cus_used now)",
+                        "cus_used": bound_cus if bound_cus > 0 else 256, "frac_of_cus_used": round(tflops / (MFMA_F16_PEAK_TFLOPS * share), 5),
+                        "measured_clock_ghz": clock,
                         "alone_on_the_chip": ({"what": "the same kernel in the same process with the kernels back to back on one stream (bound_cus 0), two steps outside the timed region: its roofline when it has all 256 CUs",
-                                               "avg_launch_ms": round(alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2), 3),
-                                               "achieved": round(alg_flops_launch / (alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2) * 1e-3) / 1e12, 2), "peak": MFMA_F16_PEAK_TFLOPS,
-                                               "frac": round(alg_flops_launch / (alone["adc_bound_ms"] / max(1, alone["adc_launches"] / 2) * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 5)} if alone else None),
-                        "peak_is": ("the fp16 matrix peak of the CUs the kernel runs on: it is confined to %d of the 256 CUs (hipExtStreamCreateWithCUMask) and the minutiae stage runs beside it on the others; "
-                                    "frac_of_chip_peak prices the same duration against the whole chip (with --bound-cus 0 the kernel has the chip to itself: frac 0.47)" % bound_cus) if bound_cus > 0 else
-                                   "the chip's fp16 matrix peak (the kernel has every CU)",
+                                               "avg_launch_ms": round(alone_ms, 3), "achieved": round(alone_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "frac": round(alone_tf / MFMA_F16_PEAK_TFLOPS, 5),
+                                               "measured_clock_ghz": {"bound_pass_ghz": round(alone.get("bound_clock_ghz", 0.0), 4), "candidate_kernel_ghz": round(alone.get("cands_clock_ghz", 0.0), 4)}} if alone else None),
                         "traffic": carried.get("traffic_bytes_per_launch") if carried else None,
-                        "traffic_source": ("profiles/r04_adc_counters.json (carried: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
+                        "traffic_source": ("profiles/r04_adc_counters.json (carried, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
                                            "MI355X_MICROARCH.md prescribes and profiles/r03_fetch_calibration.json confirms; collected with the kernels back to back, --bound-cus 0; PMC counters cannot be read inside this run)") if carried else None,
                         "stage_traffic": carried.get("stage_traffic") if carried else None,
                         "achieved_is": "ALGORITHMIC flops (latent texture rows of the launch x rolled texture points of the shard x 192) / average kernel duration; padding rows / points and the "
@@ -376,8 +390,8 @@ def main():
                         "hbm_view": {"what": "the same stage (bound pass + recomputation) priced as north_star prices it: 24 algorithmic bytes per rolled texture point per query / stage time", "alg_bytes_per_launch": alg_bytes_launch,
                                      "achieved_GBps": round(hbm_achieved, 2), "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_achieved / HBM_PEAK_GBS, 6)},
                         "unit_fractions_from_counters": carried.get("fractions") if carried else None,
-                        "limiting_resource": "power: the chip holds 1.88 GHz under this kernel (2.34-2.38 GHz under every other kernel of the step) with the matrix pipe 0.60 busy; with its tracking "
-                                             "and decode compiled out the kernel's own MFMA loop reaches 0.60 of the nominal peak (profiles/r04_bound_pass_ablation.json), see DESIGN section 4"}
+                        "unit_fractions_source": "profiles/r04_adc_counters.json (carried)" if carried else None,
+                        "limiting_resource": limiting}
         else:
             lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0
             quantised = variant == 8                                            # the 16-bit pass: 2 LDS bytes per look-up
@@ -395,7 +409,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch {Q} latents vs {G}-template synthetic rolled gallery "
-                                   f"({'BASELINE.json configs[2]' if (Q, G) == (100, 100000) else 'not the headline size'}); planted mates; top-{a.k} rank lists", "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
+                                   f"({'BASELINE.json configs[2]' if (Q, G, a.workload) == (100, 100000, 'headline') else 'NOT the headline: ' + ('workload wide — rolled minutiae clip(N(130, 40), 20, 400), latent minutiae U{20..150}, everything else as configs[2]' if a.workload == 'wide' else 'not the headline size')}); planted mates; top-{a.k} rank lists",
+                       "workload_name": a.workload, "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
@@ -403,10 +418,17 @@ def main():
                        "schedule": ("bound pass on %d CUs, minutiae stage (candidates + lists) beside it on the other %d, then recomputation + texture lists on the whole chip; stage times overlap: their sum exceeds ms_per_step" % (bound_cus, 256 - bound_cus))
                                    if bound_cus > 0 else "one stream, the kernels of a launch group back to back", "bound_pass_dtype": ("f16 operands, f32 accumulation on the matrix cores: used for BOUNDS only, every score is the reference's f32 arithmetic" if variant == 9 else
                                                                    "u16 fixed point in LDS: used for BOUNDS only" if variant == 8 else "none"), "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
-                       "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean())},
+                       "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean()),
+                       "mean_latent_minutiae_selected": float(np.mean([L.minu[i].n for L in lats for i in (26, 2, 11) if len(L.minu) > i]))},
             "roofline": dict(roofline, pipeline_achieved_GBps=round(pipeline_bytes / (ms_per_step * 1e-3) / 1e9, 3)),
             "stage_ms_per_step": {k_: round(tm_acc[k_] / a.steps, 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "cands_ms", "minu_graph_ms", "fuse_ms", "topk_ms", "total_ms")},
             "stage_ms_per_step_back_to_back": ({k_: round(alone[k_], 3) for k_ in ("lut_ms", "adc_ms", "adc_bound_ms", "adc_refine_ms", "tex_tail_ms", "minu_ms", "cands_ms", "minu_graph_ms", "fuse_ms", "topk_ms", "total_ms")} if alone else None),
+            "minutiae_candidate_tasks": {"per_step": int(tm_acc.get("minu_tasks", 0) // a.steps),
+                                         "fast_kernel_small_class": int(tm_acc.get("minu_tasks_small", 0) // a.steps), "fast_kernel_medium_class": int(tm_acc.get("minu_tasks_medium", 0) // a.steps),
+                                         "fast_kernel_large_class": int(tm_acc.get("minu_tasks_large", 0) // a.steps), "any_shape_fallback_kernel": int(tm_acc.get("minu_fallback_tasks", 0) // a.steps),
+                                         "fallback_share": round(tm_acc.get("minu_fallback_tasks", 0) / max(1, tm_acc.get("minu_tasks", 0)), 6),
+                                         "fast_kernel_limits": {k_: m.get_option(k_) for k_ in ("minu_fast_max_latent", "minu_fast_max_rolled", "minu_fast_max_cells")},
+                                         "how": "counted by the kernels of this run (afis_timing.minu_*): small = <= 64 x 128 minutiae (256-thread workgroups), medium = <= 16 384 similarities (512), large = <= 32 768 (1024)"},
             "refine_stats": m.refine_stats() if a.refine_stats else None,
             "per_rank_ms_per_step": {"search": {"min": round(float(pr_min[0]), 3), "max": round(float(pr_max[0]), 3)},
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},

@@ -99,7 +99,7 @@ template <int NB>
 __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
                                                             const int2* __restrict__ tile_meta, const int32_t* __restrict__ tile0, const uint4* __restrict__ cw16,
                                                             const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
-                                                            int n_rg, int chunk, uint2* __restrict__ rec)
+                                                            int n_rg, int chunk, uint2* __restrict__ rec, unsigned long long* __restrict__ diag)
 {
     constexpr int kWaves = kM12RowBlocks / NB, kThreads = 64 * kWaves, kStageTiles = kThreads / 128;
     static_assert(kWaves * NB == kM12RowBlocks && kStageTiles * 128 == kThreads, "row blocks per wave must divide 24, and the threads must decode whole tiles");
@@ -114,6 +114,11 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
     const int n_tiles = tile_hi - tile_lo;
     if (n_tiles <= 0) return;
     const int n_stages = (n_tiles + kStageTiles - 1) / kStageTiles;
+    // The clock the chip holds under THIS kernel (afis_timing.bound_clock_ghz): one lane of every 64th workgroup reads the shader-cycle counter (s_memtime) and the
+    // constant 100 MHz counter (s_memrealtime) when its workgroup starts and when it ends; the sums of the differences go to the launch group's diagnostics row.
+    const bool sampler = diag != nullptr && (blockIdx.x & 63) == 0 && tid == 0;
+    unsigned long long clk0 = 0, wall0 = 0;
+    if (sampler) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
     for (int i = tid; i < kM * kK; i += kThreads) s_cw[i] = cw16[i];
 
     const int h = lane >> 5, col = lane & 31;
@@ -284,6 +289,7 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
         __syncthreads();
 #endif
     }
+    if (sampler) { atomicAdd(&diag[kDiagBoundClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagBoundWall], (unsigned long long)wall_clock64() - wall0); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(512) void k_adc_mfma_pipe(GalleryDev g, const uint4
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------------
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
-                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec, hipStream_t stream)
+                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec, unsigned long long* diag, hipStream_t stream)
 {
     if (n_rb <= 0 || g.G <= 0) return hipSuccess;
     const int n_chunks = (g.G + chunk - 1) / chunk;
@@ -489,10 +495,10 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
     }
     if (blocks_per_wave == 3)
         hipLaunchKernelGGL(k_adc_mfma<3>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 3)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
-                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
+                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag);
     else
         hipLaunchKernelGGL(k_adc_mfma<2>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 2)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
-                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec);
+                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag);
     return hipGetLastError();
 }
 

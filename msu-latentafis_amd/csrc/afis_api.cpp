@@ -104,6 +104,8 @@ struct afis_ctx {
     int mf_blocks = 2;                   // row blocks per wave of the bound pass: 2 (12 waves per workgroup) or 3 (8 waves, a third less LDS traffic per MFMA)
     DevBuf lutq, lutq_min, lutq_rng, lutq_rowc, lut32;      // adc_variant 8: 16-row fixed-point tiles, per-(row, m) min / range, per-row (offset, step, margin), fp32 table
     DevBuf lut, rm_val, rm_arg, rm_cv, rm_n, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
+    DevBuf diag;                         // kDiagWords unsigned 64-bit counters per launch group of a search (afis_device.h): zeroed when the search starts, read back with its results
+    std::vector<unsigned long long> h_diag;
     std::vector<float> h_scores, h_parts;
     int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // adc_variant 8: consecutive chunks per tile on an XCD; 0 = 4 (the refine's fp32 table stays in L2)
@@ -317,7 +319,7 @@ void afis_destroy(afis_ctx* c)
     for (hipStream_t* ps : {&c->stream_lo, &c->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release(); c->rm_cv.release(); c->rm_n.release();
-    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
+    c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->diag.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
     c->mf_cw16.release(); c->mf_cwn.release(); c->mf_bfrag.release(); c->mf_rowk.release(); c->mf_rec.release(); c->mf_stats.release();
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -970,7 +972,7 @@ static int ensure_mf_gallery(afis_ctx* ctx, hipStream_t s)
 // recomputation.  all_rows: every row is evaluated exactly (parity taps); otherwise rows that cannot reach the pair's top 200 get -inf.
 // sb: the stream of the row constants and the bound pass (the context's stream, or the CU-masked one); refine_now false: the caller launches the selection / recomputation kernel itself (adc_refine_mfma)
 static int adc_refine_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, bool compact);
-static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr, bool compact = false, hipStream_t sb = nullptr, bool refine_now = true)
+static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t after_lut = nullptr, hipEvent_t after_bound = nullptr, bool compact = false, hipStream_t sb = nullptr, bool refine_now = true, unsigned long long* diag = nullptr)
 {
     const QueryDev& d = grp.dev;
     hipStream_t s = sb ? sb : ctx->stream;
@@ -994,7 +996,7 @@ static int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEven
     const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
     HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
-                                ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_blocks, ctx->mf_rec.p, s));
+                                ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_blocks, ctx->mf_rec.p, diag, s));
     if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s));
     return refine_now ? adc_refine_mfma(ctx, grp, all_rows, compact) : AFIS_OK;
 }
@@ -1030,6 +1032,8 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     const size_t n_groups = q->groups.size();
     while (ctx->evpool.size() < n_groups * 10 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
     if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
+    HIPCHK(ctx, ctx->diag.ensure(std::max<size_t>(n_groups, 1) * kDiagWords * 8));
+    HIPCHK(ctx, hipMemsetAsync(ctx->diag.p, 0, std::max<size_t>(n_groups, 1) * kDiagWords * 8, s));    // before the first group's ev[0]: ordered before everything the side streams do
     // Every buffer of the launch groups is brought to its size HERE, while the device is idle and before anything of this search is queued: for the largest group of
     // the search and for its worst case (every latent with kTexMax texture rows — what group_bytes_per_query budgets), so that the calls further down never
     // re-allocate.  A hipMalloc of 6-13 GB takes 0.3 ms on an idle device; issued behind queued work (the row records used to be allocated inside adc_stage_mfma, after
@@ -1045,7 +1049,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
             HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
-            HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
+            HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
             {   // the generic candidate kernel's scratch (sized as in the loop below, for the longest latent minutiae template of the search)
                 const size_t per_wg = 2 * (((size_t)nL_max * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
                 int n_wg = 1024;
@@ -1073,6 +1077,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
         hipEvent_t* ev = &ctx->evpool[gi * 10];
+        unsigned long long* const diag_row = ctx->diag.as<unsigned long long>() + gi * kDiagWords;
         if (G > 0) {
             const size_t n_pairs = (size_t)nq * G;
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
@@ -1088,7 +1093,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
             HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
-            HIPCHK(ctx, ctx->minu_fb.ensure((n_pairs * 3 + 1) * 4));
+            HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
             float* grp_scores = ctx->scores.as<float>() + (size_t)q0 * G;
             // One ADC workgroup fills a CU (128 KB LUT tile), so nothing overlaps its tile load: chunks of ~640 templates keep that
             // under 3 % of a workgroup's life.  The blocks of XCD x are the chunks c % 8 == x, so the chunk COUNT is a multiple of 8
@@ -1105,7 +1110,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const bool overlap = ctx->adc_variant == 9 && ctx->stream_lo != nullptr && n_pairs >= 65536;
             const bool compact9 = ctx->adc_variant == 9;                  // the recomputation kernel's compact list of the rows that matter (S7 reads a third of the rows)
             auto minutiae_stage = [&]() -> int {
-                HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
+                HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, s));
                 HIPCHK(ctx, hipEventRecord(ev[7], s));
                 HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
                 return AFIS_OK;
@@ -1119,9 +1124,9 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 hipStream_t sl = ctx->stream_lo, sh = ctx->stream_hi;
                 HIPCHK(ctx, hipStreamWaitEvent(sl, ev[0], 0));                             // everything of the previous group (this stream's order) is done
                 HIPCHK(ctx, hipStreamWaitEvent(sh, ev[0], 0));
-                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true, sl, false);
+                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true, sl, false, diag_row);
                 if (rc9 != AFIS_OK) return rc9;
-                HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), sh));
+                HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, sh));
                 HIPCHK(ctx, hipMemsetAsync(g.task_ctr + 1, 0, 4, sh));                     // the list counter both instances of the list kernel draw from: reset BEFORE either may start
                 HIPCHK(ctx, hipEventRecord(ev[7], sh));
                 HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, sh, true));
@@ -1143,7 +1148,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, hipStreamSynchronize(sh));
             } else {
             if (ctx->adc_variant == 9) {                                    // fp16 matrix-core bound pass + exact recomputation
-                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true);
+                int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true, nullptr, true, diag_row);
                 if (rc9 != AFIS_OK) return rc9;
             } else if (ctx->adc_variant == 8) {                             // 16-bit fixed-point LDS-table bound pass + exact refine
                 int rc16 = adc_stage_q(ctx, grp, chunk, true, ev[1]);
@@ -1194,7 +1199,18 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         if (!h_sc) { ctx->h_scores.resize((size_t)nq_all * G); h_sc = ctx->h_scores.data(); }
         HIPCHK(ctx, hipMemcpyAsync(h_sc, ctx->scores.p, (size_t)nq_all * G * 4, hipMemcpyDeviceToHost, s));
     }
+    ctx->h_diag.assign(std::max<size_t>(n_groups, 1) * kDiagWords, 0ull);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_diag.data(), ctx->diag.p, ctx->h_diag.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
+    {   // where the candidate tasks went, and the clocks the sampled workgroups saw (shader cycles per tick of the constant 100 MHz counter)
+        unsigned long long acc[kDiagWords] = {};
+        for (size_t i = 0; i < n_groups; ++i) for (int w = 0; w < kDiagWords; ++w) acc[w] += ctx->h_diag[i * kDiagWords + w];
+        tm.minu_fallback_tasks = (int64_t)acc[kDiagFallback];
+        tm.minu_tasks_small = (int64_t)acc[kDiagSmall]; tm.minu_tasks_medium = (int64_t)acc[kDiagSmall + 1]; tm.minu_tasks_large = (int64_t)acc[kDiagSmall + 2];
+        tm.minu_tasks = tm.minu_tasks_small + tm.minu_tasks_medium + tm.minu_tasks_large + tm.minu_fallback_tasks;
+        tm.cands_clock_ghz = acc[kDiagCandsWall] ? (float)((double)acc[kDiagCandsClk] / (double)acc[kDiagCandsWall] * 0.1) : 0.0f;
+        tm.bound_clock_ghz = acc[kDiagBoundWall] ? (float)((double)acc[kDiagBoundClk] / (double)acc[kDiagBoundWall] * 0.1) : 0.0f;
+    }
     if (G > 0) {
         for (size_t i = 0; i < n_groups; ++i) {
             hipEvent_t* ev = &ctx->evpool[i * 10];
@@ -1260,7 +1276,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
         HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
         HIPCHK(ctx, ctx->cands.ensure((size_t)n * 3 * kTopMinu * sizeof(MinuCand)));
         HIPCHK(ctx, ctx->cand_n.ensure((size_t)n * 3 * 4));
-        HIPCHK(ctx, ctx->minu_fb.ensure(4 * 4));
+        HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(3, 1) * 4));
         HIPCHK(ctx, ctx->parts.ensure((size_t)n * 16));
         HIPCHK(ctx, d_xy.ensure((size_t)n * 3 * kTopMinu * sizeof(short4)));
         HIPCHK(ctx, d_n.ensure((size_t)n * 3 * 4));
@@ -1272,7 +1288,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
             one.G = 1; one.minu_off += gi; one.minu_tile_off += gi; one.tex_off += gi; one.tex_cf_blk += gi; one.empty += gi;
             MinuCand* cands = ctx->cands.as<MinuCand>() + (size_t)i * 3 * kTopMinu;
             int32_t* cand_n = ctx->cand_n.as<int32_t>() + (size_t)i * 3;
-            if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, cands, cand_n, ctx->minu_fb.as<int32_t>(), s) != hipSuccess ||
+            if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, cands, cand_n, ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, nullptr, s) != hipSuccess ||
                 launch_graph_minutiae(grp.dev, one, cands, cand_n, ctx->parts.as<float>() + (size_t)i * 4,
                                       d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, nullptr, nullptr, 2, s) != hipSuccess)
                 err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: kernel launch failed");
@@ -1400,6 +1416,9 @@ int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
     else if (n == "chunk") *value = ctx->chunk;
     else if (n == "tile_share") *value = ctx->tile_share;
     else if (n == "minu_generic") *value = ctx->minu_generic;
+    else if (n == "minu_fast_max_latent") *value = rt_class_max_latent(4);            // read-only: what the fast candidate kernel's largest shape class takes (afis_device.h: rt_max_rows)
+    else if (n == "minu_fast_max_rolled") *value = rt_class_max_rolled(4);
+    else if (n == "minu_fast_max_cells") *value = 8192 * 4;
     else if (n == "mf_stats") *value = ctx->mf_collect_stats;
     else if (n == "rowmax_budget_mb") *value = ctx->rowmax_budget_bytes >> 20;
     else if (n == "lut_dtype") *value = 32;
@@ -1594,8 +1613,8 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             slot = which - 1; cap = kTopMinu;
             const size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * 64));
-            HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12)); HIPCHK(ctx, ctx->minu_fb.ensure(4 * 4));
-            HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), s));
+            HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12)); HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(3, 1) * 4));
+            HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, nullptr, s));
             HIPCHK(ctx, launch_graph_minutiae(d, one, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr,
                                               d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
         }

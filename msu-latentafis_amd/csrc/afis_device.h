@@ -120,20 +120,53 @@ hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hi
 hipError_t launch_mf_tiles(const GalleryDev& g, const int32_t* t32_blk, const float* cwn, void* codes_p, float* nrm_p, void* tile_meta, hipStream_t stream);
 hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream);
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
-                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec, hipStream_t stream);
+                           const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec,
+                           unsigned long long* diag /* NULL or a diagnostics row: clock samples */, hipStream_t stream);
 hipError_t launch_tex_refine(const QueryDev& q, const GalleryDev& g, const float* codewords, const void* rec, const void* rowk, int R_pad, int all_rows,
                              float* rm_val, int32_t* rm_arg, unsigned long long* stats, float* rm_cv, int32_t* rm_n, hipStream_t stream);
 // one correspondence of a minutiae-template list (S3 output), 8 bytes
 struct MinuCand { float sim; short li, ri; };
+
+// ---- shape classes of the fast candidate kernel k_minu_cands_rt<S> (minu.hip), S = 1, 2, 4: workgroups of 256 S threads.  A task (nL latent x nR rolled
+// minutiae) fits class S when its similarity matrix fits the class's LDS array with row stride rt_row_stride() and the selection's 32 keys per thread
+// cover it: nL <= rt_max_rows(S, nR).  It is done by the smallest class that takes it; tasks no class takes go to the any-shape kernel.
+// (matcher.cpp:788-790 lets a template carry 2000 minutiae; extraction_rolled.py:105-108 caps nothing for rolled prints.)
+#ifdef __HIPCC__
+#define AFIS_HOST_DEVICE __host__ __device__
+#else
+#define AFIS_HOST_DEVICE
+#endif
+AFIS_HOST_DEVICE constexpr int rt_class_max_rolled(int S) { return S == 1 ? 128 : 256; }
+AFIS_HOST_DEVICE constexpr int rt_class_max_latent(int S) { return S == 1 ? 64 : 256; }
+AFIS_HOST_DEVICE constexpr int rt_class_simi_floats(int S) { return S == 1 ? 8192 : 8192 * S + 256; }     // 32 similarities per thread (+ the odd stride's padding column)
+AFIS_HOST_DEVICE inline int rt_row_stride(int S, int nR) { return S == 1 ? (((nR & 1) || nR == 128) ? nR : nR + 1) : (nR | 1); }
+AFIS_HOST_DEVICE inline int rt_max_rows(int S, int nR)            // the largest latent minutiae count class S takes against nR rolled minutiae (0: none); non-decreasing in S
+{
+    if (nR <= 0 || nR > rt_class_max_rolled(S)) return 0;
+    int m = 32 * ((256 * S) / nR);                                           // 32 keys per thread: thread = (column, row phase)
+    const int cap = rt_class_simi_floats(S) / rt_row_stride(S, nR);
+    m = m < cap ? m : cap;
+    return m < rt_class_max_latent(S) ? m : rt_class_max_latent(S);
+}
+// ints of the candidate stage's control buffer: [fallback count | n_tasks fallback task ids | 8 control words | 3 G work-list entries]
+inline size_t minu_fb_ints(size_t n_tasks, size_t G) { return 1 + n_tasks + 8 + 3 * G; }
+// One row of 16 unsigned 64-bit diagnostics per launch group, zeroed at the start of a search and read back with its results (afis_timing):
+enum { kDiagFallback = 0,       // candidate tasks handed to the any-shape kernel
+       kDiagSmall = 1,          // tasks done by k_minu_cands_rt<1>, <2>, <4> (kDiagSmall + class)
+       kDiagCandsClk = 4, kDiagCandsWall = 5,      // sampled workgroups of the candidate kernel: shader cycles and 100 MHz ticks they lived
+       kDiagBoundClk = 6, kDiagBoundWall = 7,      // the same for the bound pass
+       kDiagWords = 16 };
 // S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
                                 const float* rm_val, const int32_t* rm_arg, const float* rm_cv, const int32_t* rm_n, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
-// (task = (q*3+s)*G + g).  Pairs with <= 64 latent and <= 128 rolled minutiae go through the rolled-template-stationary MFMA kernel;
-// what it cannot take (other shapes, degenerate key distributions) it appends to `fallback` ([1 + n_tasks] ints: count, task ids), which the
-// generic kernel then works off.  force_generic: the generic kernel does every task.
+// (task = (q*3+s)*G + g).  Pairs of up to 256 x 256 minutiae and 32 768 similarities go through the rolled-template-stationary MFMA kernel in one of its
+// three shape classes (above); what it cannot take (other shapes, degenerate key distributions) it appends to `fallback` (count, task ids), which the
+// generic kernel then works off.  force_generic: the generic kernel does every task.  max_nL / max_nR: the longest latent list of the launch and the
+// longest rolled minutiae template of the gallery (which classes can have work at all).
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                             int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback, hipStream_t stream);
+                             int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback /* minu_fb_ints() ints */, int max_nL, int max_nR,
+                             unsigned long long* diag /* NULL or a diagnostics row */, hipStream_t stream);
 // S8a+S9 on those lists, one wave per list -> parts[(q*G+g)*4+{0,1,2}]
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
                                  float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream, bool join = false);

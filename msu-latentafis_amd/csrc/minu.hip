@@ -75,7 +75,8 @@ struct MinuSmem {
 // Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
 __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
                                                          MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n,
-                                                         const int32_t* __restrict__ fb /* NULL: every task; else fb[0] tasks listed in fb[1 ...] */)
+                                                         const int32_t* __restrict__ fb /* NULL: every task; else fb[0] tasks listed in fb[1 ...] */,
+                                                         unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     const int tid = threadIdx.x;
     const long long n_work = fb ? (long long)fb[0] : n_tasks;
+    if (diag != nullptr && blockIdx.x == 0 && tid == 0) diag[kDiagFallback] = (unsigned long long)n_work;
     for (long long work = blockIdx.x; work < n_work; work += gridDim.x) {
         const long long task = fb ? (long long)fb[1 + work] : work;
         // task order: gallery template fastest, then selected template, then query
@@ -253,26 +255,32 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Fast path, rolled-template-stationary: pairs with nL <= 64 latent and nR <= 128 rolled minutiae (every template the
-// extraction normally produces).  One workgroup owns ONE rolled minutiae template at a time and runs every (latent, selected
-// template) list of the launch against it:
+// Fast path, rolled-template-stationary, in three SHAPE CLASSES (template parameter S = 1, 2, 4: workgroups of 256 S threads).
+// One workgroup owns ONE rolled minutiae template at a time and runs every (latent, selected template) list of the launch that
+// belongs to its class against it:
 //   * S1, the one dense contraction of the path (the reference's Eigen GEMM), runs on the matrix cores with the exact-fp32
-//     v_mfma_f32_16x16x4_f32.  Wave w keeps the B fragment (16 rolled descriptors, k-permuted) of column tile w in 24
-//     registers for all <= 24 tasks of the rolled template; only the latent A fragments are fetched per task (24 x 15 KB
-//     shared by every workgroup: L2/L1 resident).  Rolled descriptors therefore cross HBM -> CU once per launch instead of
-//     once per task.  Column tiles 4.. (rolled templates with > 64 minutiae) are dealt round-robin over the waves with the B
-//     fragment fetched per item (an L1/L2 hit: the same workgroup reads it for every task).
+//     v_mfma_f32_16x16x4_f32.  A wave keeps the B fragment (16 rolled descriptors, k-permuted) of one column tile in 24
+//     registers for all tasks of the rolled template; only the latent A fragments are fetched per task (shared by every
+//     workgroup: L2/L1 resident).  Rolled descriptors therefore cross HBM -> CU once per launch instead of once per task.
+//     With fewer column tiles than waves the waves of a column tile split the row tiles; column tiles beyond the wave count
+//     are dealt round-robin over the waves with the B fragment fetched per item (an L1/L2 hit).
 //   * the similarity matrix sits in LDS with an ODD row stride, so the sequential row sums (one lane per row) and the column
 //     sums (one lane per column) are both bank-conflict free.
-//   * S3: a 256-bin LDS histogram (16 bins per octave from 2^-15 up; one bin per thread for the scan) of fp32 APPROXIMATIONS of
+//   * S3: a 256-bin LDS histogram (16 bins per octave from 2^-15 up) of fp32 APPROXIMATIONS of
 //     the norm keys — v_rcp_f32 instead of the reference's double division, at most 6 ulp away (see below) — finds the bin B
 //     holding the 120th largest key.  Keys of zero similarities (half of all entries, all in one bin: they serialised the LDS
-//     atomics) are not counted.  Only the ~130-150 entries that can still be among the 120 largest get the exact double-precision
-//     key; they are ranked among themselves by counting on 45-bit composites (norm key, lowest element index first), which
+//     atomics) are not counted.  Only the ~130-190 entries that can still be among the 120 largest get the exact double-precision
+//     key; they are ranked among themselves by counting on 48-bit composites (norm key, lowest element index first), which
 //     yields exactly the reference's top 120 in the reference's order.  The kernel is bound by VALU issue, so the passes are laid
-//     out for few instructions per element (thread = column x row phase; keys stay in registers between the passes).
-//   * anything else — shapes beyond 64 x 128, fewer than 512 entries, a threshold in the two lowest bins (fewer than 120
-//     similarities with a norm of at least 2^-15), more than 256 candidates — is appended to a fallback list that k_minu_cands (exact threshold
+//     out for few instructions per element (thread = column x row phase; <= 32 keys per thread stay in registers between the passes).
+//   * the classes: what bounds a task is its similarity matrix in LDS and the 32 keys per thread.  S = 1 (round 2's kernel): <= 64 latent x
+//     <= 128 rolled minutiae, 37.7 KB, four workgroups per CU; S = 2: <= 16 384 similarities (128 x 128, 64 x 256 ...), 73 KB, two per CU;
+//     S = 4: <= 32 768 (128 x 256, 160 x 200, 256 x 128 ...), 138 KB, one 16-wave workgroup per CU.  rt_max_rows(S, nR) (afis_device.h) is the
+//     rule; a task goes to the smallest class that takes it (k_minu_classify lists, per class, the rolled templates that have such tasks in
+//     this launch).
+//   * anything else — more than 256 minutiae on either side or more than 32 768 similarities (the reference's reader allows 2000 per
+//     template, matcher.cpp:788-790), fewer than 512 entries, a threshold in the two lowest bins (fewer than 120 similarities with a
+//     norm of at least 2^-15), more than 256 candidates — is appended to a fallback list that k_minu_cands (exact threshold
 //     search on exact keys, any shape) works off afterwards.
 // Approximation bound.  a = sv * rcp(f + 1e-6f) with f the reference's own float (rowsum + colsum) - sv: the float sum
 // f + 1e-6f (<= 2^-23 relative incl. the constant's rounding), v_rcp_f32 (1 ulp) and the product (2^-24) put a within
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 // exact float key, |ka - ke| <= E = 8 as ordered integers.  With Ta = the 120th largest approximate key (in bin B): at least
 // 120 exact keys are >= Ta - E, so every entry of the exact top 120 has ke >= Ta - E, hence ka >= Ta - 2E >= edge(B) - 2E.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSelBins = 256;                        // histogram bins: 16 per octave (4 mantissa bits) from 2^-15 up, one per thread
+constexpr int kSelBins = 256;                        // histogram bins: 16 per octave (4 mantissa bits) from 2^-15 up
 constexpr int kBinBase = (127 - 15) * 16 - 1;        // key bits 30..19 of 2^-15, minus one: bin 0 = everything below (never counted)
 constexpr int kHistMinN = 512;                       // smaller pairs go to the fallback kernel
 constexpr int kCandCap = 256;                        // entries that may still be in the top 120 (exact keys computed for these)
@@ -289,15 +297,22 @@ constexpr uint32_t kKeySlack = 16;                   // 2E
 #define AFIS_PF_TILES 2
 #endif
 constexpr int kPfTiles = AFIS_PF_TILES;              // latent row tiles of the next task copied ahead into the tail of simi[] (6 KB each)
-struct __attribute__((aligned(16))) RtSmem {
-    float simi[kFastN];                              // 32 KB, row stride ld (odd unless nR == 128)
-    float rowsum[kFastL];
-    float colsum[kFastR];
+template <int S> struct RtCfg {
+    static constexpr int kT = 256 * S;               // threads of a workgroup
+    static constexpr int kW = 4 * S;                 // its waves: resident column tiles
+    static constexpr int kMaxR = rt_class_max_rolled(S);     // column sums: thread j; row sums: thread kMaxR + i
+    static constexpr int kMaxL = rt_class_max_latent(S);
+    static constexpr int kSimi = rt_class_simi_floats(S);
+};
+template <int S> struct __attribute__((aligned(16))) RtSmem {
+    float simi[RtCfg<S>::kSimi];                     // row stride ld (odd, except the 128 of S = 1's widest templates)
+    float rowsum[RtCfg<S>::kMaxL];
+    float colsum[RtCfg<S>::kMaxR];
     uint32_t hist[kSelBins];                         // bin b >= 1: approximate keys with bits 30..19 == kBinBase + b (top bin: and above)
     u64 cand[kCandCap];                              // exact composite keys of the candidates
-    uint32_t cand_e[kCandCap];                       // their (row << 8 | column)
-    int wave_tot[kWaves];
-    int thr_bin, pad_;
+    uint32_t cand_e[kCandCap];                       // their (bin << 16 | row << 8 | column)
+    int wave_tot[4];
+    int thr_bin, ticket;
 };
 
 __device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
@@ -316,6 +331,49 @@ __device__ __forceinline__ uint32_t approx_norm_key(float sv, float rs, float cs
     return __float_as_uint(a) | 0x80000000u;                                                    // a >= 0: ord_f32's key
 }
 
+// Which rolled templates have work for which class in THIS launch (the class of a task follows from its two minutiae counts; the latent counts
+// change from launch to launch).  One thread per rolled template: work[c * G + ...] receives the templates with at least one list in class c
+// (ctl[c] = how many), in no particular order — every task writes its own slot of cands[] / cand_n[], so the order changes no result.  Tasks
+// no class takes are settled here: no minutiae on a side -> an empty list (matcher.cpp:400-404); too large for every class -> the fallback list.
+// ctl[0..2] = list lengths, ctl[4..6] = the classes' draw counters (zeroed by the launcher).
+__global__ __launch_bounds__(256) void k_minu_classify(QueryDev q, GalleryDev g, int32_t* __restrict__ work, int32_t* __restrict__ ctl,
+                                                       int32_t* __restrict__ cand_n, int32_t* __restrict__ fb)
+{
+    __shared__ int cnt[258];                                                         // after the scan: cnt[x], 1 <= x <= 256: lists with 1 <= nL <= x; cnt[257]: all non-empty lists; cnt[0]: the empty ones
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nqs = q.nq * 3;
+    for (int i = tid; i < 258; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int qs = tid; qs < nqs; qs += 256) { const int nL = q.lm_off[qs + 1] - q.lm_off[qs]; atomicAdd(&cnt[nL <= 0 ? 0 : min(nL, 257)], 1); }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int x = 1; x <= 257; ++x) { run += cnt[x]; cnt[x] = run; } }
+    __syncthreads();
+    const int gi = blockIdx.x * 256 + tid;
+    const bool live = gi < g.G;
+    const int nR = live ? g.minu_off[gi + 1] - g.minu_off[gi] : 0;
+    const int L1 = rt_max_rows(1, nR), L2 = rt_max_rows(2, nR), L4 = rt_max_rows(4, nR);
+    const int has[3] = {live ? cnt[L1] : 0, live ? cnt[L2] - cnt[L1] : 0, live ? cnt[L4] - cnt[L2] : 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                                    // one atomic per wave and class
+        const u64 m = __ballot(has[c] > 0);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&ctl[c], __popcll(m));
+            base = __shfl(base, leader);
+            if (has[c] > 0) work[(size_t)c * g.G + base + lane_prefix(m)] = gi;
+        }
+    }
+    if (live && (nR <= 0 || cnt[0] > 0 || cnt[257] > cnt[L4])) {                     // some task of this rolled template belongs to no class
+        for (int qs = 0; qs < nqs; ++qs) {
+            const long long task = (long long)qs * g.G + gi;
+            const int nL = q.lm_off[qs + 1] - q.lm_off[qs];
+            if (nR <= 0 || nL <= 0) cand_n[task] = 0;
+            else if (nL > L4) { const int p = atomicAdd(&fb[0], 1); fb[1 + p] = (int32_t)task; }
+        }
+    }
+}
+
 // fb[0] = number of fallback tasks, fb[1 ...] = their task indices
 #ifndef AFIS_MC_ABLATE
 #define AFIS_MC_ABLATE 0
@@ -325,11 +383,18 @@ __device__ __forceinline__ uint32_t approx_norm_key(float sv, float rs, float cs
 #else
 #define RT_SYNC() __syncthreads()
 #endif
-__global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, GalleryDev g, const float4* __restrict__ lat_frag,
+template <int S>
+__global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, GalleryDev g, const float4* __restrict__ lat_frag,
                                                                 const float4* __restrict__ rol_frag,  // descriptors as operand fragments
-                                                                MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb, int32_t* __restrict__ next_rolled)
+                                                                MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb,
+                                                                const int32_t* __restrict__ work /* rolled templates with tasks of this class */,
+                                                                int32_t* __restrict__ ctl /* ctl[c]: entries of work[]; ctl[4 + c]: the draw counter */,
+                                                                unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row (afis_device.h) */)
 {
-    __shared__ RtSmem sm;
+    typedef RtCfg<S> Cfg;
+    constexpr int kT = Cfg::kT, kW = Cfg::kW, kSimi = Cfg::kSimi, kCls = S == 1 ? 0 : S == 2 ? 1 : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem_raw[];
+    RtSmem<S>& sm = *reinterpret_cast<RtSmem<S>*>(rt_smem_raw);
     PHASE_DECL();
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
@@ -337,48 +402,52 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
     const int li = lane & 15, lg = lane >> 4;
     const int nqs = q.nq * 3;
     auto to_fallback = [&](long long task) { const int p = atomicAdd(&fb[0], 1); fb[1 + p] = (int32_t)task; };
+    // The clock the chip holds under this kernel (afis_timing.cands_clock_ghz): one lane of the first workgroups reads the shader-cycle counter and the constant
+    // 100 MHz counter when it starts and when it leaves; the sums of the two differences go to the diagnostics row.
+    const bool sampler = diag != nullptr && blockIdx.x < 8 && tid == 0;
+    unsigned long long clk0 = 0, wall0 = 0;
+    if (sampler) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
+    int n_done = 0;                                                                 // tasks this workgroup completed (thread 0's count)
+    const int n_work = ctl[kCls];
     // Rolled templates are DRAWN from a counter, not dealt by stride: the kernel may start on the part of the chip the (CU-masked) bound pass leaves free and spread
     // over the rest when that finishes (afis_api.cpp, option bound_cus): workgroups that start late must not find a fixed share of the work waiting for them.
-    __shared__ int s_ticket;
     for (;;) {
-        if (tid == 0) s_ticket = atomicAdd(next_rolled, 1);
+        if (tid == 0) sm.ticket = atomicAdd(&ctl[4 + kCls], 1);
         __syncthreads();
-        const int gi = s_ticket;
+        const int wi = sm.ticket;
         __syncthreads();                                                            // everyone has read the ticket before thread 0 draws the next one
-        if (gi >= g.G) break;
+        if (wi >= n_work) break;
+        const int gi = work[(size_t)kCls * g.G + wi];
         const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
-        if (nR <= 0 || nR > kFastR) {                                               // no rolled minutiae (matcher.cpp:400-404) / too many for this kernel
-            for (int qs = tid; qs < nqs; qs += kThreads) {
-                const long long task = (long long)qs * g.G + gi;
-                const int nL = q.lm_off[qs + 1] - q.lm_off[qs];
-                if (nR <= 0 || nL <= 0) cand_n[task] = 0; else to_fallback(task);
-            }
-            continue;
-        }
+        const int Lhi = rt_max_rows(S, nR), Llo = S == 1 ? 0 : rt_max_rows(S / 2, nR); // this class: Llo < nL <= Lhi (k_minu_classify listed the template: Lhi > 0)
         const int n_jt = (nR + 15) >> 4;
-        const int ld = ((nR & 1) || nR == kFastR) ? nR : nR + 1;
-        const int R = kThreads / nR;                                                // selection: row phases per column (>= 2)
+        const int ld = rt_row_stride(S, nR);
+        const int R = kT / nR;                                                      // selection: row phases per column (>= 2)
         const int cr = tid / nR, cj = tid - cr * nR;                                // this thread's row phase and column (idle if cr >= R)
-        // ---- the wave's resident B fragment: rolled descriptors 16*wave .. 16*wave+15 (lane l: descriptor l&15, k-group l>>4) ----
+        // ---- the wave's resident B fragment: rolled descriptors of column tile jt_res (lane l: descriptor l&15, k-group l>>4); with fewer column tiles than
+        // waves, P waves share a column tile and split its row tiles ----
+        const int n_res = min(n_jt, kW), P = kW / n_res;
+        const int jt_res = wave % n_res, part = wave / n_res;                       // part >= P: no resident work
         const float4* btiles = rol_frag + (size_t)g.minu_tile_off[gi] * (6 * 64) + lane;
         float bres[24];
-        if (wave < n_jt) {
 #pragma unroll
-            for (int v = 0; v < 6; ++v) { const float4 x = btiles[(wave * 6 + v) * 64]; bres[4 * v] = x.x; bres[4 * v + 1] = x.y; bres[4 * v + 2] = x.z; bres[4 * v + 3] = x.w; }
-        } else {
-#pragma unroll
-            for (int v = 0; v < 24; ++v) bres[v] = 0.0f;
-        }
+        for (int v = 0; v < 6; ++v) { const float4 x = btiles[(jt_res * 6 + v) * 64]; bres[4 * v] = x.x; bres[4 * v + 1] = x.y; bres[4 * v + 2] = x.z; bres[4 * v + 3] = x.w; }
+        auto next_in_class = [&](int from) {                                        // uniform: scalar loads
+            int x = from;
+            for (; x < nqs; ++x) { const int nl = q.lm_off[x + 1] - q.lm_off[x]; if (nl > Llo && nl <= Lhi) break; }
+            return x;
+        };
         // The latent row tiles of the NEXT task of this rolled template are copied into the unused tail of simi[] while this task is being selected from
-        // (global_load_lds: memory -> LDS without registers; one 16-byte element per lane, one copy for the four waves, which each fetched every tile
+        // (global_load_lds: memory -> LDS without registers; one 16-byte element per lane, one copy for the workgroup's waves, which each fetched every tile
         // themselves before) — the fetch was the exposed L2 round trip at the head of every task.  pf_qs: the task whose tiles the tail holds (-1: none).
         int pf_qs = -1;
-        for (int qs = 0; qs < nqs; ++qs) {
+        int qs_next = next_in_class(0);
+        for (int qs = qs_next; qs < nqs; qs = qs_next) {
+            qs_next = next_in_class(qs + 1);
             const long long task = (long long)qs * g.G + gi;
             const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
-            if (nL <= 0) { if (tid == 0) cand_n[task] = 0; continue; }               // matcher.cpp:400-404
             const int n = nL * nR;
-            if (nL > kFastL || n < kHistMinN) { if (tid == 0) to_fallback(task); continue; }
+            if (n < kHistMinN) { if (tid == 0) to_fallback(task); continue; }
             PHASE_INIT();
             // ---- S1 (matcher.cpp:440-452): simi = max(0, A * B^T); v_mfma_f32_16x16x4_f32 == the k-ascending fmaf chain ----
             // Operand layout: lane l supplies A[i = l&15][k = 4s + (l>>4)] and B[k][j = l&15] at step s = 4v + c; the fragment arrays
@@ -386,7 +455,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             const int n_it = (nL + 15) >> 4;
             const float4* atiles = lat_frag + (size_t)q.lm_tile_off[qs] * (6 * 64) + lane;
             const int n_pf = pf_qs == qs ? min(n_it, kPfTiles) : 0;                 // uniform: row tiles 0 .. n_pf - 1 wait in the tail of simi[]
-            const float4* const a_lds = reinterpret_cast<const float4*>(sm.simi + kFastN) - kPfTiles * (6 * 64) + lane;
+            const float4* const a_lds = reinterpret_cast<const float4*>(sm.simi + kSimi) - kPfTiles * (6 * 64) + lane;
             auto load_frag = [&](const float4* __restrict__ tiles, int t, float (&f)[24]) {
 #pragma unroll
                 for (int v = 0; v < 6; ++v) { const float4 x = tiles[(t * 6 + v) * 64]; f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w; }
@@ -409,10 +478,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 for (int st = 0; st < 24; ++st) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st], bf[st], acc, 0, 0, 0);
                 return acc;
             };
-            if (wave < n_jt) {                                                      // column tile `wave`, every row tile: B stays in registers
+            if (part < P) {                                                         // column tile jt_res, this wave's share of the row tiles: B stays in registers
                 // row tiles in pairs: two independent accumulator chains keep the matrix pipe issuing every 32 cycles (one chain alone
                 // waits 40+ cycles for each result)
-                for (int it = 0; it < n_it; it += 2) {
+                for (int it = 2 * part; it < n_it; it += 2 * P) {
                     float a0[24], a1[24];
                     if (it < n_pf) load_frag(a_lds, it, a0); else load_frag(atiles, it, a0);
                     if (it + 1 < n_it) {
@@ -424,36 +493,37 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[st], bres[st], acc0, 0, 0, 0);
                             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[st], bres[st], acc1, 0, 0, 0);
                         }
-                        store_tile(it, wave, acc0);
-                        store_tile(it + 1, wave, acc1);
+                        store_tile(it, jt_res, acc0);
+                        store_tile(it + 1, jt_res, acc1);
                     } else {
                         __builtin_amdgcn_sched_barrier(0);
-                        store_tile(it, wave, mfma_tile(a0, bres));
+                        store_tile(it, jt_res, mfma_tile(a0, bres));
                     }
                 }
             }
-            for (int item = wave; item < (n_jt - kWaves) * n_it; item += kWaves) {   // column tiles 4..: dealt round-robin
-                const int jt = kWaves + item / n_it, it = item - (jt - kWaves) * n_it;
+            if (S < 4)                                                               // (16 waves hold every column tile of <= 256 rolled minutiae)
+            for (int item = wave; item < (n_jt - kW) * n_it; item += kW) {           // column tiles kW ..: dealt round-robin
+                const int jt = kW + item / n_it, it = item - (jt - kW) * n_it;
                 float af[24], bf[24];
                 load_frag(btiles, jt, bf);
                 if (it < n_pf) load_frag(a_lds, it, af); else load_frag(atiles, it, af);
                 __builtin_amdgcn_sched_barrier(0);
                 store_tile(it, jt, mfma_tile(af, bf));
             }
-            sm.hist[tid] = 0u;
+            if (S == 1 || tid < kSelBins) sm.hist[tid] = 0u;
             if (tid == 0) sm.thr_bin = -1;
             RT_SYNC();
             pf_qs = -1;
-            if (qs + 1 < nqs) {                                                      // uniform
-                const int nLn = q.lm_off[qs + 2] - q.lm_off[qs + 1];
+            if (qs_next < nqs) {                                                     // uniform
+                const int nLn = q.lm_off[qs_next + 1] - q.lm_off[qs_next];
                 const int n_cp = min((nLn + 15) >> 4, kPfTiles);
                 // the tail must clear this task's matrix (still being read) and the next one's (written before the tiles are read)
-                if (nLn > 0 && nLn <= kFastL && max(nL, nLn) * ld + kPfTiles * (6 * 64 * 4) <= kFastN) {
-                    const float4* src = lat_frag + (size_t)q.lm_tile_off[qs + 1] * (6 * 64) + lane;
-                    float4* dst = reinterpret_cast<float4*>(sm.simi + kFastN) - kPfTiles * (6 * 64);
-                    for (int c = wave; c < n_cp * 6; c += kWaves)                    // chunk = 64 lanes x 16 B = one (tile, v) slice
+                if (max(nL, nLn) * ld + kPfTiles * (6 * 64 * 4) <= kSimi) {
+                    const float4* src = lat_frag + (size_t)q.lm_tile_off[qs_next] * (6 * 64) + lane;
+                    float4* dst = reinterpret_cast<float4*>(sm.simi + kSimi) - kPfTiles * (6 * 64);
+                    for (int c = wave; c < n_cp * 6; c += kW)                        // chunk = 64 lanes x 16 B = one (tile, v) slice
                         __builtin_amdgcn_global_load_lds(src + c * 64, (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
-                    pf_qs = qs + 1;
+                    pf_qs = qs_next;
                 }
             }
             PHASE(16);
@@ -478,8 +548,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                 }
                 for (; k < nL; ++k) sacc += p[k * ld];
                 sm.colsum[tid] = sacc;
-            } else if (tid >= 128 && tid - 128 < nL) {
-                const float* p = &sm.simi[(tid - 128) * ld];
+            } else if (tid >= Cfg::kMaxR && tid - Cfg::kMaxR < nL) {
+                const float* p = &sm.simi[(tid - Cfg::kMaxR) * ld];
                 float sacc = 0.f;
                 int k = 0;
                 for (; k + 8 <= nR; k += 8) {
@@ -491,7 +561,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                     for (int u = 0; u < 8; ++u) sacc += v[u];
                 }
                 for (; k < nR; ++k) sacc += p[k];
-                sm.rowsum[tid - 128] = sacc;
+                sm.rowsum[tid - Cfg::kMaxR] = sacc;
             }
             RT_SYNC();
             PHASE(17);
@@ -499,7 +569,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             // and task before this layout), so the selection is organised for few instructions per element: thread = (column cj, row
             // phase cr) walks the rows cr, cr + R, ... of ITS column — the column sum stays in a register, the address advances by a
             // constant — and keeps the approximate keys in registers for the second pass.
-            const int n_rows = (nL + R - 1) / R;                                     // <= 32 (nL <= 64, R >= 2)
+            const int n_rows = (nL + R - 1) / R;                                     // <= 32: rt_max_rows()
             const int my_rows = cr < R ? (nL - cr + R - 1) / R : 0;
             uint32_t rk[32];
             {
@@ -521,18 +591,23 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             }
             RT_SYNC();
             PHASE(29);
-            {   // thread tid owns bin tid: suffix sums over the higher bins find the bin holding the 120th largest approximate key
-                const int own = (int)sm.hist[tid];
-                int suf = own;
+            {   // thread b < 256 owns bin b: suffix sums over the higher bins find the bin holding the 120th largest approximate key
+                int own = 0, suf = 0;
+                if (S == 1 || tid < kSelBins) {
+                    own = (int)sm.hist[tid];
+                    suf = own;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
-                if (lane == 0) sm.wave_tot[wave] = suf;
+                    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
+                    if (lane == 0) sm.wave_tot[wave] = suf;
+                }
                 RT_SYNC();
-                int above = suf - own;
+                if (S == 1 || tid < kSelBins) {
+                    int above = suf - own;
 #pragma unroll
-                for (int w = 0; w < kWaves; ++w) if (w > wave) above += sm.wave_tot[w];
-                if (above < kTopMinu && above + own >= kTopMinu) sm.thr_bin = tid;
-                sm.hist[tid] = (uint32_t)above;                                      // from here on: where the next candidate of this bin goes
+                    for (int w = 0; w < 4; ++w) if (w > wave) above += sm.wave_tot[w];
+                    if (above < kTopMinu && above + own >= kTopMinu) sm.thr_bin = tid;
+                    sm.hist[tid] = (uint32_t)above;                                  // from here on: where the next candidate of this bin goes
+                }
             }
             RT_SYNC();
             PHASE(30);
@@ -566,7 +641,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
             if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
                 const uint32_t pe = sm.cand_e[tid];
                 cbin = (int)(pe >> 16); ci = (int)((pe >> 8) & 255u); cj2 = (int)(pe & 255u);
-                sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 13) | (u64)(8191 - (ci * nR + cj2));
+                sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 16) | (u64)(65535 - (ci * nR + cj2));
             } else if (tid == n_c) sm.cand[tid & (kCandCap - 1)] = 0ull;             // pad of an odd list (n_c == kCandCap is even: nothing is overwritten)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the next task's tiles has landed in LDS (waited for here, before the list's stores join the counter)
             RT_SYNC();
@@ -588,38 +663,66 @@ __global__ __launch_bounds__(kThreads, 4) void k_minu_cands_rt(QueryDev q, Galle
                     cands[(size_t)task * kTopMinu + r] = cd;
                 }
             }
-            if (tid == 0) cand_n[task] = kTopMinu;
+            if (tid == 0) { cand_n[task] = kTopMinu; ++n_done; }
             RT_SYNC();
             PHASE(20);
         }
     }
+    if (diag != nullptr && tid == 0) {
+        if (n_done) atomicAdd(&diag[kDiagSmall + kCls], (unsigned long long)n_done);
+        if (sampler) { atomicAdd(&diag[kDiagCandsClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagCandsWall], (unsigned long long)wall_clock64() - wall0); }
+    }
     PHASE_FLUSH();
 }
 
+template <int S>
+static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int32_t* work, int32_t* ctl, unsigned long long* diag, hipStream_t stream)
+{
+    // opt-in to > 64 KB of dynamic LDS: a per-device function attribute, set on every launch (cheap) rather than cached per process
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands_rt<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RtSmem<S>));
+    if (e != hipSuccess) return e;
+    const int per_cu = 4 / S;                                                      // 4 / 2 / 1 workgroups (16 waves) per CU, persistent: rolled templates are drawn from ctl[4 + class]
+    const int grid = g.G < 256 * per_cu ? g.G : 256 * per_cu;
+    hipLaunchKernelGGL(k_minu_cands_rt<S>, dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag);
+    return hipGetLastError();
+}
+
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
-                             int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback, hipStream_t stream)
+                             int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int max_nL, int max_nR, unsigned long long* diag, hipStream_t stream)
 {
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
     if (n_tasks > 0x7ffffff0LL) return hipErrorInvalidValue;
     hipError_t e;
     if (!force_generic) {
+        int32_t* ctl = fallback + 1 + n_tasks;                                    // minu_fb_ints(): [count | n_tasks task ids | 8 control words | 3 G work-list entries]
+        int32_t* work = ctl + 8;
         e = hipMemsetAsync(fallback, 0, sizeof(int32_t), stream);
         if (e != hipSuccess) return e;
-        if (!g.task_ctr) return hipErrorInvalidValue;
-        e = hipMemsetAsync(g.task_ctr + 3, 0, sizeof(int32_t), stream);
+        e = hipMemsetAsync(ctl, 0, 8 * sizeof(int32_t), stream);
         if (e != hipSuccess) return e;
-        const int grid = g.G < 1024 ? g.G : 1024;                                 // 4 workgroups per CU, persistent: rolled templates are drawn from g.task_ctr[3]
-        hipLaunchKernelGGL(k_minu_cands_rt, dim3(grid), dim3(kThreads), 0, stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, g.task_ctr + 3);
+        hipLaunchKernelGGL(k_minu_classify, dim3((g.G + 255) / 256), dim3(256), 0, stream, q, g, work, ctl, cand_n, fallback);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
+        e = launch_rt_class<1>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
+        if (e != hipSuccess) return e;
+        // the larger classes only when the shapes of this launch can reach them (a kernel that finds its work list empty still costs a launch)
+        const int mr = max_nR < 256 ? (max_nR > 0 ? max_nR : 1) : 256;
+        if (max_nL > rt_class_max_latent(1) || max_nR > rt_class_max_rolled(1)) {
+            e = launch_rt_class<2>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
+            if (e != hipSuccess) return e;
+            if (max_nL > rt_max_rows(2, mr)) {
+                e = launch_rt_class<4>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
+                if (e != hipSuccess) return e;
+            }
+        }
     }
     // opt-in to > 64 KB of dynamic LDS: a per-device function attribute, set on every launch (cheap) rather than cached per process
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MinuSmem));
     if (e != hipSuccess) return e;
     const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
     hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n,
-                       force_generic ? (const int32_t*)nullptr : fallback);
+                       force_generic ? (const int32_t*)nullptr : fallback, diag);
     return hipGetLastError();
 }
 

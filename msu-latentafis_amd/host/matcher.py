@@ -41,7 +41,9 @@ class TemplateView(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("lut_ms", C.c_float), ("adc_ms", C.c_float), ("tex_tail_ms", C.c_float), ("minu_ms", C.c_float), ("fuse_ms", C.c_float), ("topk_ms", C.c_float),
                 ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64), ("adc_bound_ms", C.c_float), ("adc_refine_ms", C.c_float),
-                ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("reserved_", C.c_int32)]
+                ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("reserved_", C.c_int32),
+                ("minu_tasks", C.c_int64), ("minu_fallback_tasks", C.c_int64), ("minu_tasks_small", C.c_int64), ("minu_tasks_medium", C.c_int64), ("minu_tasks_large", C.c_int64),
+                ("bound_clock_ghz", C.c_float), ("cands_clock_ghz", C.c_float)]
 
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch", "afis_gallery_reserve",

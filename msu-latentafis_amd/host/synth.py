@@ -142,21 +142,29 @@ class PackedGallery:
 
 GEN_BLOCK = 1024   # templates per independently seeded block: any shard can be generated without the rest
 
+# Named workloads of bench.py / the sweeps.  "headline" = SURVEY section 8d's shapes (BASELINE.json's ~80 minutiae per rolled print); "wide" = the shapes the reference's
+# reader also accepts but the synthetic envelope never produced (matcher.cpp:788-790 allows 2000 minutiae per template, extraction_rolled.py:105-108 caps nothing for rolled
+# prints): rolled minutiae clip(N(130, 40), 20, 400), latent minutiae U{20..150}; texture templates as in the headline.
+WORKLOADS = {
+    "headline": {"gallery": {}, "latent": {}},
+    "wide": {"gallery": {"n_minu_mean": 130, "n_minu_sd": 40, "n_minu_max": 400}, "latent": {"n_minu_lo": 20, "n_minu_hi": 150}},
+}
 
-def gallery_counts(seed: int, G: int, n_minu_mean: float = 80, n_tex_lo: int = 600, n_tex_hi: int = 1000):
+
+def gallery_counts(seed: int, G: int, n_minu_mean: float = 80, n_tex_lo: int = 600, n_tex_hi: int = 1000, n_minu_sd: float = 15, n_minu_max: int = 200):
     """Per-template point counts of the synthetic gallery (cheap; every rank computes all of them to place shard bounds)."""
     rng = np.random.default_rng([seed, 0xC0])
-    nm = np.clip(np.rint(rng.normal(n_minu_mean, 15, G)), 20, 200).astype(np.int64)
+    nm = np.clip(np.rint(rng.normal(n_minu_mean, n_minu_sd, G)), 20, n_minu_max).astype(np.int64)
     nt = rng.integers(n_tex_lo, n_tex_hi + 1, G).astype(np.int64)
     return nm, nt
 
 
 def make_packed_gallery(seed: int, G: int, cb: Codebook, lo: int = 0, hi: Optional[int] = None, n_minu_mean: float = 80,
-                        n_tex_lo: int = 600, n_tex_hi: int = 1000) -> PackedGallery:
+                        n_tex_lo: int = 600, n_tex_hi: int = 1000, n_minu_sd: float = 15, n_minu_max: int = 200) -> PackedGallery:
     """Vectorised random (non-mate) gallery, templates [lo, hi) of a G-template gallery; plant mates afterwards with
     plant_mates().  Content depends only on (seed, G, template index), not on the shard bounds."""
     hi = G if hi is None else hi
-    nm_all, nt_all = gallery_counts(seed, G, n_minu_mean, n_tex_lo, n_tex_hi)
+    nm_all, nt_all = gallery_counts(seed, G, n_minu_mean, n_tex_lo, n_tex_hi, n_minu_sd, n_minu_max)
     nm, nt = nm_all[lo:hi], nt_all[lo:hi]
     mo = np.concatenate([[0], np.cumsum(nm)]); to = np.concatenate([[0], np.cumsum(nt)])
     NM, NT = int(mo[-1]), int(to[-1])

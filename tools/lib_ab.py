@@ -9,7 +9,9 @@ cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stri
 args = sys.argv[1:]
 G = int(args.pop(0)) if args and args[0].isdigit() else 20000
 Q = int(args.pop(0)) if args and args[0].isdigit() else 8
-lats = S.make_latents(1, Q); gal = S.make_packed_gallery(1, G, cb, n_minu_mean=float(os.environ.get("AFIS_AB_MINU_MEAN", "80"))); S.plant_mates(1, gal, cb, lats)
+wl = S.WORKLOADS[os.environ.get("AFIS_AB_WORKLOAD", "headline")]                 # AFIS_AB_WORKLOAD=wide: the off-envelope shapes (synth.py)
+gkw = dict(wl["gallery"]); gkw.setdefault("n_minu_mean", float(os.environ.get("AFIS_AB_MINU_MEAN", "80")))
+lats = S.make_latents(1, Q, **wl["latent"]); gal = S.make_packed_gallery(1, G, cb, **gkw); S.plant_mates(1, gal, cb, lats)
 paths = [M.LIB_PATH] + sorted(args)
 ms = []
 for path in paths:
@@ -28,4 +30,4 @@ for rep in range(4):
             best[i] = tm if best[i] is None else {k: min(best[i][k], v) if k.endswith("_ms") else v for k, v in tm.items()}
             best[i]["identical"] = same
 for p, b in zip(paths, best):
-    print(os.path.basename(p), {k: round(v, 2) for k, v in b.items() if k.endswith("_ms")}, "identical", b["identical"])
+    print(os.path.basename(p), {k: round(v, 2) for k, v in b.items() if k.endswith("_ms")}, {k: v for k, v in b.items() if k.startswith("minu_") and k.endswith("tasks") or k.endswith("_ghz")}, "identical", b["identical"])
