@@ -306,6 +306,10 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / max(1, a.steps)
     value = Q / (ms_per_step / 1000.0)
+    if bound_cus > 0 and tm_acc.get("overlapped_groups", 1) == 0:            # the library ran every group back to back (a workload whose minutiae stage outweighs the bound pass): the pass had all CUs
+        bound_cus_opt, bound_cus = bound_cus, 0
+    else:
+        bound_cus_opt = bound_cus
     # where a step's time goes on each rank: the search of the rank's shard, and the exchange step (all-gather + merge; a rank that finishes its
     # shard early waits here for the slowest one, so max(exchange) - min(exchange) is the imbalance and min(exchange) the cost of the step itself)
     per_rank = np.array([wall["search"], wall["exchange"]], np.float64) * 1000.0 / max(1, a.steps)
@@ -314,6 +318,15 @@ def main():
         t_lo = torch.tensor(per_rank, dtype=torch.float64, device=dev); t_hi = t_lo.clone()
         dist.all_reduce(t_lo, op=dist.ReduceOp.MIN); dist.all_reduce(t_hi, op=dist.ReduceOp.MAX)
         pr_min, pr_max = t_lo.cpu().numpy(), t_hi.cpu().numpy()
+
+    # ---- who ran: per rank the device the HIP runtime reports (name, PCI bus id, UUID), its shard and its wall times; rank 0 gathers them so that the line certifies
+    # itself: N ranks on N DISTINCT devices with an N-rank RCCL communicator, or ranks sharing a GPU (test mode) ------------------------------------------------
+    me = dict(m.device_info(gpu), rank=rank, local_rank=local, device_index=gpu, shard=[int(lo), int(hi)], search_ms=round(float(per_rank[0]), 3), exchange_ms=round(float(per_rank[1]), 3),
+              rccl_comm_count=(xch.comm_count if xch is not None else None), rccl_comm_device=(xch.comm_device if xch is not None else None))
+    ranks_info = [me]
+    if use_dist:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
 
     # ---- rank-list sanity: the planted true mate must be rank 1 ------------------------------------------------------
     hits = sum(1 for q in range(Q) if int(idx[q, 0]) == planted[q][0][0])
@@ -330,7 +343,7 @@ def main():
             acc = t_ if acc is None else {k_: acc[k_] + v for k_, v in t_.items()}
         assert np.array_equal(r_["topk_idx"], np.asarray(idx)) or use_dist, "the schedule changed a rank list"
         alone = {k_: (v / 2 if (k_.endswith("_ms") or k_.endswith("_ghz")) else v) for k_, v in acc.items()}
-        m.set_option("bound_cus", bound_cus)
+        m.set_option("bound_cus", bound_cus_opt)
 
     out = None
     if rank == 0 and a.dump_ranks:
@@ -414,9 +427,11 @@ def main():
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
-                       "adc_variant": variant, "bound_cus": bound_cus,
+                       "adc_variant": variant, "bound_cus": bound_cus, "bound_cus_option": bound_cus_opt,
                        "schedule": ("bound pass on %d CUs, minutiae stage (candidates + lists) beside it on the other %d, then recomputation + texture lists on the whole chip; stage times overlap: their sum exceeds ms_per_step" % (bound_cus, 256 - bound_cus))
-                                   if bound_cus > 0 else "one stream, the kernels of a launch group back to back", "bound_pass_dtype": ("f16 operands, f32 accumulation on the matrix cores: used for BOUNDS only, every score is the reference's f32 arithmetic" if variant == 9 else
+                                   if bound_cus > 0 else
+                                   ("one stream, the kernels of a launch group back to back" + (" (the library chose it for this workload: the minutiae stage outweighs the bound pass, option bound_cus %d notwithstanding)" % bound_cus_opt if bound_cus_opt > 0 else "")),
+                       "overlapped_groups_per_step": tm_acc.get("overlapped_groups", 0) // max(1, a.steps), "bound_pass_dtype": ("f16 operands, f32 accumulation on the matrix cores: used for BOUNDS only, every score is the reference's f32 arithmetic" if variant == 9 else
                                                                    "u16 fixed point in LDS: used for BOUNDS only" if variant == 8 else "none"), "mean_latent_tex_rows": float(np.mean([L.tex[0].n for L in lats])),
                        "mean_rolled_tex_points": float(nt_all.mean()), "mean_rolled_minutiae": float(nm_all.mean()),
                        "mean_latent_minutiae_selected": float(np.mean([L.minu[i].n for L in lats for i in (26, 2, 11) if len(L.minu) > i]))},
@@ -434,6 +449,14 @@ def main():
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},
                                      "note": "host wall time per rank; a rank that finishes its shard early waits in the exchange for the slowest: min(exchange) is the step's own cost"},
             "exchange_ms_per_step": round(float(pr_min[1]), 3),
+            "ranks": ranks_info,
+            "distinct_devices": len({(r_["uuid"] or r_["pci_bus_id"]) for r_ in ranks_info}),
+            "shared_gpu": bool(a.share_gpu) or len({(r_["uuid"] or r_["pci_bus_id"]) for r_ in ranks_info}) < world,
+            "rccl_ranks": ((xch.comm_count if xch.is_rccl else 0) if xch is not None else (dist.get_world_size() if (use_dist and a.backend == "nccl") else 0)),
+            "rccl_ranks_is": ("ncclCommCount of the C++ exchange's communicator (csrc/rank_exchange.cpp)" if (xch is not None and xch.is_rccl) else
+                              "0: the TCP stand-in carries the exchange, there is no RCCL communicator" if xch is not None else
+                              "world size of torch.distributed's nccl (= RCCL) process group" if (use_dist and a.backend == "nccl") else "0: no RCCL communicator in this run (one rank, or a gloo test run)"),
+            "scaling_curve_note": "no 1 -> 8 GPU curve has been measured by the builder: multi-GPU boxes are only available to the driver",
             "latency_ms_per_query": round(ms_per_step / max(1, Q), 3), "launch_groups_per_step": tm_acc["launch_groups"] // max(1, a.steps),
             "rank1_hits": f"{hits}/{Q}", "setup_s": {"generate": round(t_gen, 1), "upload": round(t_up, 1)},
         }

@@ -83,7 +83,7 @@ typedef struct afis_timing {
     float   cands_ms;      /* part of minu_ms: S1-S3 (descriptor GEMM, normalisation, top-120 candidates)                      */
     float   minu_graph_ms; /* part of minu_ms: S8a + S9 on the minutiae correspondence lists                                   */
     int32_t launch_groups; /* launch groups the queries were cut into                                                          */
-    int32_t reserved_;
+    int32_t overlapped_groups; /* of those: groups that ran the overlapped schedule (option bound_cus); the others ran their kernels back to back */
     /* round 5 (afis_get_timing2 with the caller's struct size): where the minutiae candidate tasks went, and the clocks the device held */
     int64_t minu_tasks;          /* (latent minutiae list, rolled template) candidate tasks of the call with minutiae on both sides   */
     int64_t minu_fallback_tasks; /* of those: tasks the shape-class kernels handed to the any-shape kernel (k_minu_cands)             */
@@ -101,6 +101,11 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
 int afis_create_from_codebook(afis_ctx** out, const void* codebook_bytes, size_t len, int device_id);
 void afis_destroy(afis_ctx* ctx);
 const char* afis_last_error(const afis_ctx* ctx);   /* ctx may be NULL: last afis_create failure */
+
+/* Identity of HIP device `device_id` as the runtime reports it: marketing name + architecture, PCI bus id ("0000:c1:00.0", hipDeviceGetPCIBusId), UUID as 32 hex digits
+ * (hipDeviceGetUuid), compute units.  Any output may be NULL.  One process per GPU: a multi-GPU job reports these per rank so that it can be told
+ * from ranks sharing one device. */
+int afis_device_info(int device_id, char* name, size_t name_cap, char* pci_bus_id, size_t pci_cap, char* uuid_hex /* >= 33 bytes */, size_t uuid_cap, int* n_cus);
 
 /* Gallery build: replaces the per-pair load_FP_template(rolled) at matcher.cpp:173/:278 — parse once, keep the
  * gallery resident in HBM.  Only minutiae template 0 and texture template 0 of a rolled template are ever used
@@ -219,7 +224,8 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * (the north_star's LDS-LUT design; 1.6 x the time of 9); 7 = direct exact kernel, conflict-free lane classes, 1024-thread workgroups (2.9 x); 6 = the same with 512;
  * 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
  * "mf_blocks" (form of variant 9's bound pass: 2 [default] / 3 row blocks per wave, 102 = software-pipelined; bit-identical), "bound_cus" (below), "query_batch" (latents per launch group),
- * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "rowmax_budget_mb" (device memory of a launch group's per-pair
+ * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
+ * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded), "rowmax_budget_mb" (device memory of a launch group's per-pair
  * buffers; default 60 % of the free memory), "mf_stats" (adc_variant 9: collect the counters the parity tap afis_debug_refine_stats reads).  ("lut_dtype" accepts only 32: the
  * opt-in 16-bit tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */

@@ -58,6 +58,8 @@ struct QueryGroup {
     QueryDev dev;
     DevBuf lm_off, lm_xy, lm_ori, lm_des, lm_frag, lm_tile_off, lt_off, lt_xy, lt_ori, lt_des, tile_off, tile16_off, tex_slot, status;
     int nq = 0; int max_nL = 0; int n_lt_rows = 0; int64_t lut_rows_x_tiles = 0;
+    int64_t n_lm_points = 0;             // latent minutiae of the group's three selected templates per query, summed
+    bool overlapped = false;             // how the last search scheduled this group (afis_search_resident)
     std::vector<int32_t> h_lt_n;
     void release() { lm_off.release(); lm_xy.release(); lm_ori.release(); lm_des.release(); lm_frag.release(); lm_tile_off.release(); lt_off.release(); lt_xy.release(); lt_ori.release();
                      lt_des.release(); tile_off.release(); tile16_off.release(); tex_slot.release(); status.release(); }
@@ -96,6 +98,7 @@ struct afis_ctx {
     int64_t t32_tiles = 0;               // tiles of 32 rolled texture points (ceil(n/32) per template): the matrix-core bound pass's stream
     int max_nR = 0;
     int64_t total_tex_points = 0;
+    int64_t total_minutiae = 0;          // rolled minutiae of the shard
     // adc_variant 9: fp16 codebook + |cw|^2 (once), pair-aligned gallery codes / point terms / pair directory (first use), per group B fragments,
     // row constants and the bound pass's records
     DevBuf mf_cw16, mf_cwn, g_codes_p, g_nrm_p, g_tile_meta, mf_bfrag, mf_rowk, mf_rec, mf_stats;
@@ -112,6 +115,9 @@ struct afis_ctx {
     int query_batch = 0;                 // latents per launch group at most; 0 = by shard size (afis_queries_upload); adc_variant 9 places the cuts by latent texture rows
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
+    double search_timeout_s = 600.0;     // bound on every host wait of a search (AFIS_SEARCH_TIMEOUT_S; <= 0: plain hipStreamSynchronize, unbounded)
+    bool overlap_failed = false;         // a wait of the overlapped schedule timed out: later searches keep to one stream
+    double overlap_cell_ratio = 0.037;   // a launch group runs the overlapped schedule while (latent x rolled minutiae cells) <= this x (latent texture rows x rolled texture points); AFIS_OVERLAP_CELL_RATIO
     int64_t rowmax_budget_bytes = 0;     // device memory a launch group's per-pair buffers may take (option rowmax_budget_mb); 0 = 60 % of what hipMemGetInfo reports free
     afis_timing timing = {};
 };
@@ -138,6 +144,46 @@ int materialise(afis_ctx* ctx)
 #define HIPCHK(ctx, call)                                                                                       \
     do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                          \
         return fail(ctx, AFIS_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// Host wait for streams with a deadline: hipStreamQuery on each of them in turn (which also keeps every one of them submitting: with ROCm 7.2 a hipStreamSynchronize
+// of the context's stream ALONE never returned while work it depends on sat on the CU-masked side streams — tools/repro/side_stream_hang.hip), a yield between rounds
+// and a short sleep once the wait is long.  A device that does not come back within search_timeout_s is reported as AFIS_EDEVICE instead of holding the caller's
+// thread for ever; when that happens with side streams in use, the context stops using them (bound_cus off: one stream, the kernels back to back).
+int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, const char* what)
+{
+    if (ctx->search_timeout_s <= 0) {
+        for (hipStream_t st : streams) if (st) HIPCHK(ctx, hipStreamSynchronize(st));
+        return AFIS_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 0;; ++spins) {
+        bool all = true;
+        for (hipStream_t st : streams) {
+            if (!st) continue;
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipErrorNotReady) all = false;
+            else if (e != hipSuccess) return fail(ctx, AFIS_EDEVICE, std::string(what) + ": hipStreamQuery: " + hipGetErrorString(e));
+        }
+        if (all) return AFIS_OK;
+        if ((spins & 255) == 255 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->search_timeout_s) {
+            if (streams.size() > 1) ctx->overlap_failed = true;
+            char msg[256];
+            snprintf(msg, sizeof msg, "%s: the device did not finish within %.0f s (AFIS_SEARCH_TIMEOUT_S)%s", what, ctx->search_timeout_s,
+                     streams.size() > 1 ? "; the overlapped schedule is switched off for this context (bound_cus 0)" : "");
+            return fail(ctx, AFIS_EDEVICE, msg);
+        }
+        if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+// Work queued on the side streams must not outlive a failing search (it reads and writes the context's buffers): armed when the first kernel goes to a side stream,
+// disarmed by the group's own wait; every early return in between drains both streams (bounded).
+struct SideStreamGuard {
+    afis_ctx* ctx; hipStream_t a = nullptr, b = nullptr; bool armed = false;
+    explicit SideStreamGuard(afis_ctx* c) : ctx(c) {}
+    void arm(hipStream_t x, hipStream_t y) { a = x; b = y; armed = true; }
+    void disarm() { armed = false; }
+    ~SideStreamGuard() { if (armed) { const std::string keep = ctx->err; (void)wait_streams(ctx, {a, b}, "draining the side streams after a failed launch group"); ctx->err = keep; } }
+};
 
 template <class T, class A>
 hipError_t upload(DevBuf& b, const std::vector<T, A>& v, hipStream_t s)
@@ -297,10 +343,30 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
     // The default schedule: the power-limited bound pass on half of the chip's CUs, the minutiae stage beside it on the other half (afis_search_resident; -7.6 % per step at 100k
     // templates, profiles/r04_overlap_ab.json).  AFIS_BOUND_CUS overrides (0 = one stream, the kernels back to back).  A runtime that refuses CU masks leaves it off.
     {
+        if (const char* r = getenv("AFIS_OVERLAP_CELL_RATIO")) c->overlap_cell_ratio = atof(r);
+        if (const char* r = getenv("AFIS_SEARCH_TIMEOUT_S")) c->search_timeout_s = atof(r);
         const char* e = getenv("AFIS_BOUND_CUS");
         const int64_t n = e ? atoll(e) : (c->n_cus == 256 ? 128 : 0);          // measured on the whole MI355X (256 CUs); a partitioned device keeps the single stream unless told otherwise
         if (afis_set_option(c, "bound_cus", n) != AFIS_OK) { c->bound_cus = 0; c->err.clear(); }
     }
+    return AFIS_OK;
+}
+
+int afis_device_info(int device_id, char* name, size_t name_cap, char* pci_bus_id, size_t pci_cap, char* uuid_hex, size_t uuid_cap, int* n_cus)
+{
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device_id < 0 || device_id >= n_dev) return AFIS_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return AFIS_EDEVICE;
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (pci_bus_id && pci_cap) { if (hipDeviceGetPCIBusId(pci_bus_id, (int)pci_cap, device_id) != hipSuccess) pci_bus_id[0] = 0; }
+    if (uuid_hex && uuid_cap) {
+        uuid_hex[0] = 0;
+        hipUUID u;
+        if (uuid_cap >= 33 && hipDeviceGetUuid(&u, device_id) == hipSuccess)
+            for (int i = 0; i < 16; ++i) snprintf(uuid_hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+    }
+    if (n_cus) *n_cus = prop.multiProcessorCount;
     return AFIS_OK;
 }
 
@@ -735,7 +801,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     g.tex_ori = ctx->g_tex_ori.as<float>(); g.tex_codes = ctx->g_tex_codes.as<uint4>(); g.tex_codes_cf = nullptr; g.tex_cf_blk = ctx->g_tex_cf_blk.as<int32_t>(); g.empty = ctx->g_empty.as<uint8_t>();
     g.task_ctr = ctx->g_task_ctr.as<int32_t>();
     ctx->max_nR = max_nR;
-    ctx->total_tex_points = (int64_t)NT;
+    ctx->total_tex_points = (int64_t)NT; ctx->total_minutiae = (int64_t)NM;
     ctx->index_base = index_base;
     ctx->committed = true;
     if (ctx->adc_variant == 9 && G > 0) {                                    // the default path's derived streams belong to the resident gallery: built here, not by the first search
@@ -840,7 +906,7 @@ static int build_group(afis_ctx* ctx, const afis_template_view* qs, int nq, Quer
     d.n_tiles = tile_off.back();
     d.tile16_off = grp.tile16_off.as<int32_t>(); d.n_tiles16 = tile16_off.back(); grp.n_lt_rows = lt_off.back();
     d.lt_pad = std::max(kTileRows, (lt_max + kTileRows - 1) / kTileRows * kTileRows);
-    grp.nq = nq; grp.max_nL = max_nL;
+    grp.nq = nq; grp.max_nL = max_nL; grp.n_lm_points = (int64_t)lm_xy.size();
     status_out.insert(status_out.end(), status.begin(), status.end());
     return AFIS_OK;
 }
@@ -1027,7 +1093,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     afis_timing tm = {};
     if (status) for (int i = 0; i < nq_all; ++i) status[i] = q->status[i];
     hipStream_t s = ctx->stream;
-    // The groups run back to back on the stream: no host round trip between them.  Scores of ALL queries stay on the device
+    // The groups run back to back on the stream (the overlapped schedule adds one host round trip per group: the wait for its side streams).  Scores of ALL queries stay on the device
     // ([n_q][G]) for the rank-list kernel; they cross PCIe only when the caller asks for them.
     const size_t n_groups = q->groups.size();
     while (ctx->evpool.size() < n_groups * 10 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
@@ -1073,6 +1139,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     }
     int q0 = 0;
     size_t gi = 0;
+    SideStreamGuard side_guard(ctx);
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
@@ -1107,7 +1174,14 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)((G + n_chunks_auto - 1) / n_chunks_auto);
             HIPCHK(ctx, hipEventRecord(ev[0], s));
             // (a launch of fewer than 2^16 pairs — a single latent against 10k templates — is tail-bound, not power-bound: the side streams only add their hand-overs: 4.40 vs 4.54 ms)
-            const bool overlap = ctx->adc_variant == 9 && ctx->stream_lo != nullptr && n_pairs >= 65536;
+            // ... and a group whose minutiae stage is much heavier than its bound pass (rolled prints of 130 +- 40 minutiae against latents of up to 150: bench.py --workload wide) loses:
+            // the candidate kernels would stay confined to half of the chip long after the pass has ended (measured: 4 215 ms per step overlapped against 3 864 back to back).
+            // The stage's work is priced by its similarity cells (latent x rolled minutiae) against the pass's (latent rows x rolled points): at the headline shapes the candidate
+            // kernel alone takes 0.49 of the bound pass alone for 0.0179 of its cells; on half the CUs it takes twice that, so it still ends with the pass at about twice the headline's ratio.
+            const double cells_m = (double)grp.n_lm_points * (double)ctx->total_minutiae, cells_t = (double)grp.n_lt_rows * (double)ctx->total_tex_points;
+            const bool minutiae_light = cells_m <= ctx->overlap_cell_ratio * cells_t;
+            const bool overlap = ctx->adc_variant == 9 && ctx->stream_lo != nullptr && !ctx->overlap_failed && n_pairs >= 65536 && minutiae_light;
+            grp.overlapped = overlap;
             const bool compact9 = ctx->adc_variant == 9;                  // the recomputation kernel's compact list of the rows that matter (S7 reads a third of the rows)
             auto minutiae_stage = [&]() -> int {
                 HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, s));
@@ -1122,6 +1196,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 // would wait for them to leave).  When the bound pass is done the context's stream joins the list kernel (a second instance drawing from the same counter),
                 // then runs recomputation and texture lists on the whole chip.
                 hipStream_t sl = ctx->stream_lo, sh = ctx->stream_hi;
+                side_guard.arm(sl, sh);
                 HIPCHK(ctx, hipStreamWaitEvent(sl, ev[0], 0));                             // everything of the previous group (this stream's order) is done
                 HIPCHK(ctx, hipStreamWaitEvent(sh, ev[0], 0));
                 int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true, sl, false, diag_row);
@@ -1141,11 +1216,10 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[7], 0));                              // every candidate list exists: help with whatever lists are left
                 HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s, true));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[4], 0));
-                // The host waits for the two side streams here (the context's stream has its whole share of the group queued and keeps the chip busy meanwhile).  Without
-                // it the run hangs: waiting on the context's stream alone — or on an event of a side stream — never returns although every stream drains at once when it
-                // is synchronised itself (observed with ROCm 7.2; hipStreamQuery does not help).
-                HIPCHK(ctx, hipStreamSynchronize(sl));
-                HIPCHK(ctx, hipStreamSynchronize(sh));
+                // The host waits for the two side streams here — one host round trip per launch group; the context's stream has its whole share of the group queued and
+                // keeps the chip busy meanwhile.  Without it the run hangs: waiting on the context's stream alone — or on an event of a side stream — never returns although
+                // every stream drains at once when it is waited for itself (ROCm 7.2; tools/repro/side_stream_hang.hip is the minimal form).  The wait is bounded.
+                { const int rcw = wait_streams(ctx, {sl, sh}, "afis_search: side streams of a launch group"); side_guard.disarm(); if (rcw != AFIS_OK) return rcw; }
             } else {
             if (ctx->adc_variant == 9) {                                    // fp16 matrix-core bound pass + exact recomputation
                 int rc9 = adc_stage_mfma(ctx, grp, false, ev[1], ev[6], true, nullptr, true, diag_row);
@@ -1201,7 +1275,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     }
     ctx->h_diag.assign(std::max<size_t>(n_groups, 1) * kDiagWords, 0ull);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_diag.data(), ctx->diag.p, ctx->h_diag.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    { const int rcw = wait_streams(ctx, {s}, "afis_search"); if (rcw != AFIS_OK) return rcw; }
     {   // where the candidate tasks went, and the clocks the sampled workgroups saw (shader cycles per tick of the constant 100 MHz counter)
         unsigned long long acc[kDiagWords] = {};
         for (size_t i = 0; i < n_groups; ++i) for (int w = 0; w < kDiagWords; ++w) acc[w] += ctx->h_diag[i * kDiagWords + w];
@@ -1216,7 +1290,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             hipEvent_t* ev = &ctx->evpool[i * 10];
             float tot = 0;
             auto el = [&](int a, int b, float& out) -> int { out = 0; HIPCHK(ctx, hipEventElapsedTime(&out, ev[a], ev[b])); return AFIS_OK; };
-            const bool ov = ctx->adc_variant == 9 && ctx->stream_lo != nullptr && (size_t)q->groups[i].nq * (size_t)G >= 65536;
+            const bool ov = q->groups[i].overlapped;
             float t_lut = 0, t_adc = 0, t_tex = 0, t_minu = 0, t_fuse = 0, t_bound = 0, t_ref = 0, t_c = 0, t_g = 0;
             if (el(0, 5, tot)) return AFIS_EDEVICE;
             if (ov) {                                                          // overlapped form: the bound pass's time is its own stream's, the minutiae stage ran beside it; the stage times overlap (their sum exceeds total_ms)
@@ -1247,6 +1321,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         }
     }
     tm.launch_groups = (int32_t)n_groups;
+    for (const QueryGroup& grp : q->groups) tm.overlapped_groups += grp.overlapped ? 1 : 0;
     ctx->timing = tm;
     return AFIS_OK;
 }
@@ -1410,7 +1485,8 @@ int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
     if (!ctx || !name || !value) return AFIS_EINVAL;
     const std::string n(name);
     if (n == "adc_variant") *value = ctx->adc_variant;
-    else if (n == "bound_cus") *value = ctx->stream_lo ? ctx->bound_cus : 0;
+    else if (n == "bound_cus") *value = (ctx->stream_lo && !ctx->overlap_failed) ? ctx->bound_cus : 0;
+    else if (n == "search_timeout_s") *value = (int64_t)ctx->search_timeout_s;
     else if (n == "mf_blocks") *value = ctx->mf_blocks;
     else if (n == "query_batch") *value = ctx->query_batch;
     else if (n == "chunk") *value = ctx->chunk;
@@ -1437,12 +1513,14 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
+    else if (n == "search_timeout_s") { ctx->search_timeout_s = (double)value; }        // <= 0: unbounded hipStreamSynchronize
     else if (n == "bound_cus") {                                           // 0 = off; 32..224 in steps of 32: the bound pass on a stream confined to that many CUs (value / 8 of every XCD), the minutiae stage beside it on the others
         if (value < 0 || value > 224 || (value & 31)) return fail(ctx, AFIS_EINVAL, "bound_cus must be 0 (off), 32, 64, ... 224 (the runtime honours CU masks in steps of 32 CUs: 4 per XCD)");
         if (value > 0 && value + 32 > ctx->n_cus) return fail(ctx, AFIS_EINVAL, "bound_cus must leave at least 32 of the device's CUs to the other stream");
         if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AFIS_EDEVICE, "bound_cus: hipSetDevice failed");
         for (hipStream_t* ps : {&ctx->stream_lo, &ctx->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
         ctx->bound_cus = (int)value;
+        ctx->overlap_failed = false;
         if (value > 0) {
             uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the runtime deals the mask's bits round-robin over the XCDs: the low N bits are N / 8 CUs of each
             const bool whole_xcds = getenv("AFIS_BOUND_WHOLE_XCDS") != nullptr;   // experiment: value / 32 WHOLE XCDs for the bound pass instead of value / 8 CUs of each — measured: the pass takes 287 ms per group on 4 whole XCDs against 235 on 16 CUs of each of the 8 (the power limit acts per XCD); the step falls back to the back-to-back time

@@ -284,6 +284,20 @@ int afis_exchange_all_gather(afis_exchange* x, const void* send, void* recv, siz
     if (!x || !send || !recv) return -1;
     return afis::world_all_gather(x->w, send, recv, bytes, x->err) ? 0 : -2;
 }
+// what RCCL itself says about the communicator: ncclCommCount (ranks), ncclCommCuDevice (the HIP device this rank's communicator is bound to);
+// -1 with the TCP stand-in (no communicator) or on error.  bench.py puts both into its JSON line so that a multi-GPU run certifies itself.
+int afis_exchange_comm_count(const afis_exchange* x)
+{
+    int n = -1;
+    if (!x || x->w.tcp || !x->w.comm) return -1;
+    return ncclCommCount((ncclComm_t)x->w.comm, &n) == ncclSuccess ? n : -1;
+}
+int afis_exchange_comm_device(const afis_exchange* x)
+{
+    int d = -1;
+    if (!x || x->w.tcp || !x->w.comm) return -1;
+    return ncclCommCuDevice((ncclComm_t)x->w.comm, &d) == ncclSuccess ? d : -1;
+}
 const char* afis_exchange_last_error(const afis_exchange* x) { return x ? x->err.c_str() : "null handle"; }
 void afis_exchange_destroy(afis_exchange* x) { if (x) { afis::world_finalize(x->w); delete x; } }
 

@@ -41,12 +41,12 @@ class TemplateView(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("lut_ms", C.c_float), ("adc_ms", C.c_float), ("tex_tail_ms", C.c_float), ("minu_ms", C.c_float), ("fuse_ms", C.c_float), ("topk_ms", C.c_float),
                 ("total_ms", C.c_float), ("adc_launches", C.c_int32), ("adc_lookups", C.c_int64), ("pairs", C.c_int64), ("adc_bound_ms", C.c_float), ("adc_refine_ms", C.c_float),
-                ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("reserved_", C.c_int32),
+                ("cands_ms", C.c_float), ("minu_graph_ms", C.c_float), ("launch_groups", C.c_int32), ("overlapped_groups", C.c_int32),
                 ("minu_tasks", C.c_int64), ("minu_fallback_tasks", C.c_int64), ("minu_tasks_small", C.c_int64), ("minu_tasks_medium", C.c_int64), ("minu_tasks_large", C.c_int64),
                 ("bound_clock_ghz", C.c_float), ("cands_clock_ghz", C.c_float)]
 
 
-EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch", "afis_gallery_reserve",
+EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_device_info", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch", "afis_gallery_reserve",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
            "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
            "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option", "afis_get_option"]
@@ -89,6 +89,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     if hasattr(lib, "afis_get_timing2"):                                # absent from older builds compared by tools/lib_ab.py
         lib.afis_get_timing2.argtypes = [vp, C.POINTER(Timing), C.c_size_t]
     lib.afis_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    if hasattr(lib, "afis_device_info"):                                # round 5
+        lib.afis_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, i32p]
     if hasattr(lib, "afis_get_option"):
         lib.afis_get_option.argtypes = [vp, C.c_char_p, i64p]
     if hasattr(lib, "afis_debug_stage_list"):                           # the parity taps: libafis_hip_test.so (and older builds) only
@@ -156,6 +158,14 @@ class Matcher:
             self.ctx = None
             raise AfisError(f"afis_create failed ({rc}): {self.lib.afis_last_error(None).decode()}")
         self.gallery_files: List[str] = []
+
+    def device_info(self, device: int) -> dict:
+        """What the HIP runtime says about a device (afis_device_info): name, PCI bus id, UUID, compute units."""
+        name = C.create_string_buffer(256); pci = C.create_string_buffer(64); uuid = C.create_string_buffer(40); ncu = C.c_int32(0)
+        rc = self.lib.afis_device_info(device, name, 256, pci, 64, uuid, 40, C.byref(ncu))
+        if rc != 0:
+            raise AfisError(f"afis_device_info({device}) failed ({rc})")
+        return {"name": name.value.decode(errors="replace"), "pci_bus_id": pci.value.decode(errors="replace"), "uuid": uuid.value.decode(errors="replace"), "compute_units": int(ncu.value)}
 
     def close(self):
         if getattr(self, "ctx", None):

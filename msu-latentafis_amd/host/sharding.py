@@ -80,7 +80,7 @@ class CppExchange:
         lib.afis_exchange_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         lib.afis_exchange_last_error.restype = C.c_char_p; lib.afis_exchange_last_error.argtypes = [C.c_void_p]
         lib.afis_exchange_destroy.restype = None; lib.afis_exchange_destroy.argtypes = [C.c_void_p]
-        for f in ("afis_exchange_world", "afis_exchange_rank", "afis_exchange_is_rccl"):
+        for f in ("afis_exchange_world", "afis_exchange_rank", "afis_exchange_is_rccl", "afis_exchange_comm_count", "afis_exchange_comm_device"):
             getattr(lib, f).argtypes = [C.c_void_p]
         err = C.create_string_buffer(512)
         self.h = lib.afis_exchange_create(device, err, 512)
@@ -88,6 +88,8 @@ class CppExchange:
             raise RuntimeError("afis_exchange_create: " + err.value.decode(errors="replace"))
         self.world = lib.afis_exchange_world(self.h); self.rank = lib.afis_exchange_rank(self.h)
         self.is_rccl = bool(lib.afis_exchange_is_rccl(self.h))
+        self.comm_count = int(lib.afis_exchange_comm_count(self.h))         # ncclCommCount of this rank's communicator (-1: the TCP stand-in has none)
+        self.comm_device = int(lib.afis_exchange_comm_device(self.h))       # ncclCommCuDevice
 
     def all_gather(self, block: np.ndarray) -> np.ndarray:
         """block: any contiguous array, the same shape and dtype on every rank -> [world, *block.shape]."""

@@ -230,3 +230,54 @@ def plant_mates(seed: int, gal: PackedGallery, cb: Codebook, latents: List[FPTem
 
 def make_latents(seed: int, n: int, **kw) -> List[FPTemplate]:
     return [make_latent(np.random.default_rng([seed, 3, i]), **kw) for i in range(n)]
+
+
+# ---- off-envelope shapes (tools/offenv_sweep.py, tests/test_gpu_parity.py) --------------------------------------------------------
+# What the reference's reader accepts and the synthetic envelope of SURVEY section 8d never produces: up to 2000 minutiae per template
+# (matcher.cpp:788-790), rolled prints of any size (extraction_rolled.py:105-108 caps nothing), texture templates beyond the scorer's 1000-row clamp
+# (matcher.cpp:544-547), pixel coordinates on both sides of 2047 (where the graph kernels' packed 16-bit arithmetic ends).
+OFFENV_ROLLED_MINUTIAE = [129, 160, 200, 257, 400, 1000, 2000]
+OFFENV_LATENT_MINUTIAE = [65, 100, 128, 200]
+
+
+def _shift_minutiae(t: FPTemplate, dx: int, dy: int) -> None:
+    for m in t.minu:
+        m.x[:] = (m.x.astype(np.int32) + dx).astype(np.int16); m.y[:] = (m.y.astype(np.int32) + dy).astype(np.int16)
+
+
+def make_offenvelope_set(seed: int, n_latents: int, n_rolled: int, cb: Codebook, mates_per_latent: int = 2):
+    """n_latents latents and n_rolled rolled templates off the synthetic envelope: latent minutiae templates of OFFENV_LATENT_MINUTIAE (+-1) minutiae and
+    1001..1900 (or 400..1000) texture rows, rolled minutiae templates of OFFENV_ROLLED_MINUTIAE (+ 0..2) minutiae and 600..1900 texture points; every latent has
+    `mates_per_latent` planted mates among the rolled templates (slots q * mates .. ); half of the templates are translated so that their pixel coordinates straddle 2047.
+    Returns (latents, rolled, {latent: [rolled indices of its mates]})."""
+    rng = np.random.default_rng([seed, 0x0FE])
+    lats: List[FPTemplate] = []
+    shifts = []
+    for q in range(n_latents):
+        nl = int(rng.choice(OFFENV_LATENT_MINUTIAE)) + int(rng.integers(-1, 2))
+        if rng.random() < 0.6: tl, th = 1001, 1900
+        else: tl, th = 400, 1000
+        L = make_latent(rng, n_tex_lo=tl, n_tex_hi=th, n_minu_lo=max(2, nl - int(rng.integers(0, 3))), n_minu_hi=nl)
+        lats.append(L)
+        shifts.append((int(rng.choice([0, 1300, 1500])), int(rng.choice([0, 1280]))))
+    rolled: List[FPTemplate] = []
+    mates: Dict[int, List[int]] = {q: [] for q in range(n_latents)}
+    for g in range(n_rolled):
+        nm = int(rng.choice(OFFENV_ROLLED_MINUTIAE)) + int(rng.integers(0, 3))
+        nm = min(nm, 2000)
+        nt = int(rng.choice([600, 800, 1000, 1001, 1500, 1900]))
+        q = g // mates_per_latent
+        if q < n_latents:
+            R = make_mate(rng, cb, lats[q], frac=float(rng.uniform(0.3, 0.9)), n_minu=nm, n_tex=nt)
+            dx, dy = shifts[q]
+            dx += int(rng.choice([0, 0, 600])); dy += int(rng.choice([0, 0, 700]))      # a mate may sit on the other side of 2047 than its latent: translation-invariant stages must not care
+            _shift_minutiae(R, dx, dy)
+            mates[q].append(g)
+        else:
+            R = make_rolled(rng, cb, n_minu=nm, n_tex=nt)
+            _shift_minutiae(R, int(rng.choice([0, 0, 1300, 1500])), int(rng.choice([0, 1280])))
+        rolled.append(R)
+    for q, L in enumerate(lats):
+        _shift_minutiae(L, *shifts[q])
+        if hasattr(L, "_pool"): del L._pool
+    return lats, rolled, mates

@@ -1255,3 +1255,75 @@ def test_a_search_allocates_before_it_queues_and_never_again(codebook_bytes, tmp
     assert len(allocs["short"]) >= 4, allocs                       # the first search of a context allocates (row maxima x 3, records, candidate lists ...)
     assert allocs["long"] == [] and allocs["fewer"] == [] and allocs["back to back"] == [], allocs
     assert len(allocs["more"]) >= 4, allocs                        # 16 latents per search: larger buffers, once
+
+
+def test_off_envelope_shapes_against_oracle(codebook_bytes, cb, oracle):
+    """A 200-pair slice of tools/offenv_sweep.py: rolled minutiae templates of 129 .. 2000 minutiae, latent ones of 65 .. 200 (matcher.cpp:788-790 allows 2000 per
+    template; extraction_rolled.py:105-108 caps nothing for rolled prints), texture templates beyond the 1000-row clamp (matcher.cpp:544-547), pixel coordinates on
+    both sides of 2047.  Every per-part and fused score against the oracle, bit for bit; the candidate stage must have used all of its routes (the three shape
+    classes of the matrix-core kernel and the any-shape kernel) and every task must be accounted for."""
+    lats, rolled, mates = S.make_offenvelope_set(5, 8, 25, cb)
+    m = M.Matcher(codebook_bytes)
+    for R in rolled: m.gallery_add_dat(T.write_rolled(R))
+    m.gallery_commit(0)
+    res = m.search(lats, k=0, want_parts=True)
+    tm = m.timing()
+    m.close()
+    assert tm["minu_tasks"] == len(lats) * 3 * len(rolled)
+    assert tm["minu_tasks_medium"] > 0 and tm["minu_tasks_large"] > 0 and tm["minu_fallback_tasks"] > 0, tm
+    assert tm["minu_tasks_small"] + tm["minu_tasks_medium"] + tm["minu_tasks_large"] + tm["minu_fallback_tasks"] == tm["minu_tasks"]
+    ocb = oracle.codebook(codebook_bytes)
+    hr = [oracle.rolled(T.write_rolled(g))[0] for g in rolled]
+    n_pos = 0
+    for qi, L in enumerate(lats):
+        hl, _ = oracle.latent(ocb, T.write_latent(L))
+        rc, sc, parts = oracle.search(ocb, hl, hr, tie_mode=1, want_parts=True)
+        got = np.concatenate([res["parts"][qi], res["scores"][qi][:, None]], axis=1)
+        diff = got.view(np.uint32) != parts.view(np.uint32)
+        assert not diff.any(), (qi, np.argwhere(diff)[:4], got[diff][:4], parts[diff][:4])
+        assert all(sc[g] > 0 for g in mates[qi])
+        n_pos += int((sc > 0).sum())
+    assert n_pos >= 2 * len(lats)
+
+
+def test_candidate_shape_classes_lists_match_oracle_traces(codebook_bytes, cb, oracle):
+    """The candidate list (S3: members, order, similarity bits) of pairs in every shape class of k_minu_cands_rt — small (<= 64 x 128), medium (<= 16 384 similarities),
+    large (<= 32 768), at the classes' own borders (rt_max_rows) — and just beyond them (any-shape kernel), against the oracle's stage-0 trace; then the same pairs'
+    scores through the generic kernel alone (option minu_generic) must be the same bits.  matcher.cpp:440-488."""
+    rng = np.random.default_rng(314)
+    # (latent minutiae, rolled minutiae): class borders — 64 x 128 | 65 x 128, 64 x 129 | 128 x 128 (S = 2: 16 640 / 129 = 128), 129 x 128 | 64 x 256 (S = 2: R = 2) |
+    # 65 x 256 (S = 4) | 128 x 256 (S = 4: 33 024 / 257 = 128) | 129 x 256 (fallback) | 256 x 128 (S = 4: 33 024 / 129 = 256) | 200 x 160 | 256 x 129 fallback? (33 024 / 129 = 256: fits) | 257 x 100 (fallback)
+    shapes = [(64, 128), (65, 128), (64, 129), (128, 128), (129, 128), (64, 256), (65, 256), (128, 256), (129, 256), (256, 128), (200, 160), (256, 129), (257, 100), (40, 300), (30, 17)]
+    lat_sizes = sorted({s[0] for s in shapes})
+    lats = {}
+    for nl in lat_sizes:
+        lats[nl] = S.make_latent(rng, n_tex_lo=100, n_tex_hi=120, n_minu_lo=nl, n_minu_hi=nl)
+    gal, pairs = [], []
+    for nl, nr in shapes:
+        gal.append(S.make_mate(rng, cb, lats[nl], frac=0.6, n_minu=nr, n_tex=300)); pairs.append((nl, len(gal) - 1))
+        gal.append(S.make_rolled(rng, cb, n_minu=nr, n_tex=300)); pairs.append((nl, len(gal) - 1))
+    m = M.Matcher(codebook_bytes, taps=True)
+    m.gallery_add(gal); m.gallery_commit(0)
+    ocb = oracle.codebook(codebook_bytes)
+    hr = [oracle.rolled(T.write_rolled(g))[0] for g in gal]
+    n_lists = 0
+    for nl, gi in pairs:
+        hl, _ = oracle.latent(ocb, T.write_latent(lats[nl]))
+        for which in range(3):
+            want = oracle.trace(ocb, hl, hr[gi], which=which, stage=0, tie_mode=1)
+            got = m.debug_stage_list(lats[nl], gi, which, 0)
+            assert (want is None) == (got is None), (nl, gi, which)
+            if want is None: continue
+            ws, wl, wr = want
+            assert np.array_equal(got[1], wl) and np.array_equal(got[2], wr), (nl, gal[gi].minu[0].n, which)
+            assert np.array_equal(got[0].view(np.uint32), ws.view(np.uint32)), (nl, gal[gi].minu[0].n, which)
+            n_lists += 1
+    assert n_lists == 3 * len(pairs)
+    L = [lats[nl] for nl in lat_sizes]
+    fast = m.search(L, k=0, want_parts=True); tm = m.timing()
+    assert tm["minu_tasks_small"] > 0 and tm["minu_tasks_medium"] > 0 and tm["minu_tasks_large"] > 0 and tm["minu_fallback_tasks"] > 0, tm
+    m.set_option("minu_generic", 1)
+    gen = m.search(L, k=0, want_parts=True)
+    assert np.array_equal(fast["parts"].view(np.uint32), gen["parts"].view(np.uint32))
+    assert m.get_option("minu_fast_max_latent") == 256 and m.get_option("minu_fast_max_rolled") == 256 and m.get_option("minu_fast_max_cells") == 32768
+    m.close()
