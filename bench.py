@@ -253,7 +253,7 @@ def main():
     planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
     t_gen = time.perf_counter() - t_gen
 
-    m = M.Matcher(cb_bytes, device=gpu, taps=a.refine_stats)      # --refine-stats reads a parity tap: libafis_hip_test.so
+    m = M.Matcher(cb_bytes, device=gpu, taps=a.refine_stats or 0 <= a.variant < 8)      # --refine-stats reads a parity tap, --variant 0..7 runs a reference kernel: libafis_hip_test.so
     if a.variant >= 0: m.set_option("adc_variant", a.variant)
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)

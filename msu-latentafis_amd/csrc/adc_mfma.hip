@@ -292,190 +292,6 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
     if (sampler) { atomicAdd(&diag[kDiagBoundClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagBoundWall], (unsigned long long)wall_clock64() - wall0); }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The bound pass as a two-stage software pipeline (option mf_kernel = 1).  Same arithmetic, same records, bit-identical results; what changes is WHEN a wave does
-// what.  In k_adc_mfma a tile is a chain: operand reads (LDS latency) -> 12 MFMAs -> their last result -> 52 tracking VALU -> the next tile's reads; the matrix pipe
-// only stays busy while ANOTHER wave of the SIMD happens to be in its MFMA phase.  Here a wave retires tile i - 1 (tracking, template end) WHILE the matrix pipe works on
-// its tile i, and the operands of tile i + 1 are already on their way: two accumulator sets and two operand sets, 8 waves x 2 row blocks (two waves per SIMD, <= 256
-// registers), stages of 4 tiles, the decode of the next stage in the middle of a stage (under the MFMAs) instead of at its end.  A workgroup covers 16 row blocks.
-// ---------------------------------------------------------------------------------------------------------------------------------
-constexpr int kPipeRowBlocks = 16;
-__global__ __launch_bounds__(512) void k_adc_mfma_pipe(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
-                                                         const int2* __restrict__ tile_meta, const int32_t* __restrict__ tile0, const uint4* __restrict__ cw16,
-                                                         const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
-                                                         int n_rg, int chunk, uint2* __restrict__ rec)
-{
-    constexpr int NB = 2, kThreads = 512, kStageTiles = 4;
-    __shared__ uint4 s_cw[kM * kK];                                     // 64 KB
-    __shared__ M12Stage<kStageTiles> s_st[2];                           // 2 x 25 KB
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
-    const int t_lo = chunk_id * chunk, t_hi = min(g.G, t_lo + chunk);
-    if (t_lo >= t_hi) return;
-    const int tile_lo = tile0[t_lo], tile_hi = tile0[t_hi];
-    const int n_tiles = tile_hi - tile_lo;
-    if (n_tiles <= 0) return;
-    const int n_stages = (n_tiles + kStageTiles - 1) / kStageTiles;
-    for (int i = tid; i < kM * kK; i += kThreads) s_cw[i] = cw16[i];
-
-    const int h = lane >> 5, col = lane & 31;
-    const int rb0 = rg * kPipeRowBlocks + wave * NB;
-    const bool wave_ok = rb0 < n_rb;
-    half8 bf[NB][6];
-    float Tg[NB]; bool force[NB];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        const int rb = rb0 + blk;
-#pragma unroll
-        for (int kk = 0; kk < 6; ++kk) {
-            const uint4 v = rb < n_rb ? bfrag[((size_t)rb * 6 + kk) * 64 + lane] : make_uint4(0, 0, 0, 0);
-            bf[blk][kk] = __builtin_bit_cast(half8, v);
-        }
-        const int row = rb * 32 + col;
-        const float4 rk = row < n_rows ? rowk[row] : make_float4(0.f, 0.f, 0.f, 0.f);
-        Tg[blk] = rk.z; force[blk] = rk.w != 0.0f;
-    }
-    const int pp = tid & 31, pQ = (tid >> 5) & 3, pj = tid >> 7;
-    const bool meta_thread = pQ == 1 && pp == 0;
-    struct Pf { uint32_t code; float nrm; int2 meta; };
-    auto fetch = [&](int s, Pf& f) {
-        const int tile = tile_lo + kStageTiles * s + pj;
-        f.code = 0u; f.nrm = kMfNeg; f.meta = make_int2(0, 0);
-        if (tile < tile_hi) {
-            const size_t e = (size_t)tile * 32 + pp;
-            f.code = reinterpret_cast<const uint32_t*>(codes_p)[e * 4 + pQ];
-            if (pQ == 0) f.nrm = nrm_p[e];
-            if (meta_thread) f.meta = tile_meta[tile];
-        }
-    };
-    auto decode = [&](int buf, const Pf& f) {
-        uint4 w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = s_cw[(4 * pQ + i) * kK + ((f.code >> (8 * i)) & 255u)];
-        M12Stage<kStageTiles>& st = s_st[buf];
-        st.a[pj][3 * pQ + 0][pp] = make_uint4(w[0].x, w[0].y, w[0].z, w[1].x);
-        st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
-        st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
-        if (pQ == 0) st.nrm[pj][pp] = f.nrm;
-        if (meta_thread) st.meta[pj] = f.meta;
-    };
-    Pf pf_cur, pf_nxt;
-    fetch(0, pf_cur);
-    __syncthreads();
-    decode(0, pf_cur);
-    fetch(1, pf_cur);
-    __syncthreads();
-
-    float m[NB][8], tb[NB], ts[NB], tu[NB];
-    auto reset = [&]() {
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) m[blk][k] = kMfNeg;
-            tb[blk] = ts[blk] = tu[blk] = kMfNeg;
-        }
-    };
-    reset();
-    auto track = [&](int blk, const floatx16& X, uint32_t gid) {
-        float lo = max3f(X[0], X[1], X[2]), hi = max3f(X[8], X[9], X[10]);
-        lo = max3f(lo, X[3], X[4]); hi = max3f(hi, X[11], X[12]);
-        lo = max3f(lo, X[5], X[6]); hi = max3f(hi, X[13], X[14]);
-        lo = fmaxf(lo, X[7]); hi = fmaxf(hi, X[15]);
-        const float el = u2f((f2u(lo) & ~63u) | gid), eh = u2f((f2u(hi) & ~63u) | (gid + 1u));
-        tu[blk] = med3f(ts[blk], el, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], el); tb[blk] = fmaxf(tb[blk], el);
-        tu[blk] = med3f(ts[blk], eh, tu[blk]); ts[blk] = med3f(tb[blk], ts[blk], eh); tb[blk] = fmaxf(tb[blk], eh);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) m[blk][k] = max3f(m[blk][k], X[k], X[k + 8]);
-    };
-    typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
-    auto finish_template = [&](int tmpl) {                               // as in k_adc_mfma: the two lane halves of a row are merged, one record per (template, row)
-        uint32_t val[NB], dsc[NB];
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            float b3 = kMfNeg, s3 = kMfNeg, u3 = kMfNeg;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float e = u2f((f2u(m[blk][k]) & ~7u) | (uint32_t)k);
-                u3 = med3f(s3, e, u3); s3 = med3f(b3, s3, e); b3 = fmaxf(b3, e);
-            }
-            const float thr = fminf(tb[blk], b3) - Tg[blk];
-            const bool many = (tu[blk] >= thr) | (u3 >= thr) | force[blk];
-            val[blk] = f2u(b3);
-            dsc[blk] = (f2u(tb[blk]) & 63u) | ((f2u(ts[blk]) & 63u) << 6) | ((f2u(b3) & 7u) << 12) | ((f2u(s3) & 7u) << 15) |
-                       ((ts[blk] >= thr ? 1u : 0u) << 18) | ((s3 >= thr ? 1u : 0u) << 19) | ((many ? 1u : 0u) << 20);
-        }
-        const uint2v rv = __builtin_amdgcn_permlane32_swap(val[0], val[1], false, false);
-        const uint2v rd = __builtin_amdgcn_permlane32_swap(dsc[0], dsc[1], false, false);
-        const float TgM = h ? Tg[1] : Tg[0];
-        const float v0 = u2f(rv.x), v1 = u2f(rv.y);
-        const bool sw = v1 > v0;
-        const float V = fmaxf(v0, v1), vo = fminf(v0, v1);
-        const uint32_t dp = sw ? rd.y : rd.x, dn = sw ? rd.x : rd.y;
-        const bool in_o = vo >= V - TgM;
-        const bool o_more = (dn & (7u << 18)) != 0u;
-        const uint32_t cell = (dn & 63u) | (((dn >> 12) & 7u) << 6);
-        const uint32_t D = (dp & 0x1fffffu) | ((sw ? 1u : 0u) << 21) | ((in_o ? 1u : 0u) << 22) | (cell << 23) | (((in_o & o_more) ? 1u : 0u) << 20);
-        if (rb0 + h < n_rb) rec[(size_t)tmpl * R_pad + (size_t)(rb0 + h) * 32 + col] = make_uint2(f2u(V), D);
-        reset();
-    };
-    struct Ops { half8 af[6]; floatx16 nrm; int2 mv; };
-    auto load_ops = [&](const M12Stage<kStageTiles>& st, int j, Ops& o) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float4 v = *reinterpret_cast<const float4*>(&st.nrm[j][8 * q4 + 4 * h]);
-            o.nrm[4 * q4] = v.x; o.nrm[4 * q4 + 1] = v.y; o.nrm[4 * q4 + 2] = v.z; o.nrm[4 * q4 + 3] = v.w;
-        }
-        o.mv = st.meta[j];
-#pragma unroll
-        for (int kk = 0; kk < 6; ++kk) o.af[kk] = __builtin_bit_cast(half8, st.a[j][2 * kk + h][col]);
-    };
-    auto mfma_tile = [&](const Ops& o, floatx16 (&X)[NB]) {
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) X[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.af[0], bf[blk][0], o.nrm, 0, 0, 0);
-#pragma unroll
-        for (int kk = 1; kk < 6; ++kk) {
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) X[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(o.af[kk], bf[blk][kk], X[blk], 0, 0, 0);
-        }
-    };
-    auto retire = [&](const floatx16 (&X)[NB], int2 mv) {               // tracking of a finished tile, and the record when it ends its template
-        const int my = __builtin_amdgcn_readfirstlane(mv.y);
-        const uint32_t gid = (uint32_t)(2 * (my & 255));
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) track(blk, X[blk], gid);
-        if (my & 256) finish_template(__builtin_amdgcn_readfirstlane(mv.x));
-    };
-    // one MFMA, then a few of the independent vector instructions of the tile being retired: the pattern the scheduler is asked to keep
-    auto interleave_hint = [&]() {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0); }
-    };
-
-    floatx16 XA[NB], XB[NB];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) XB[blk][r] = kMfNeg;                // "the tile before the first": nothing to track
-    int2 mvP = make_int2(0, 0);
-    for (int s = 0; s < n_stages; ++s) {
-        fetch(s + 2, pf_nxt);
-        const M12Stage<kStageTiles>& st = s_st[s & 1];
-        if (wave_ok) {
-            Ops o0, o1;
-            load_ops(st, 0, o0);
-            mfma_tile(o0, XA); load_ops(st, 1, o1); retire(XB, mvP); interleave_hint();
-            mfma_tile(o1, XB); if (s + 1 < n_stages) decode((s + 1) & 1, pf_cur); const int2 mv0 = o0.mv; load_ops(st, 2, o0); retire(XA, mv0); interleave_hint();
-            mfma_tile(o0, XA); const int2 mv1 = o1.mv; load_ops(st, 3, o1); retire(XB, mv1); interleave_hint();
-            mfma_tile(o1, XB); retire(XA, o0.mv); interleave_hint();
-            mvP = o1.mv;
-        } else if (s + 1 < n_stages) decode((s + 1) & 1, pf_cur);
-        pf_cur = pf_nxt;
-        __syncthreads();
-    }
-    if (wave_ok) retire(XB, mvP);
-}
-
 // ---- launcher ----------------------------------------------------------------------------------------------------------------
 hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float* nrm_p, const void* tile_meta, const int32_t* tile0, const void* cw16,
                            const void* bfrag, const void* rowk, int n_rows, int n_rb, int R_pad, int chunk, int blocks_per_wave, void* rec, unsigned long long* diag, hipStream_t stream)
@@ -485,19 +301,14 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
     const int n_rg = (n_rb + kM12RowBlocks - 1) / kM12RowBlocks;
     const long long blocks = (long long)n_rg * n_chunks;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (blocks_per_wave == 102) {                                       // the software-pipelined form: workgroups of 16 row blocks
-        const int n_rg16 = (n_rb + kPipeRowBlocks - 1) / kPipeRowBlocks;
-        const long long b16 = (long long)n_rg16 * n_chunks;
-        if (b16 > 0x7fffffffLL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_adc_mfma_pipe, dim3((unsigned)b16), dim3(512), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
-                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg16, chunk, (uint2*)rec);
-        return hipGetLastError();
-    }
-    if (blocks_per_wave == 3)
+#ifdef AFIS_EXPERIMENTAL_KERNELS                                          // three row blocks per wave (8 waves, 224 registers): -1 % alone on the chip, +2 % in the default schedule; test library only
+    if (blocks_per_wave == 3) {
         hipLaunchKernelGGL(k_adc_mfma<3>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 3)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
                            (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag);
-    else
-        hipLaunchKernelGGL(k_adc_mfma<2>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 2)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
+        return hipGetLastError();
+    }
+#endif
+    hipLaunchKernelGGL(k_adc_mfma<2>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 2)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
                            (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag);
     return hipGetLastError();
 }

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_MINU_WA
 hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const MinuCand* cands, const int32_t* cand_n,
                                  float* parts, short4* corr_out, int32_t* corr_n, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream, bool join)
 {
-    // join: a second instance of the kernel on another stream that draws from the SAME list counter as one already running (afis_api.cpp, option bound_cus): no reset
+    // join: a second instance of the kernel on another stream that draws from the SAME list counter as one already running (afis_search.cpp, option bound_cus): no reset
     const long long n_tasks = (long long)q.nq * 3 * g.G;
     if (n_tasks <= 0) return hipSuccess;
     if (n_tasks > 0x7ffffff0LL || !g.task_ctr) return hipErrorInvalidValue;

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
     int n_done = 0;                                                                 // tasks this workgroup completed (thread 0's count)
     const int n_work = ctl[kCls];
     // Rolled templates are DRAWN from a counter, not dealt by stride: the kernel may start on the part of the chip the (CU-masked) bound pass leaves free and spread
-    // over the rest when that finishes (afis_api.cpp, option bound_cus): workgroups that start late must not find a fixed share of the work waiting for them.
+    // over the rest when that finishes (afis_search.cpp, option bound_cus): workgroups that start late must not find a fixed share of the work waiting for them.
     for (;;) {
         if (tid == 0) sm.ticket = atomicAdd(&ctl[4 + kCls], 1);
         __syncthreads();

@@ -69,7 +69,7 @@ hipError_t launch_pq_encode(const float* des, long long n, const float* codeword
     return hipGetLastError();
 }
 
-// Descriptors re-laid on the device as operand fragments of v_mfma_f32_16x16x4_f32 (minu.hip; layout: afis_api.cpp::fragment_tiles, which still does the latents' on the host):
+// Descriptors re-laid on the device as operand fragments of v_mfma_f32_16x16x4_f32 (minu.hip; layout: afis_ctx.h::fragment_tiles, which still does the latents' on the host):
 // template t (rows off[t] .. off[t+1]) becomes ceil(n/16) tiles of 6 x 64 float4; lane l of load v holds des[16*tile + (l&15)][4*(4v + c) + (l>>4)], c = 0..3; rows past the
 // template's end are zero.  One workgroup per template; the gallery's fragments (34 KB per template) no longer cross PCIe at commit.
 __global__ __launch_bounds__(256) void k_fragment_tiles(const float* __restrict__ des, const int32_t* __restrict__ off, const int32_t* __restrict__ tile_off, float4* __restrict__ frag)

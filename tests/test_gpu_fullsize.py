@@ -65,10 +65,15 @@ def test_config1_one_latent_vs_10k(codebook_bytes, cb, oracle):
     lats = S.make_latents(seed, 1)
     gal = S.make_packed_gallery(seed, G, cb)
     planted = S.plant_mates(seed, gal, cb, lats, G=G, n_partial=5)
-    m = M.Matcher(codebook_bytes)
-    m.gallery_add_packed(gal); m.gallery_commit(0)
-    res = m.search(lats, k=24, want_parts=True)
+    mp = M.Matcher(codebook_bytes)                                     # the product library ...
+    mp.gallery_add_packed(gal); mp.gallery_commit(0)
+    res = mp.search(lats, k=24, want_parts=True)
     _check_properties(res, planted, G, 24)
+    mp.set_option("adc_variant", 8)
+    assert np.array_equal(mp.search(lats, k=0)["scores"], res["scores"])
+    mp.close()
+    m = M.Matcher(codebook_bytes, taps=True)                            # ... and the test library with the direct reference kernels (adc_variant 1, 6, 7)
+    m.gallery_add_packed(gal); m.gallery_commit(0)
     for v in (1, 6, 7, 8, 9):                                           # other ADC variants (8 / 9 = bound pass + exact evaluation), same bits
         m.set_option("adc_variant", v)
         assert np.array_equal(m.search(lats, k=0)["scores"], res["scores"]), v

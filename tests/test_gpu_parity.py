@@ -32,7 +32,8 @@ def small(cb):
 
 
 def _matcher(codebook_bytes, gal, variant=None, taps=False):
-    m = M.Matcher(codebook_bytes, taps=taps)        # taps: libafis_hip_test.so (the product objects + afis_debug_*); default = the product library
+    taps = taps or (variant is not None and variant < 8)   # the direct exact kernels (adc_variant 0-3, 6, 7: the second witness of the row maxima) are built into the test library only
+    m = M.Matcher(codebook_bytes, taps=taps)        # taps: libafis_hip_test.so (the product objects + afis_debug_* + the reference kernels); default = the product library
     if variant is not None:
         m.set_option("adc_variant", variant)
     m.gallery_add(gal)
@@ -338,6 +339,10 @@ def test_c_abi_error_behaviour(codebook_bytes, cb, small):
         m.gallery_commit(0)
     with pytest.raises(M.AfisError):
         m.set_option("adc_variant", 4)                               # removed variants
+    with pytest.raises(M.AfisError, match="libafis_hip_test"):
+        m.set_option("adc_variant", 7)                               # the direct kernels are reference kernels of the test library, not product surface
+    with pytest.raises(M.AfisError, match="libafis_hip_test"):
+        m.set_option("mf_blocks", 3)
     with pytest.raises(M.AfisError):
         m.set_option("no_such_option", 1)
     with pytest.raises(M.AfisError, match="96"):
@@ -623,9 +628,12 @@ def medium(cb):
 def test_medium_properties_and_sharding(codebook_bytes, cb, oracle, medium):
     lats, gal, planted = medium
     G = gal.G
-    m = M.Matcher(codebook_bytes)
+    m = M.Matcher(codebook_bytes, taps=True)                            # the test library: step (5) compares with the direct reference kernels
     m.gallery_add_packed(gal); m.gallery_commit(0)
     r1 = m.search(lats, k=24, want_parts=True)
+    mp = M.Matcher(codebook_bytes); mp.gallery_add_packed(gal); mp.gallery_commit(0)      # the product library gives the same bits
+    rp = mp.search(lats, k=24, want_parts=True); mp.close()
+    assert np.array_equal(rp["parts"].view(np.uint32), r1["parts"].view(np.uint32)) and np.array_equal(rp["topk_idx"], r1["topk_idx"])
     # (1) idempotence + resident == one-shot
     qh = m.upload_queries(lats)
     r2 = m.search_resident(qh, k=24, want_scores=True, want_parts=True)
@@ -1093,16 +1101,16 @@ def test_results_do_not_depend_on_the_schedule(codebook_bytes, cb, medium):
 
 
 def test_bound_pass_kernel_forms_are_bit_identical(codebook_bytes, cb, oracle, small):
-    """The matrix-core bound pass exists in three forms — two row blocks per wave (default), three (mf_blocks 3: a third less LDS operand traffic per MFMA) and the
-    two-stage software pipeline (mf_blocks 102) — which differ only in when a wave does what.  Row maxima / first arg-maxima of each against the oracle, and the
-    searches' per-part scores and rank lists against the default form's, bit for bit; workgroup chunks of 1 and 3 templates exercise the stage / template edges
-    of the 4-tile stages the two alternative forms use."""
+    """The matrix-core bound pass exists in two forms — two row blocks per wave (default) and three (mf_blocks 3: a third less LDS operand traffic per MFMA; test
+    library only) — which differ only in when a wave does what (round 4's third form, a two-stage software pipeline, measured 6 % slower and was deleted in round 5).
+    Row maxima / first arg-maxima against the oracle, and the searches' per-part scores and rank lists against the default form's, bit for bit; workgroup chunks of 1
+    and 3 templates exercise the stage / template edges of the 4-tile stages the alternative form uses."""
     lats, gal = small
     m = _matcher(codebook_bytes, gal, taps=True)
     ocb = oracle.codebook(codebook_bytes)
     hl, hr = cases.to_orc(oracle, ocb, lats, gal)
     want = m.search(lats, k=10, want_parts=True)
-    for mb in (3, 102):
+    for mb in (3,):
         m.set_option("mf_blocks", mb)
         for chunk in (0, 1, 3):
             m.set_option("chunk", chunk)
@@ -1113,8 +1121,9 @@ def test_bound_pass_kernel_forms_are_bit_identical(codebook_bytes, cb, oracle, s
                 val, arg = m.debug_texture_rowmax(lats[qi], g)
                 oval, oarg = oracle.texture_rowmax(ocb, hl[qi], hr[g])
                 assert np.array_equal(val.view(np.uint32), oval.view(np.uint32)) and np.array_equal(arg, oarg), (mb, qi, g)
-    with pytest.raises(M.AfisError):
-        m.set_option("mf_blocks", 4)
+    for bad in (4, 102):
+        with pytest.raises(M.AfisError):
+            m.set_option("mf_blocks", bad)
     m.close()
 
 

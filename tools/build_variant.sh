@@ -14,7 +14,7 @@ esac
 mkdir -p ../../tools/exp
 /opt/rocm/bin/hipcc $FL $EXTRA -c $SRC -o /tmp/variant_${NAME}.o
 OBJS=""
-for o in adc.o adc_mfma.o adc_refine.o graph.o minu.o pq_encode.o afis_api.o template_io.o; do
+for o in adc.o adc_mfma.o adc_refine.o graph.o minu.o pq_encode.o afis_api.o afis_gallery.o afis_search.o template_io.o; do
   if [ "$o" = "$BASE.o" ]; then OBJS="$OBJS /tmp/variant_${NAME}.o"; else OBJS="$OBJS $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../../tools/exp/libafis_${NAME}.so
