@@ -127,7 +127,7 @@ int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
     else if (n == "minu_generic") *value = ctx->minu_generic;
     else if (n == "minu_fast_max_latent") *value = rt_class_max_latent(4);            // read-only: what the fast candidate kernel's largest shape class takes (afis_device.h: rt_max_rows)
     else if (n == "minu_fast_max_rolled") *value = rt_class_max_rolled(4);
-    else if (n == "minu_fast_max_cells") *value = 8192 * 4;
+    else if (n == "minu_fast_max_cells") *value = rt_class_simi_floats(4);
     else if (n == "mf_stats") *value = ctx->mf_collect_stats;
     else if (n == "rowmax_budget_mb") *value = ctx->rowmax_budget_bytes >> 20;
     else if (n == "lut_dtype") *value = 32;

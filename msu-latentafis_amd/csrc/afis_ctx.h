@@ -130,7 +130,9 @@ inline int fail(afis_ctx* ctx, int code, const std::string& msg)
 }
 #define HIPCHK(ctx, call)                                                                                       \
     do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                          \
-        return fail(ctx, AFIS_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+        return fail(ctx, AFIS_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_) + (e_ == hipErrorOutOfMemory ?                                      \
+            " (device memory: a launch group's buffers are sized from the memory that was free when the queries were uploaded - with several contexts or processes on one "  \
+            "device lower option rowmax_budget_mb or query_batch)" : "")); } while (0)
 
 template <class T, class A>
 inline hipError_t upload(DevBuf& b, const std::vector<T, A>& v, hipStream_t s)

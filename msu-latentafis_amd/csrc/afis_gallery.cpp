@@ -2,6 +2,7 @@
 // the PQ encoder entry points, and afis_gallery_commit: SoA packing, upload through pinned buffers, the device-side derived streams.
 // Replaces the per-pair load_FP_template(rolled) of matching/matcher.cpp:173 / :278: parse once, keep the shard resident in HBM.
 #include "afis_ctx.h"
+#include <sys/stat.h>
 
 using namespace afis;
 
@@ -13,7 +14,7 @@ int materialise(afis_ctx* ctx)
     if (!ctx->pend) return AFIS_OK;
     std::string err;
     HostGallery add;
-    if (!read_gallery_container(ctx->pend->path, ctx->pend_first, ctx->pend_count, add, nullptr, nullptr, err)) return fail(ctx, AFIS_EFORMAT, "gallery container: " + err);
+    if (!copy_from_mapping(*ctx->pend, ctx->pend_first, ctx->pend_count, add, err)) return fail(ctx, AFIS_EFORMAT, "gallery container: " + err);   // from the mapping afis_gallery_load validated: no second open of the path
     ctx->hg = std::move(add);
     ctx->pend.reset(); ctx->pend_first = ctx->pend_count = 0;
     return AFIS_OK;
@@ -68,7 +69,7 @@ void free_gallery_dev(afis_ctx* c)
 {
     c->g_minu_off.release(); c->g_minu_xy.release(); c->g_minu_ori.release(); c->g_minu_des.release(); c->g_minu_frag.release(); c->g_minu_tile_off.release();
     c->g_tex_off.release(); c->g_tex_xy.release(); c->g_tex_ori.release(); c->g_tex_codes.release(); c->g_tex_codes_cf.release(); c->g_tex_cf_blk.release(); c->g_tex_codes_q.release(); c->g_tex_q_blk.release(); c->g_tex_t32_blk.release(); c->g_empty.release(); c->g_task_ctr.release();
-    c->g_codes_p.release(); c->g_nrm_p.release(); c->g_tile_meta.release(); c->mf_gal_built = false;
+    c->g_codes_p.release(); c->g_nrm_p.release(); c->g_tile_meta.release(); c->mf_gal_built = false; c->codes_cf_built = false; c->codes_q_built = false;
 }
 
 }  // namespace afis
@@ -385,10 +386,26 @@ static hipError_t upload_bulk(PinnedPipe& pp, DevBuf& b, const void* src, size_t
     return hipSuccess;
 }
 
+static int commit_shard(afis_ctx* ctx, int64_t index_base);
+
+// A failed commit leaves the context as it was before the call: not committed, no half-uploaded shard on the device, the staged templates (host arrays or the mapped
+// container) still in place, so that the caller may retry or destroy.
 int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
 {
     if (!ctx) return AFIS_EINVAL;
     if (ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_gallery_commit: already committed");
+    const int rc = commit_shard(ctx, index_base);
+    if (rc != AFIS_OK) {
+        ctx->committed = false;
+        (void)hipStreamSynchronize(ctx->stream);
+        free_gallery_dev(ctx);
+        ctx->gal = GalleryDev();
+    }
+    return rc;
+}
+
+static int commit_shard(afis_ctx* ctx, int64_t index_base)
+{
     // The staged shard as plain arrays: ctx->hg, or the mapped container's range (offsets rebased to the shard's first point).
     HostGallery& hg = ctx->hg;
     const GalleryMapping* gm = ctx->pend.get();
@@ -404,6 +421,10 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     const uint8_t* s_empty = gm ? gm->empty + ctx->pend_first : hg.empty.data();
     if (G > 0x7fffffff / 8 || NM > 0x7fffffffull || NT > 0x7fffffffull)
         return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for 32-bit point offsets; split the gallery into more shards");
+    if (gm && gm->fd_ >= 0) {                                               // the arrays are read straight from the mapping, by several threads: a file truncated since afis_gallery_load would fault
+        struct stat st;
+        if (fstat(gm->fd_, &st) != 0 || (size_t)st.st_size < gm->len_) return fail(ctx, AFIS_EFORMAT, "gallery container: " + gm->path + " was truncated after it was loaded");
+    }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool clock_it = getenv("AFIS_COMMIT_TIMING") != nullptr;           // development aid: where the commit's time goes, on stderr
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -484,7 +505,7 @@ int afis_gallery_commit(afis_ctx* ctx, int64_t index_base)
     ctx->committed = true;
     if (ctx->adc_variant == 9 && G > 0) {                                    // the default path's derived streams belong to the resident gallery: built here, not by the first search
         int rcg = ensure_mf_gallery(ctx, ctx->stream);
-        if (rcg != AFIS_OK) { ctx->committed = false; return rcg; }
+        if (rcg != AFIS_OK) return rcg;
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         lap("bound pass's code stream");
     }

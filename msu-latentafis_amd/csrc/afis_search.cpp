@@ -31,8 +31,10 @@ int64_t group_budget_bytes(const afis_ctx* ctx)
 // thread for ever; when that happens with side streams in use, the context stops using them (bound_cus off: one stream, the kernels back to back).
 int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, const char* what)
 {
-    if (ctx->search_timeout_s <= 0) {
-        for (hipStream_t st : streams) if (st) HIPCHK(ctx, hipStreamSynchronize(st));
+    if (ctx->search_timeout_s <= 0) {                                      // unbounded: every stream of the list in turn (the side streams come first)
+        static const bool last_only = getenv("AFIS_WAIT_CTX_SYNC_ONLY") != nullptr;     // experiment (tools/repro/README.md): round 4's hanging form, a blocking wait on the context's stream alone
+        hipStream_t last = nullptr; for (hipStream_t st : streams) last = st;
+        for (hipStream_t st : streams) if (st && (!last_only || st == last)) HIPCHK(ctx, hipStreamSynchronize(st));
         return AFIS_OK;
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -334,7 +336,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     afis_timing tm = {};
     if (status) for (int i = 0; i < nq_all; ++i) status[i] = q->status[i];
     hipStream_t s = ctx->stream;
-    // The groups run back to back on the stream (the overlapped schedule adds one host round trip per group: the wait for its side streams).  Scores of ALL queries stay on the device
+    // The groups run back to back on the stream(s): no host round trip between them.  Scores of ALL queries stay on the device
     // ([n_q][G]) for the rank-list kernel; they cross PCIe only when the caller asks for them.
     const size_t n_groups = q->groups.size();
     while (ctx->evpool.size() < n_groups * 10 + 2) { hipEvent_t e; HIPCHK(ctx, hipEventCreate(&e)); ctx->evpool.push_back(e); }
@@ -460,11 +462,12 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[7], 0));                              // every candidate list exists: help with whatever lists are left
                 HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s, true));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[4], 0));
-                // The host waits for the two side streams here — one host round trip per launch group; the context's stream has its whole share of the group queued and
-                // keeps the chip busy meanwhile.  Without it the run hangs: waiting on the context's stream alone — or on an event of a side stream — never returns although
-                // every stream drains at once when it is waited for itself (ROCm 7.2; tools/repro/side_stream_hang.hip is the minimal form).  The wait is bounded.
-                static const bool no_group_wait = getenv("AFIS_NO_GROUP_WAIT") != nullptr;   // experiment (tools/repro): leave the side streams to the search's final wait, which then polls all three
-                if (!no_group_wait) { const int rcw = wait_streams(ctx, {sl, sh}, "afis_search: side streams of a launch group"); side_guard.disarm(); if (rcw != AFIS_OK) return rcw; }
+                // No host wait here: the groups of a search follow one another on the three streams through events alone, and the search's final wait polls ALL THREE streams
+                // (wait_streams).  Round 4 blocked on the two side streams after every group because hipStreamSynchronize of the context's stream alone never returned with
+                // ROCm 7.2 while work it depends on sat on the CU-masked side streams; a hipStreamQuery loop does return (profiles/r05_side_stream_waits.json: 46.11 / 46.09 / 46.03
+                // queries/s without the group wait polling one stream / all three / with the group wait), and it is bounded.  AFIS_GROUP_WAIT=1 restores the per-group wait.
+                static const bool group_wait = getenv("AFIS_GROUP_WAIT") != nullptr;
+                if (group_wait) { const int rcw = wait_streams(ctx, {sl, sh}, "afis_search: side streams of a launch group"); side_guard.disarm(); if (rcw != AFIS_OK) return rcw; }
                 any_overlap = true;
             } else {
             if (ctx->adc_variant == 9) {                                    // fp16 matrix-core bound pass + exact recomputation
@@ -526,8 +529,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     ctx->h_diag.assign(std::max<size_t>(n_groups, 1) * kDiagWords, 0ull);
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_diag.data(), ctx->diag.p, ctx->h_diag.size() * 8, hipMemcpyDeviceToHost, s));
     {
-        static const int final_wait = getenv("AFIS_FINAL_WAIT") ? atoi(getenv("AFIS_FINAL_WAIT")) : 0;     // experiment: 1 = the final wait also polls the side streams
-        const int rcw = (final_wait == 1 && any_overlap) ? wait_streams(ctx, {ctx->stream_lo, ctx->stream_hi, s}, "afis_search") : wait_streams(ctx, {s}, "afis_search");
+        const int rcw = any_overlap ? wait_streams(ctx, {ctx->stream_lo, ctx->stream_hi, s}, "afis_search") : wait_streams(ctx, {s}, "afis_search");
         side_guard.disarm();
         if (rcw != AFIS_OK) return rcw;
     }

@@ -10,6 +10,7 @@
 // Canonical arithmetic (see oracle/afis_oracle.cpp): descriptor dot products are k-ascending fmaf chains, row/column sums are
 // index-ascending, the normalisation is evaluated in double exactly as the reference's expression promotes it.
 #include "afis_device.h"
+#include <cstdlib>
 
 namespace afis {
 
@@ -275,10 +276,11 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 //     out for few instructions per element (thread = column x row phase; <= 32 keys per thread stay in registers between the passes).
 //   * the classes: what bounds a task is its similarity matrix in LDS and the 32 keys per thread.  S = 1 (round 2's kernel): <= 64 latent x
 //     <= 128 rolled minutiae, 37.7 KB, four workgroups per CU; S = 2: <= 16 384 similarities (128 x 128, 64 x 256 ...), 73 KB, two per CU;
-//     S = 4: <= 32 768 (128 x 256, 160 x 200, 256 x 128 ...), 138 KB, one 16-wave workgroup per CU.  rt_max_rows(S, nR) (afis_device.h) is the
+//     S = 4: <= 39 168 incl. the padding column (152 x 256, 160 x 240, 256 x 150 ...), 159 KB, one 16-wave workgroup per CU; its threads keep 32 keys each
+//     and recompute the keys of the rows beyond (a second key block).  rt_max_rows(S, nR) (afis_device.h) is the
 //     rule; a task goes to the smallest class that takes it (k_minu_classify lists, per class, the rolled templates that have such tasks in
 //     this launch).
-//   * anything else — more than 256 minutiae on either side or more than 32 768 similarities (the reference's reader allows 2000 per
+//   * anything else — more than 256 minutiae on either side or more than 39 168 similarities (the reference's reader allows 2000 per
 //     template, matcher.cpp:788-790), fewer than 512 entries, a threshold in the two lowest bins (fewer than 120 similarities with a
 //     norm of at least 2^-15), more than 256 candidates — is appended to a fallback list that k_minu_cands (exact threshold
 //     search on exact keys, any shape) works off afterwards.
@@ -309,10 +311,11 @@ template <int S> struct __attribute__((aligned(16))) RtSmem {
     float rowsum[RtCfg<S>::kMaxL];
     float colsum[RtCfg<S>::kMaxR];
     uint32_t hist[kSelBins];                         // bin b >= 1: approximate keys with bits 30..19 == kBinBase + b (top bin: and above)
-    u64 cand[kCandCap];                              // exact composite keys of the candidates
+    u64 cand[kCandCap + 8];                          // exact composite keys of the candidates (+ zero padding: the ranking reads eight at a time)
     uint32_t cand_e[kCandCap];                       // their (bin << 16 | row << 8 | column)
     int wave_tot[4];
     int thr_bin, ticket;
+    uint32_t sink[64];                               // where the histogram adds of entries that no bin counts go (one word per lane: conflict free): no branch around the atomic
 };
 
 __device__ __forceinline__ int lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
@@ -404,11 +407,15 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
     auto to_fallback = [&](long long task) { const int p = atomicAdd(&fb[0], 1); fb[1 + p] = (int32_t)task; };
     // The clock the chip holds under this kernel (afis_timing.cands_clock_ghz): one lane of the first workgroups reads the shader-cycle counter and the constant
     // 100 MHz counter when it starts and when it leaves; the sums of the two differences go to the diagnostics row.
-    const bool sampler = diag != nullptr && blockIdx.x < 8 && tid == 0;
+    const bool sampler = diag != nullptr && blockIdx.x < 8 && wave == 0;               // wave-uniform: the two counters stay in scalar registers
     unsigned long long clk0 = 0, wall0 = 0;
     if (sampler) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
-    int n_done = 0;                                                                 // tasks this workgroup completed (thread 0's count)
+    int n_done = 0;                                                                 // tasks this workgroup completed (uniform)
     const int n_work = ctl[kCls];
+    // A short work list (a class that only a few rolled templates reach in this launch: the medium class at the headline shapes gets ~50 of 100 000) would leave most of the chip idle
+    // while a handful of workgroups walk 60 latent lists each: the lists of a template are then split over n_split tickets (uniform: from n_work, the grid and the list count).
+    const int n_split = n_work <= 0 || n_work >= 2 * (int)gridDim.x ? 1 : min(nqs, (2 * (int)gridDim.x + n_work - 1) / n_work);
+    const int n_tickets = n_work * n_split;
     // Rolled templates are DRAWN from a counter, not dealt by stride: the kernel may start on the part of the chip the (CU-masked) bound pass leaves free and spread
     // over the rest when that finishes (afis_search.cpp, option bound_cus): workgroups that start late must not find a fixed share of the work waiting for them.
     for (;;) {
@@ -416,8 +423,10 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
         __syncthreads();
         const int wi = sm.ticket;
         __syncthreads();                                                            // everyone has read the ticket before thread 0 draws the next one
-        if (wi >= n_work) break;
-        const int gi = work[(size_t)kCls * g.G + wi];
+        if (wi >= n_tickets) break;
+        const int gi = work[(size_t)kCls * g.G + wi / n_split];
+        const int tpart = wi - (wi / n_split) * n_split;
+        const int qs_lo = (int)((long long)nqs * tpart / n_split), qs_hi = (int)((long long)nqs * (tpart + 1) / n_split);   // this ticket's latent lists
         const int r0 = g.minu_off[gi], nR = g.minu_off[gi + 1] - r0;
         const int Lhi = rt_max_rows(S, nR), Llo = S == 1 ? 0 : rt_max_rows(S / 2, nR); // this class: Llo < nL <= Lhi (k_minu_classify listed the template: Lhi > 0)
         const int n_jt = (nR + 15) >> 4;
@@ -428,21 +437,24 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
         // waves, P waves share a column tile and split its row tiles ----
         const int n_res = min(n_jt, kW), P = kW / n_res;
         const int jt_res = wave % n_res, part = wave / n_res;                       // part >= P: no resident work
-        const float4* btiles = rol_frag + (size_t)g.minu_tile_off[gi] * (6 * 64) + lane;
+        // fragment addresses = a wave-uniform base (scalar registers) + the lane's 16-byte slot as an unsigned 32-bit offset: no 64-bit per-lane pointers to keep alive
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const char* const btiles = reinterpret_cast<const char*>(rol_frag + (size_t)g.minu_tile_off[gi] * (6 * 64));
+        auto frag_at = [&](const char* base, int t, int v) -> const float4& { return *reinterpret_cast<const float4*>(base + ((unsigned)((t * 6 + v) * 1024) + lane16)); };
         float bres[24];
 #pragma unroll
-        for (int v = 0; v < 6; ++v) { const float4 x = btiles[(jt_res * 6 + v) * 64]; bres[4 * v] = x.x; bres[4 * v + 1] = x.y; bres[4 * v + 2] = x.z; bres[4 * v + 3] = x.w; }
+        for (int v = 0; v < 6; ++v) { const float4 x = frag_at(btiles, jt_res, v); bres[4 * v] = x.x; bres[4 * v + 1] = x.y; bres[4 * v + 2] = x.z; bres[4 * v + 3] = x.w; }
         auto next_in_class = [&](int from) {                                        // uniform: scalar loads
             int x = from;
-            for (; x < nqs; ++x) { const int nl = q.lm_off[x + 1] - q.lm_off[x]; if (nl > Llo && nl <= Lhi) break; }
+            for (; x < qs_hi; ++x) { const int nl = q.lm_off[x + 1] - q.lm_off[x]; if (nl > Llo && nl <= Lhi) break; }
             return x;
         };
         // The latent row tiles of the NEXT task of this rolled template are copied into the unused tail of simi[] while this task is being selected from
         // (global_load_lds: memory -> LDS without registers; one 16-byte element per lane, one copy for the workgroup's waves, which each fetched every tile
         // themselves before) — the fetch was the exposed L2 round trip at the head of every task.  pf_qs: the task whose tiles the tail holds (-1: none).
         int pf_qs = -1;
-        int qs_next = next_in_class(0);
-        for (int qs = qs_next; qs < nqs; qs = qs_next) {
+        int qs_next = next_in_class(qs_lo);
+        for (int qs = qs_next; qs < qs_hi; qs = qs_next) {
             qs_next = next_in_class(qs + 1);
             const long long task = (long long)qs * g.G + gi;
             const int l0 = q.lm_off[qs], nL = q.lm_off[qs + 1] - l0;
@@ -453,21 +465,25 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             // Operand layout: lane l supplies A[i = l&15][k = 4s + (l>>4)] and B[k][j = l&15] at step s = 4v + c; the fragment arrays
             // hold exactly that per (tile, v, lane), so a fragment is six fully coalesced 1 KB loads.
             const int n_it = (nL + 15) >> 4;
-            const float4* atiles = lat_frag + (size_t)q.lm_tile_off[qs] * (6 * 64) + lane;
+            const char* const atiles = reinterpret_cast<const char*>(lat_frag + (size_t)q.lm_tile_off[qs] * (6 * 64));
             const int n_pf = pf_qs == qs ? min(n_it, kPfTiles) : 0;                 // uniform: row tiles 0 .. n_pf - 1 wait in the tail of simi[]
-            const float4* const a_lds = reinterpret_cast<const float4*>(sm.simi + kSimi) - kPfTiles * (6 * 64) + lane;
-            auto load_frag = [&](const float4* __restrict__ tiles, int t, float (&f)[24]) {
+            const char* const a_lds = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(sm.simi + kSimi) - kPfTiles * (6 * 64));
+            auto load_frag = [&](const char* __restrict__ tiles, int t, float (&f)[24]) {
 #pragma unroll
-                for (int v = 0; v < 6; ++v) { const float4 x = tiles[(t * 6 + v) * 64]; f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w; }
+                for (int v = 0; v < 6; ++v) { const float4 x = frag_at(tiles, t, v); f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w; }
             };
             auto store_tile = [&](int it, int jt, const f32x4& acc) {              // D: col = lane & 15, row = (lane >> 4) * 4 + r
                 const int j = jt * 16 + li;
+                const int i0 = it * 16 + lg * 4;
+                float* const p = &sm.simi[(int)__umul24((unsigned)i0, (unsigned)ld) + j];   // one 24-bit multiply per tile; the four rows are ld floats apart
+                if (j < nR) {                                                       // (a column beyond the template would land in the next row)
+                    if (it * 16 + 16 <= nL) {                                       // uniform: a full row tile needs no row tests
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = it * 16 + lg * 4 + r;
-                    float v = acc[r];
-                    if (v < 0) v = 0;
-                    if (i < nL && j < nR) sm.simi[i * ld + j] = v;
+                        for (int r = 0; r < 4; ++r) { float v = acc[r]; if (v < 0) v = 0; p[r * ld] = v; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { float v = acc[r]; if (v < 0) v = 0; if (i0 + r < nL) p[r * ld] = v; }
+                    }
                 }
             };
             // The six loads of a fragment are issued together (sched_barrier pins that: left alone, the scheduler sinks every load next
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             if (tid == 0) sm.thr_bin = -1;
             RT_SYNC();
             pf_qs = -1;
-            if (qs_next < nqs) {                                                     // uniform
+            if (qs_next < qs_hi) {                                                   // uniform
                 const int nLn = q.lm_off[qs_next + 1] - q.lm_off[qs_next];
                 const int n_cp = min((nLn + 15) >> 4, kPfTiles);
                 // the tail must clear this task's matrix (still being read) and the next one's (written before the tiles are read)
@@ -569,21 +585,42 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             // and task before this layout), so the selection is organised for few instructions per element: thread = (column cj, row
             // phase cr) walks the rows cr, cr + R, ... of ITS column — the column sum stays in a register, the address advances by a
             // constant — and keeps the approximate keys in registers for the second pass.
-            const int n_rows = (nL + R - 1) / R;                                     // <= 32: rt_max_rows()
+            const int n_rows = (nL + R - 1) / R;                                     // <= 32 (S = 4: <= 64, the rows beyond 32 R form a second key block): rt_max_rows()
             const int my_rows = cr < R ? (nL - cr + R - 1) / R : 0;
             uint32_t rk[32];
             {
                 const float cs = sm.colsum[cj];
                 int a = cr * ld + cj, i = cr;
+                const int a_step = R * ld;
+                // four rows per trip: their eight LDS reads are issued together and nothing branches around an element (a row beyond this thread's share reads element 0 and
+                // gets key 0, which no bin counts) — one element at a time, each with its own wait and its own exec-mask regions, made this pass 20 % of the kernel
 #pragma unroll
-                for (int t = 0; t < 32; ++t) {
-                    rk[t] = 0u;
-                    if (t < n_rows) {                                                // uniform
+                for (int tb = 0; tb < 32; tb += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rk[tb + u] = 0u;
+                    if (tb < n_rows) {                                               // uniform
+                        float sv[4], rs[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool ok = tb + u < my_rows;
+                            sv[u] = sm.simi[ok ? a + u * a_step : 0]; rs[u] = sm.rowsum[ok ? i + u * R : 0];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t key = approx_norm_key(sv[u], rs[u], cs) & (uint32_t)-(int)(tb + u < my_rows);   // (a mask, not a select: the compiler turns the select into a branch region)
+                            rk[tb + u] = key;
+                            const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
+                            atomicAdd(bin > 0 ? &sm.hist[bin] : &sm.sink[lane], 1u);  // zero similarities, norms < 2^-15 and absent rows are not counted
+                        }
+                        a += 4 * a_step; i += 4 * R;
+                    }
+                }
+                if (S == 4 && n_rows > 32) {                                         // second key block (large class only): counted now, recomputed in the candidate pass instead of kept
+                    for (int t = 32; t < n_rows; ++t) {                              // uniform
                         if (t < my_rows) {
                             const uint32_t key = approx_norm_key(sm.simi[a], sm.rowsum[i], cs);
-                            rk[t] = key;
                             const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
-                            if (bin > 0) atomicAdd(&sm.hist[bin], 1u);               // zero similarities and norms < 2^-15 are not counted
+                            if (bin > 0) atomicAdd(&sm.hist[bin], 1u);
                         }
                         a += R * ld; i += R;
                     }
@@ -611,14 +648,16 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             }
             RT_SYNC();
             PHASE(30);
-            const int B = sm.thr_bin;
+            const int B = __builtin_amdgcn_readfirstlane(sm.thr_bin);               // (uniform: one LDS word)
             if (B < 2) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
             // ---- the candidates: approximate key >= edge(B) - 2E ----
             {
                 const uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
+                const uint32_t edge_s = edge - kKeySlack;                            // key + slack >= edge  <=>  key >= edge - slack (no wrap: keys of real entries are below 0xff800000, unused slots hold 0)
                 uint32_t hits = 0;
 #pragma unroll
-                for (int t = 0; t < 32; ++t) hits |= (rk[t] + kKeySlack >= edge ? 1u : 0u) << t;   // unused slots hold 0 (bounding the loop by n_rows was measured: 2 % slower)
+                for (int t = 31; t >= 0; --t)                                        // hits = 2 hits + (key >= edge_s): a compare into the carry and an add-with-carry per key (the compiler's compare / select / shift-or took four)
+                    asm("v_cmp_le_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(rk[t]), "s"(edge_s) : "vcc");
                 // The candidates are appended GROUPED BY BIN, highest bin first (every key of a bin above B is a candidate, so the suffix
                 // counts of the scan are the groups' start positions; keys of bin B - 1 within the slack join group B, the last one).
                 // The bin of a hit is recomputed from LDS: indexing rk[] with a runtime t would put the 32 keys into scratch.
@@ -632,6 +671,17 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                     const uint32_t p = atomicAdd(&sm.hist[bin], 1u);
                     if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 16) | (i << 8) | cj);
                 }
+                if (S == 4 && n_rows > 32) {                                         // the second key block's entries: keys recomputed
+                    for (int t = 32; t < my_rows; ++t) {
+                        const int i = cr + R * t;
+                        const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs);
+                        if (key + kKeySlack >= edge) {
+                            const int bin = max(min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1), B);
+                            const uint32_t p = atomicAdd(&sm.hist[bin], 1u);
+                            if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 16) | (i << 8) | cj);
+                        }
+                    }
+                }
             }
             RT_SYNC();
             PHASE(31);
@@ -642,7 +692,8 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 const uint32_t pe = sm.cand_e[tid];
                 cbin = (int)(pe >> 16); ci = (int)((pe >> 8) & 255u); cj2 = (int)(pe & 255u);
                 sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 16) | (u64)(65535 - (ci * nR + cj2));
-            } else if (tid == n_c) sm.cand[tid & (kCandCap - 1)] = 0ull;             // pad of an odd list (n_c == kCandCap is even: nothing is overwritten)
+            }
+            if (tid < 8) sm.cand[n_c + tid] = 0ull;                                  // padding: the ranking below reads the list eight composites at a time
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the next task's tiles has landed in LDS (waited for here, before the list's stores join the counter)
             RT_SYNC();
             PHASE(18);
@@ -657,20 +708,26 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 const int hi = cbin - 1 > B ? (int)sm.hist[cbin - 1] : n_c;
                 int r = lo;
                 const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(sm.cand);
-                for (int k = lo; k < hi; k += 2) { const ulonglong2 kk = c2[k >> 1]; r += kk.x > mine; r += kk.y > mine; }
+                // eight composites per trip, all four reads in flight together (the loop is a chain of LDS round trips, as long as the longest range of the wave: two per trip made it
+                // 22 % of the kernel).  What a trip reads beyond `hi` belongs to lower bins or is padding: smaller than `mine`, never counted.
+                for (int k = lo; k < hi; k += 8) {
+                    const ulonglong2 k0 = c2[(k >> 1)], k1 = c2[(k >> 1) + 1], k2 = c2[(k >> 1) + 2], k3 = c2[(k >> 1) + 3];
+                    r += (int)(k0.x > mine) + (int)(k0.y > mine) + (int)(k1.x > mine) + (int)(k1.y > mine) + (int)(k2.x > mine) + (int)(k2.y > mine) + (int)(k3.x > mine) + (int)(k3.y > mine);
+                }
                 if (r < kTopMinu) {
                     MinuCand cd; cd.sim = sm.simi[ci * ld + cj2]; cd.li = (short)ci; cd.ri = (short)cj2;
                     cands[(size_t)task * kTopMinu + r] = cd;
                 }
             }
-            if (tid == 0) { cand_n[task] = kTopMinu; ++n_done; }
+            if (tid == 0) cand_n[task] = kTopMinu;
+            ++n_done;
             RT_SYNC();
             PHASE(20);
         }
     }
     if (diag != nullptr && tid == 0) {
         if (n_done) atomicAdd(&diag[kDiagSmall + kCls], (unsigned long long)n_done);
-        if (sampler) { atomicAdd(&diag[kDiagCandsClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagCandsWall], (unsigned long long)wall_clock64() - wall0); }
+        if (sampler) { atomicAdd(&diag[kDiagCandsClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagCandsWall], (unsigned long long)wall_clock64() - wall0); }   // (tid 0 is in wave 0)
     }
     PHASE_FLUSH();
 }
@@ -682,7 +739,9 @@ static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCa
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands_rt<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RtSmem<S>));
     if (e != hipSuccess) return e;
     const int per_cu = 4 / S;                                                      // 4 / 2 / 1 workgroups (16 waves) per CU, persistent: rolled templates are drawn from ctl[4 + class]
-    const int grid = g.G < 256 * per_cu ? g.G : 256 * per_cu;
+    static const int grid_cap = getenv("AFIS_RT_GRID") ? atoi(getenv("AFIS_RT_GRID")) : 0;      // experiment: occupancy probe (512 = two small-class workgroups per CU, ...)
+    const int full = (grid_cap > 0 && S == 1) ? grid_cap : 256 * per_cu;
+    const int grid = g.G < full ? g.G : full;
     hipLaunchKernelGGL(k_minu_cands_rt<S>, dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag);
     return hipGetLastError();
 }

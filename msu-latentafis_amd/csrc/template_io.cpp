@@ -312,6 +312,43 @@ std::unique_ptr<GalleryMapping> map_gallery_container(const std::string& path, s
     return g;
 }
 
+// The template range [first, first + count) of a container that is ALREADY mapped and validated (afis_gallery_load) copied into host arrays: the same bytes
+// afis_gallery_commit would have uploaded, no second open of the path (a file replaced in between would be read without the per-template checks the load did).
+// The mapping is private to the file as it was opened; a file truncated since then would fault on access, so the size is checked again first.
+bool copy_from_mapping(const GalleryMapping& g, int64_t first, int64_t count, HostGallery& out, std::string& err)
+{
+    if (first < 0 || count < 0 || first + count > g.G) { err = g.path + ": template range outside the container"; return false; }
+    struct stat st;
+    if (g.fd_ >= 0 && (fstat(g.fd_, &st) != 0 || (size_t)st.st_size < g.len_)) { err = g.path + ": the container was truncated after it was loaded"; return false; }
+    const int64_t m0 = g.minu_off[first], m1 = g.minu_off[first + count], t0 = g.tex_off[first], t1 = g.tex_off[first + count];
+    struct Job { uint8_t* dst; const uint8_t* src; size_t bytes; };
+    std::vector<Job> jobs;
+    auto app = [&](auto& vec, const auto* src_arr, int64_t a, int64_t b, size_t per) {
+        typedef typename std::remove_reference<decltype(vec)>::type V;
+        typedef typename V::value_type T;
+        const size_t old = vec.size(), n = (size_t)(b - a) * per;
+        vec.resize(old + n);
+        const uint8_t* src = (const uint8_t*)(src_arr + (size_t)a * per);
+        uint8_t* dst = (uint8_t*)(vec.data() + old);
+        const size_t chunk = (size_t)8 << 20;
+        for (size_t o = 0; o < n * sizeof(T); o += chunk) jobs.push_back({dst + o, src + o, std::min(chunk, n * sizeof(T) - o)});
+    };
+    app(out.mx, g.mx, m0, m1, 1); app(out.my, g.my, m0, m1, 1); app(out.mori, g.mori, m0, m1, 1); app(out.mdes, g.mdes, m0, m1, 96);
+    app(out.tx, g.tx, t0, t1, 1); app(out.ty, g.ty, t0, t1, 1); app(out.tori, g.tori, t0, t1, 1); app(out.tcodes, g.tcodes, t0, t1, 16);
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t j = next.fetch_add(1); j < jobs.size(); j = next.fetch_add(1)) memcpy(jobs[j].dst, jobs[j].src, jobs[j].bytes); };
+        const size_t n_thr = std::min<size_t>(std::max<size_t>(jobs.size(), 1), std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < n_thr; ++t) th.emplace_back(work);
+        work();
+        for (std::thread& x : th) x.join();
+    }
+    const int64_t mb = out.minu_off.back() - m0, tb = out.tex_off.back() - t0;
+    for (int64_t i = first; i < first + count; ++i) { out.minu_off.push_back(g.minu_off[i + 1] + mb); out.tex_off.push_back(g.tex_off[i + 1] + tb); out.empty.push_back(g.empty[i]); }
+    return true;
+}
+
 bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
                             std::vector<int32_t>* tex_counts, std::string& err, bool load_data)
 {

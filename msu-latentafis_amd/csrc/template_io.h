@@ -91,6 +91,7 @@ struct GalleryMapping {
     void* base_ = nullptr; size_t len_ = 0; int fd_ = -1;
 };
 std::unique_ptr<GalleryMapping> map_gallery_container(const std::string& path, std::string& err);   // header, section sizes and offsets checked; null on error
+bool copy_from_mapping(const GalleryMapping& g, int64_t first, int64_t count, HostGallery& out, std::string& err);   // a range of an already validated mapping -> host arrays
 bool read_gallery_container(const std::string& path, int64_t first, int64_t count, HostGallery& out, std::vector<std::string>* names,
                             std::vector<int32_t>* tex_counts, std::string& err, bool load_data = true);   // load_data false: names / counts only, the arrays are not copied
 
