@@ -296,9 +296,9 @@ constexpr int kHistMinN = 512;                       // smaller pairs go to the 
 constexpr int kCandCap = 256;                        // entries that may still be in the top 120 (exact keys computed for these)
 constexpr uint32_t kKeySlack = 16;                   // 2E
 #ifndef AFIS_PF_TILES
-#define AFIS_PF_TILES 2
+#define AFIS_PF_TILES 4
 #endif
-constexpr int kPfTiles = AFIS_PF_TILES;              // latent row tiles of the next task copied ahead into the tail of simi[] (6 KB each)
+constexpr int kPfTiles = AFIS_PF_TILES;              // latent row tiles of the next task copied ahead into the tail of simi[] (6 KB each): at most this many, as many as the tail holds
 template <int S> struct RtCfg {
     static constexpr int kT = 256 * S;               // threads of a workgroup
     static constexpr int kW = 4 * S;                 // its waves: resident column tiles
@@ -313,7 +313,7 @@ template <int S> struct __attribute__((aligned(16))) RtSmem {
     uint32_t hist[kSelBins];                         // bin b >= 1: approximate keys with bits 30..19 == kBinBase + b (top bin: and above)
     u64 cand[kCandCap + 8];                          // exact composite keys of the candidates (+ zero padding: the ranking reads eight at a time)
     uint32_t cand_e[kCandCap];                       // their (bin << 16 | row << 8 | column)
-    int wave_tot[4];
+    int pad_[4];
     int thr_bin, ticket;
     uint32_t sink[64];                               // where the histogram adds of entries that no bin counts go (one word per lane: conflict free): no branch around the atomic
 };
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
         // The latent row tiles of the NEXT task of this rolled template are copied into the unused tail of simi[] while this task is being selected from
         // (global_load_lds: memory -> LDS without registers; one 16-byte element per lane, one copy for the workgroup's waves, which each fetched every tile
         // themselves before) — the fetch was the exposed L2 round trip at the head of every task.  pf_qs: the task whose tiles the tail holds (-1: none).
-        int pf_qs = -1;
+        int pf_qs = -1, pf_n = 0;
         int qs_next = next_in_class(qs_lo);
         for (int qs = qs_next; qs < qs_hi; qs = qs_next) {
             qs_next = next_in_class(qs + 1);
@@ -466,8 +466,9 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             // hold exactly that per (tile, v, lane), so a fragment is six fully coalesced 1 KB loads.
             const int n_it = (nL + 15) >> 4;
             const char* const atiles = reinterpret_cast<const char*>(lat_frag + (size_t)q.lm_tile_off[qs] * (6 * 64));
-            const int n_pf = pf_qs == qs ? min(n_it, kPfTiles) : 0;                 // uniform: row tiles 0 .. n_pf - 1 wait in the tail of simi[]
-            const char* const a_lds = reinterpret_cast<const char*>(reinterpret_cast<const float4*>(sm.simi + kSimi) - kPfTiles * (6 * 64));
+            const int n_pf = pf_qs == qs ? pf_n : 0;                                // uniform: row tiles 0 .. n_pf - 1 wait in the tail of simi[], tile t in the t-th 6 KB from the end
+            const char* const a_end = reinterpret_cast<const char*>(sm.simi + kSimi);
+            auto a_lds = [&](int t) { return a_end - (t + 1) * (6 * 64 * 16); };
             auto load_frag = [&](const char* __restrict__ tiles, int t, float (&f)[24]) {
 #pragma unroll
                 for (int v = 0; v < 6; ++v) { const float4 x = frag_at(tiles, t, v); f[4 * v] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w; }
@@ -499,9 +500,9 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 // waits 40+ cycles for each result)
                 for (int it = 2 * part; it < n_it; it += 2 * P) {
                     float a0[24], a1[24];
-                    if (it < n_pf) load_frag(a_lds, it, a0); else load_frag(atiles, it, a0);
+                    if (it < n_pf) load_frag(a_lds(it), 0, a0); else load_frag(atiles, it, a0);
                     if (it + 1 < n_it) {
-                        if (it + 1 < n_pf) load_frag(a_lds, it + 1, a1); else load_frag(atiles, it + 1, a1);
+                        if (it + 1 < n_pf) load_frag(a_lds(it + 1), 0, a1); else load_frag(atiles, it + 1, a1);
                         __builtin_amdgcn_sched_barrier(0);
                         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 const int jt = kW + item / n_it, it = item - (jt - kW) * n_it;
                 float af[24], bf[24];
                 load_frag(btiles, jt, bf);
-                if (it < n_pf) load_frag(a_lds, it, af); else load_frag(atiles, it, af);
+                if (it < n_pf) load_frag(a_lds(it), 0, af); else load_frag(atiles, it, af);
                 __builtin_amdgcn_sched_barrier(0);
                 store_tile(it, jt, mfma_tile(af, bf));
             }
@@ -532,14 +533,16 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             pf_qs = -1;
             if (qs_next < qs_hi) {                                                   // uniform
                 const int nLn = q.lm_off[qs_next + 1] - q.lm_off[qs_next];
-                const int n_cp = min((nLn + 15) >> 4, kPfTiles);
-                // the tail must clear this task's matrix (still being read) and the next one's (written before the tiles are read)
-                if (max(nL, nLn) * ld + kPfTiles * (6 * 64 * 4) <= kSimi) {
+                // the tail must clear this task's matrix (still being read) and the next one's (written before the tiles are read): as many tiles as fit above both
+                const int n_cp = min(min((nLn + 15) >> 4, kPfTiles), (kSimi - max(nL, nLn) * ld) / (6 * 64 * 4));
+                if (n_cp > 0) {
                     const float4* src = lat_frag + (size_t)q.lm_tile_off[qs_next] * (6 * 64) + lane;
-                    float4* dst = reinterpret_cast<float4*>(sm.simi + kSimi) - kPfTiles * (6 * 64);
-                    for (int c = wave; c < n_cp * 6; c += kW)                        // chunk = 64 lanes x 16 B = one (tile, v) slice
-                        __builtin_amdgcn_global_load_lds(src + c * 64, (__attribute__((address_space(3))) void*)(dst + c * 64), 16, 0, 0);
-                    pf_qs = qs_next;
+                    float4* const end4 = reinterpret_cast<float4*>(sm.simi + kSimi);
+                    for (int c = wave; c < n_cp * 6; c += kW) {                      // chunk = 64 lanes x 16 B = one (tile, v) slice
+                        const int t = c / 6, v = c - t * 6;
+                        __builtin_amdgcn_global_load_lds(src + c * 64, (__attribute__((address_space(3))) void*)(end4 - (t + 1) * (6 * 64) + v * 64), 16, 0, 0);
+                    }
+                    pf_qs = qs_next; pf_n = n_cp;
                 }
             }
             PHASE(16);
@@ -548,37 +551,34 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             __syncthreads();
             continue;
 #endif
-            // ---- S2 (:455-456): index-ascending sums; odd row stride: both walks are conflict free.  Eight reads are issued before
-            // the eight dependent adds (one LDS round trip per eight elements instead of one per element).
-            if (tid < nR) {
-                const float* p = &sm.simi[tid];
+            // ---- S2 (:455-456): index-ascending sums; odd row stride: both walks are conflict free.  The adds are one dependent chain per lane (that IS the reference's order); the
+            // LDS reads are not: eight are issued before the eight adds that use them, and the NEXT eight are already in flight while those adds run.
+            auto seq_sum = [&](const float* __restrict__ p, const int stride, const int n) {
                 float sacc = 0.f;
                 int k = 0;
-                for (; k + 8 <= nL; k += 8) {
-                    float v[8];
+                if (n >= 8) {
+                    float cur[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * ld];
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < 8; ++u) cur[u] = p[u * stride];
+                    for (; k + 16 <= n; k += 8) {
+                        float nxt[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sacc += v[u];
+                        for (int u = 0; u < 8; ++u) nxt[u] = p[(k + 8 + u) * stride];
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) sacc += cur[u];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc += cur[u];
+                    k += 8;
                 }
-                for (; k < nL; ++k) sacc += p[k * ld];
-                sm.colsum[tid] = sacc;
-            } else if (tid >= Cfg::kMaxR && tid - Cfg::kMaxR < nL) {
-                const float* p = &sm.simi[(tid - Cfg::kMaxR) * ld];
-                float sacc = 0.f;
-                int k = 0;
-                for (; k + 8 <= nR; k += 8) {
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = p[k + u];                   // immediate offsets: no address arithmetic
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sacc += v[u];
-                }
-                for (; k < nR; ++k) sacc += p[k];
-                sm.rowsum[tid - Cfg::kMaxR] = sacc;
-            }
+                for (; k < n; ++k) sacc += p[k * stride];
+                return sacc;
+            };
+            if (tid < nR) sm.colsum[tid] = seq_sum(&sm.simi[tid], ld, nL);
+            else if (tid >= Cfg::kMaxR && tid - Cfg::kMaxR < nL) sm.rowsum[tid - Cfg::kMaxR] = seq_sum(&sm.simi[(tid - Cfg::kMaxR) * ld], 1, nR);
             RT_SYNC();
             PHASE(17);
             // ---- S3 (:461-488): the 120 largest norm values.  The kernel is bound by VALU issue (about 2000 wave-instructions per wave
@@ -628,23 +628,22 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             }
             RT_SYNC();
             PHASE(29);
-            {   // thread b < 256 owns bin b: suffix sums over the higher bins find the bin holding the 120th largest approximate key
-                int own = 0, suf = 0;
-                if (S == 1 || tid < kSelBins) {
-                    own = (int)sm.hist[tid];
-                    suf = own;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_down(suf, off); if (lane + off < 64) suf += v; }
-                    if (lane == 0) sm.wave_tot[wave] = suf;
-                }
-                RT_SYNC();
-                if (S == 1 || tid < kSelBins) {
-                    int above = suf - own;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) if (w > wave) above += sm.wave_tot[w];
-                    if (above < kTopMinu && above + own >= kTopMinu) sm.thr_bin = tid;
-                    sm.hist[tid] = (uint32_t)above;                                  // from here on: where the next candidate of this bin goes
-                }
+            if (wave == 0) {   // one wave scans the 256 bins (lane = four consecutive bins): suffix sums over the higher bins find the bin holding the 120th largest approximate key
+                const uint4 h = reinterpret_cast<const uint4*>(sm.hist)[lane];
+                const int s0 = (int)(h.x + h.y + h.z + h.w);
+                int suf = s0;                                                        // becomes the sum over this lane and every higher one: four row_shl steps inside the rows of 16 lanes ...
+                suf += __builtin_amdgcn_update_dpp(0, suf, 0x101, 0xf, 0xf, true);
+                suf += __builtin_amdgcn_update_dpp(0, suf, 0x102, 0xf, 0xf, true);
+                suf += __builtin_amdgcn_update_dpp(0, suf, 0x104, 0xf, 0xf, true);
+                suf += __builtin_amdgcn_update_dpp(0, suf, 0x108, 0xf, 0xf, true);
+                const int r1 = __builtin_amdgcn_readlane(suf, 16), r2 = __builtin_amdgcn_readlane(suf, 32), r3 = __builtin_amdgcn_readlane(suf, 48);   // ... and the totals of the rows above
+                suf += lane < 16 ? r1 + r2 + r3 : lane < 32 ? r2 + r3 : lane < 48 ? r3 : 0;
+                const int a3 = suf - s0, a2 = a3 + (int)h.w, a1 = a2 + (int)h.z, a0 = a1 + (int)h.y;     // entries in the bins ABOVE each of the four
+                if (a3 < kTopMinu && a3 + (int)h.w >= kTopMinu) sm.thr_bin = 4 * lane + 3;
+                if (a2 < kTopMinu && a2 + (int)h.z >= kTopMinu) sm.thr_bin = 4 * lane + 2;
+                if (a1 < kTopMinu && a1 + (int)h.y >= kTopMinu) sm.thr_bin = 4 * lane + 1;
+                if (a0 < kTopMinu && a0 + (int)h.x >= kTopMinu) sm.thr_bin = 4 * lane;
+                reinterpret_cast<uint4*>(sm.hist)[lane] = make_uint4((uint32_t)a0, (uint32_t)a1, (uint32_t)a2, (uint32_t)a3);   // from here on: where the next candidate of each bin goes
             }
             RT_SYNC();
             PHASE(30);
@@ -688,24 +687,30 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             const int n_c = (int)sm.hist[B];                                         // >= 120: group B ends the list
             if (n_c > kCandCap) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }
             int ci = 0, cj2 = 0, cbin = 0;
+            uint32_t ke = 0u;
             if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
                 const uint32_t pe = sm.cand_e[tid];
                 cbin = (int)(pe >> 16); ci = (int)((pe >> 8) & 255u); cj2 = (int)(pe & 255u);
-                sm.cand[tid] = ((u64)exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]) << 16) | (u64)(65535 - (ci * nR + cj2));
+                ke = exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]);
+                sm.cand[tid] = ((u64)ke << 16) | (u64)(65535 - (ci * nR + cj2));
             }
             if (tid < 8) sm.cand[n_c + tid] = 0ull;                                  // padding: the ranking below reads the list eight composites at a time
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this wave's share of the next task's tiles has landed in LDS (waited for here, before the list's stores join the counter)
             RT_SYNC();
             PHASE(18);
             // ---- rank the candidates by counting (composites are unique); ranks < 120 are the list, in the reference's order.
-            // Approximate and exact key differ by at most E = 8 << a bin's width (2^19), so a candidate of bin g can only be out of order
-            // with candidates of bins g - 1 .. g + 1: it counts the larger composites among THOSE (a contiguous range of the grouped list)
-            // and adds the number of candidates in higher bins, which all beat it.  sm.hist[b] now holds the END of group b (= the start
-            // of group b - 1).  The range is widened to even positions: the extra element in front is larger, the one behind smaller or the pad.
+            // The list is grouped by the bin of the APPROXIMATE key, highest bin first; sm.hist[b] now holds the END of group b (= the start of group b - 1).  Approximate and
+            // exact key differ by at most E = 8 << a bin's width (2^19): a candidate of bin g whose exact key lies at least 2E inside the bin is beaten by every candidate of the
+            // higher bins and beats every one of the lower bins, so it counts the larger composites of its OWN group only (a third of the three-bin window every candidate
+            // used to walk: the loop is a chain of LDS round trips as long as the wave's longest range); one within 2E of an edge also walks the group on that side.
+            // The range is widened to even positions: the extra element in front is larger, the one behind smaller or the pad.
             if (tid < n_c) {
                 const u64 mine = sm.cand[tid];
-                const int lo = cbin + 2 < kSelBins ? (int)sm.hist[cbin + 2] & ~1 : 0;
-                const int hi = cbin - 1 > B ? (int)sm.hist[cbin - 1] : n_c;
+                const uint32_t edge_own = 0x80000000u | ((uint32_t)(cbin + kBinBase) << 19), edge_up = edge_own + (1u << 19);
+                const bool need_up = cbin + 1 < kSelBins && ke + kKeySlack >= edge_up;   // (the top bin also holds everything above it: nothing lies higher)
+                const bool need_dn = ke < edge_own + kKeySlack;
+                const int lo = need_up ? (cbin + 2 < kSelBins ? (int)sm.hist[cbin + 2] & ~1 : 0) : (cbin + 1 < kSelBins ? (int)sm.hist[cbin + 1] & ~1 : 0);
+                const int hi = cbin <= B ? n_c : need_dn ? (cbin - 1 > B ? (int)sm.hist[cbin - 1] : n_c) : (int)sm.hist[cbin];
                 int r = lo;
                 const ulonglong2* c2 = reinterpret_cast<const ulonglong2*>(sm.cand);
                 // eight composites per trip, all four reads in flight together (the loop is a chain of LDS round trips, as long as the longest range of the wave: two per trip made it
