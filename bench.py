@@ -360,8 +360,9 @@ def main():
         hbm_achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
         variant = 9 if a.variant < 0 else a.variant
         carried = None
-        cp = os.path.join(ROOT, "profiles", "r04_adc_counters.json")
-        if os.path.exists(cp) and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only (PMC passes with the kernels back to back, --bound-cus 0: a kernel's traffic does not depend on what runs beside it)
+        cp = next((p_ for p_ in (os.path.join(ROOT, "profiles", f) for f in ("r05_adc_counters.json", "r04_adc_counters.json")) if os.path.exists(p_)), "")
+        carried_name = "profiles/" + os.path.basename(cp)
+        if cp and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only (PMC passes with the kernels back to back, --bound-cus 0: a kernel's traffic does not depend on what runs beside it)
             try:
                 carried = json.load(open(cp))
             except Exception:
@@ -395,7 +396,7 @@ def main():
                                                "avg_launch_ms": round(alone_ms, 3), "achieved": round(alone_tf, 2), "peak": MFMA_F16_PEAK_TFLOPS, "frac": round(alone_tf / MFMA_F16_PEAK_TFLOPS, 5),
                                                "measured_clock_ghz": {"bound_pass_ghz": round(alone.get("bound_clock_ghz", 0.0), 4), "candidate_kernel_ghz": round(alone.get("cands_clock_ghz", 0.0), 4)}} if alone else None),
                         "traffic": carried.get("traffic_bytes_per_launch") if carried else None,
-                        "traffic_source": ("profiles/r04_adc_counters.json (carried, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
+                        "traffic_source": (carried_name + " (carried, not measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; FETCH_SIZE x 2 for the 16 B/lane streams as "
                                            "MI355X_MICROARCH.md prescribes and profiles/r03_fetch_calibration.json confirms; collected with the kernels back to back, --bound-cus 0; PMC counters cannot be read inside this run)") if carried else None,
                         "stage_traffic": carried.get("stage_traffic") if carried else None,
                         "achieved_is": "ALGORITHMIC flops (latent texture rows of the launch x rolled texture points of the shard x 192) / average kernel duration; padding rows / points and the "
@@ -405,7 +406,7 @@ def main():
                         "hbm_view": {"what": "the same stage (bound pass + recomputation) priced as north_star prices it: 24 algorithmic bytes per rolled texture point per query / stage time", "alg_bytes_per_launch": alg_bytes_launch,
                                      "achieved_GBps": round(hbm_achieved, 2), "peak_GBps": HBM_PEAK_GBS, "frac": round(hbm_achieved / HBM_PEAK_GBS, 6)},
                         "unit_fractions_from_counters": carried.get("fractions") if carried else None,
-                        "unit_fractions_source": "profiles/r04_adc_counters.json (carried)" if carried else None,
+                        "unit_fractions_source": (carried_name + " (carried)") if carried else None,
                         "limiting_resource": limiting}
         else:
             lookups_per_s = tm_acc["adc_lookups"] / (tm_acc["adc_ms"] * 1e-3) if tm_acc["adc_ms"] > 0 else 0.0

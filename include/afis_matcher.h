@@ -225,7 +225,8 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
  * "mf_blocks" (form of variant 9's bound pass: 2 [default] / 3 row blocks per wave, 102 = software-pipelined; bit-identical), "bound_cus" (below), "query_batch" (latents per launch group),
  * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
- * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded), "rowmax_budget_mb" (device memory of a launch group's per-pair
+ * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded; "search_timeout_ms" sets the same bound in
+ * milliseconds.  After such a timeout the device may still be working on the call: the caller's output buffers must stay valid until afis_destroy, or until a later call on the context succeeds), "rowmax_budget_mb" (device memory of a launch group's per-pair
  * buffers; default 60 % of the free memory), "mf_stats" (adc_variant 9: collect the counters the parity tap afis_debug_refine_stats reads).  ("lut_dtype" accepts only 32: the
  * opt-in 16-bit tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */

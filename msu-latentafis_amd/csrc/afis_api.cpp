@@ -155,6 +155,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
     else if (n == "search_timeout_s") { ctx->search_timeout_s = (double)value; }        // <= 0: unbounded hipStreamSynchronize
+    else if (n == "search_timeout_ms") { ctx->search_timeout_s = (double)value * 1e-3; }
     else if (n == "bound_cus") {                                           // 0 = off; 32..224 in steps of 32: the bound pass on a stream confined to that many CUs (value / 8 of every XCD), the minutiae stage beside it on the others
         if (value < 0 || value > 224 || (value & 31)) return fail(ctx, AFIS_EINVAL, "bound_cus must be 0 (off), 32, 64, ... 224 (the runtime honours CU masks in steps of 32 CUs: 4 per XCD)");
         if (value > 0 && value + 32 > ctx->n_cus) return fail(ctx, AFIS_EINVAL, "bound_cus must leave at least 32 of the device's CUs to the other stream");

@@ -253,3 +253,31 @@ def test_config4_one_million_templates_in_eight_virtual_shards(codebook_bytes, c
         oracle.lib.orc_latent_free(hl)
         n_pairs += len(gidx); n_nz += int((want[:, :4] > 0).sum())
     assert n_pairs >= 4 * Q + 3 * 190 and n_nz > 100
+
+
+def test_a_search_that_outlasts_its_deadline_returns_an_error_and_the_context_recovers(headline):
+    """Every host wait of a search is bounded (option search_timeout_s / AFIS_SEARCH_TIMEOUT_S): a device that does not finish in time — here a 2 s search given 150 ms — makes
+    afis_search return AFIS_EDEVICE instead of holding the caller's thread; with side streams in use the context then keeps to one stream (bound_cus reads 0) until the option
+    is set again.  Once the device has drained, the context searches as before, same bits.  (No output buffer is passed to the call that times out: the device may still be writing.)"""
+    import time
+    lats, gal, planted, m, res = headline
+    m.set_option("adc_variant", 9); m.set_option("minu_generic", 0)      # (an earlier test leaves a reference kernel selected)
+    assert m.get_option("bound_cus") == 128
+    qh = m.upload_queries(lats)
+    m.search_resident(qh, k=0)                                           # warm: buffers allocated
+    m.set_option("search_timeout_ms", 150)
+    t0 = time.time()
+    with pytest.raises(M.AfisError, match="did not finish"):
+        m.search_resident(qh, k=0)
+    assert time.time() - t0 < 2.0                                        # it came back at the deadline, not when the device was done
+    assert m.get_option("bound_cus") == 0                                # the overlapped schedule is off for this context
+    time.sleep(6.0)                                                      # the device drains what the failed call had queued
+    m.set_option("search_timeout_s", 600)
+    sub = [5, 50]
+    r = m.search([lats[i] for i in sub], k=24)                           # one stream now
+    assert np.array_equal(r["scores"], res["scores"][sub]) and np.array_equal(r["topk_idx"], res["topk_idx"][sub])
+    m.set_option("bound_cus", 128)
+    assert m.get_option("bound_cus") == 128
+    r = m.search([lats[i] for i in sub], k=24)
+    assert np.array_equal(r["scores"], res["scores"][sub])
+    m.free_queries(qh)

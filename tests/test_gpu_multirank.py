@@ -43,6 +43,34 @@ def test_bench_two_ranks_share_one_gpu(tmp_path):
     assert j2["n_gpus"] == 2 and j2["rank1_hits"] == "6/6" and j2["config"]["parallelism"] == "gallery-shard x2"
     a, b = np.load(tmp_path / "one.npz"), np.load(tmp_path / "two.npz")
     assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["score"], b["score"])
+    # the line certifies who ran: two ranks, ONE device (the same PCI bus id and UUID twice), no RCCL communicator (gloo) — it cannot be mistaken for a two-GPU run
+    assert len(j2["ranks"]) == 2 and [r["rank"] for r in j2["ranks"]] == [0, 1]
+    assert j2["distinct_devices"] == 1 and j2["shared_gpu"] is True and j2["rccl_ranks"] == 0
+    assert j2["ranks"][0]["pci_bus_id"] == j2["ranks"][1]["pci_bus_id"] != "" and j2["ranks"][0]["uuid"] == j2["ranks"][1]["uuid"]
+    assert j2["ranks"][0]["shard"][1] == j2["ranks"][1]["shard"][0] and j2["ranks"][1]["shard"][1] == 3000
+    j1 = json.loads(one.stdout.strip().splitlines()[-1])
+    assert j1["distinct_devices"] == 1 and j1["shared_gpu"] is False and j1["rccl_ranks"] == 0 and len(j1["ranks"]) == 1 and j1["ranks"][0]["compute_units"] == 256
+
+
+def test_one_rank_with_the_exchange_step_equals_the_plain_run(tmp_path):
+    """The N = 1 invariant: `bench.py --gpus 1 --force-dist` (a process group of one rank, the RCCL all-gather of the rank lists executed for real — torch's and the C++
+    host's own) must print the rank lists of the plain single-process run, and its line must say: one device, one RCCL rank."""
+    import json
+    common = ["--gallery", "3000", "--queries", "6", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--dump-ranks", str(tmp_path / "one.npz")], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a = np.load(tmp_path / "one.npz")
+    for exch in ("torch", "cpp"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), AFIS_EXCHANGE_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        env.pop("AFIS_EXCHANGE", None)
+        f = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--exchange", exch, *common, "--dump-ranks", str(tmp_path / f"f_{exch}.npz")],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert f.returncode == 0, f.stderr[-2000:]
+        j = json.loads(f.stdout.strip().splitlines()[-1])
+        b = np.load(tmp_path / f"f_{exch}.npz")
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["score"], b["score"]), exch
+        assert j["n_gpus"] == 1 and j["distinct_devices"] == 1 and j["shared_gpu"] is False and j["rccl_ranks"] == 1, (exch, j["rccl_ranks"], j["rccl_ranks_is"])
+        if exch == "cpp": assert j["ranks"][0]["rccl_comm_count"] == 1 and j["ranks"][0]["rccl_comm_device"] == 0
 
 
 def _run_match(exe, args, cwd, world=1, extra_env=None, timeout=300):
