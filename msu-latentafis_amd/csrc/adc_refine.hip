@@ -224,6 +224,12 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         // ---- A: lower bounds of every row's maximum (ordered keys, 16 registers) ------------------------------------------------------------
         constexpr int kRegs = (kTexMax + 63) / 64;
         const int n_regs = (n_lt + 63) >> 6;
+        auto bounds_rk = [&](const float4& rk, const uint2& a, float& lo, float& hi) {
+            const float mid = rk.x + 2.0f * u2f(a.x);
+            const float sl = rk.y + 4e-6f * fmaxf(1.0f, fabsf(mid));
+            lo = mid - sl; hi = mid + sl;
+            if (rk.w != 0.0f) { lo = -INFINITY; hi = INFINITY; }
+        };
         auto bounds = [&](int e, const uint2& a, float& lo, float& hi) {
             const float4 rk = rowk[l0 + e];
             const float mid = rk.x + 2.0f * u2f(a.x);
@@ -265,9 +271,41 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         int n_items = 0, n_act = 0;
         const bool compact = rm_n != nullptr;
         unsigned long long st_active = 0, st_items = 0, st_full = 0;
+        // The same value with FOUR lanes per item, lane = one of the reference's four chains (matcher.cpp:571-592: chain c subtracts the entries of sub-quantizers c, c + 4, c + 8, c + 12
+        // in that order from 6 / 0 / 0 / 0; the chains meet as (d0 + d1) + (d2 + d3)): the four lanes of an item read 96 contiguous bytes of the latent row per step instead of every
+        // lane walking its own 384-byte row (64 cache lines per load instruction, 24 instructions per item: the address path of the CU, not the arithmetic, was what the wave waited for).
+        auto exact_sim4 = [&](int e, int p, int c) -> float {                // valid in the lanes with c == 0
+            const uint4 cd = g.tex_codes[r0 + p];
+            const uint32_t w4[4] = {cd.x, cd.y, cd.z, cd.w};
+            const float2* a2 = reinterpret_cast<const float2*>(des + (size_t)e * kDes);
+            float d = c == 0 ? 6.0f : 0.0f;
+            float2 av[4][3];
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) av[mg][k] = a2[3 * (4 * mg + c) + k];
+#pragma unroll
+            for (int mg = 0; mg < 4; ++mg) {
+                const int mm = 4 * mg + c;
+                const float2* wv = reinterpret_cast<const float2*>(s_cw + ((size_t)mm * kK + ((w4[mg] >> (8 * c)) & 255u)) * kDsub);
+                const float2 w0 = wv[0], w1 = wv[1], w2 = wv[2];
+                const float a6[kDsub] = {av[mg][0].x, av[mg][0].y, av[mg][1].x, av[mg][1].y, av[mg][2].x, av[mg][2].y};
+                const float w6[kDsub] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+                d -= lut_entry(a6, w6);
+            }
+            const float t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xF5, 0xf, 0xf, false));   // quad_perm [1, 1, 3, 3]: lane 0 <- d1, lane 2 <- d3
+            const float s2 = d + t;                                                                                    // lane 0: d0 + d1, lane 2: d2 + d3
+            const float u2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2), 0xAA, 0xf, 0xf, false)); // quad_perm [2, 2, 2, 2]
+            return s2 + u2;                                                                                            // lane 0: (d0 + d1) + (d2 + d3)
+        };
         auto flush = [&]() {
             RF_WSYNC();
-            for (int it = lane; it < n_items; it += 64) W.val[it] = exact_sim(W.row[it], W.pt[it]);
+            for (int it0 = 0; it0 < n_items; it0 += 16) {                   // sixteen items per trip
+                const int it = it0 + (lane >> 2);
+                const bool ok = it < n_items;
+                const float v = exact_sim4(W.row[ok ? it : 0], W.pt[ok ? it : 0], lane & 3);
+                if (ok && (lane & 3) == 0) W.val[it] = v;
+            }
             RF_WSYNC();
             for (int it = lane; it < n_items; it += 64) {
                 const int row = W.row[it];
@@ -289,14 +327,17 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             n_items = 0;
             RF_WSYNC();
         };
+        // (the record and the row constants of round u + 1 are fetched before round u is worked on: one exposed memory round trip per pair instead of one per round)
+        uint2 ra_n = make_uint2(0u, 0u); float4 rk_n = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < n_lt) { ra_n = rec0[lane]; rk_n = rowk[l0 + lane]; }
         for (int u = 0; u < n_regs; ++u) {
             const int e = u * 64 + lane;
             const bool in = e < n_lt;
-            uint2 ra = make_uint2(0u, 0u);
+            const uint2 ra = ra_n; const float4 rkc = rk_n;
+            if (e + 64 < n_lt) { ra_n = rec0[e + 64]; rk_n = rowk[l0 + e + 64]; }
             bool active = false;
             if (in) {
-                ra = rec0[e];
-                float lo, hi; bounds(e, ra, lo, hi);
+                float lo, hi; bounds_rk(rkc, ra, lo, hi);
                 active = ord_f32(hi) >= C;
             }
             if (in && !active && !compact) { rm_val[o + e] = -INFINITY; rm_arg[o + e] = 0; }
@@ -348,10 +389,14 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 ++st_full;
             }
             // append this round's items, rows in ascending order (a row's items stay adjacent)
-            int incl = cnt;                                             // inclusive prefix sum over the lanes
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            const int total = __shfl(incl, 63);
+            int incl = cnt;                                             // inclusive prefix sum over the lanes: four row_shr steps inside the rows of 16 lanes, then the totals of the rows below (no LDS permutes)
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+            const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47), t3 = __builtin_amdgcn_readlane(incl, 63);
+            incl += lane < 16 ? 0 : lane < 32 ? t0 : lane < 48 ? t0 + t1 : t0 + t1 + t2;
+            const int total = t0 + t1 + t2 + t3;
             if (n_items + total > kRfItems) flush();
             const int base = n_items + incl - cnt;
 #pragma unroll
