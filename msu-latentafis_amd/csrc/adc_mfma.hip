@@ -247,11 +247,16 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
                 const int jr = j;
 #endif
                 floatx16 nrm;
+#if AFIS_MF_ABLATE == 10                                 // timing experiment only (wrong results): the point terms are not read — what delivering the C operand for free could save at most
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[r] = 0.0f;
+#else
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const float4 v = *reinterpret_cast<const float4*>(&st.nrm[jr][8 * q4 + 4 * h]);
                     nrm[4 * q4] = v.x; nrm[4 * q4 + 1] = v.y; nrm[4 * q4 + 2] = v.z; nrm[4 * q4 + 3] = v.w;
                 }
+#endif
                 const int2 mv = st.meta[j];
                 half8 af[6];
 #pragma unroll
@@ -266,9 +271,20 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
                 }
                 const int my = __builtin_amdgcn_readfirstlane(mv.y);
                 const uint32_t gid = (uint32_t)(2 * (my & 255));
-#if AFIS_MF_ABLATE == 1 || AFIS_MF_ABLATE >= 4          // timing experiments only (wrong results): no tracking
+#if AFIS_MF_ABLATE == 1 || (AFIS_MF_ABLATE >= 4 && AFIS_MF_ABLATE <= 7)          // timing experiments only (wrong results): no tracking
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) m[blk][0] = max3f(m[blk][0], X[blk][0], X[blk][15]);
+                (void)gid;
+#elif AFIS_MF_ABLATE == 11                               // timing experiment only (wrong results): the cheapest conceivable packed tracking — 8 conversions to fp16 pairs + 8 v_pk_max_f16 per 16 values, no group tracking
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                        const half2v pk = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(X[blk][k], X[blk][k + 8]));
+                        const half2v cur = __builtin_bit_cast(half2v, m[blk][k]);
+                        m[blk][k] = __builtin_bit_cast(float, __builtin_elementwise_max(cur, pk));
+                    }
                 (void)gid;
 #else
 #pragma unroll
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
                 if (my & 256) finish_template(__builtin_amdgcn_readfirstlane(mv.x));
             }
         }
-#if AFIS_MF_ABLATE == 3 || AFIS_MF_ABLATE >= 4           // timing experiments only: the stages after the first two are not decoded (stale operands)
+#if AFIS_MF_ABLATE == 3 || (AFIS_MF_ABLATE >= 4 && AFIS_MF_ABLATE <= 7)           // timing experiments only: the stages after the first two are not decoded (stale operands)
         if (s + 1 < n_stages && s < 1) decode((s + 1) & 1, pf_cur);
 #else
         if (s + 1 < n_stages) decode((s + 1) & 1, pf_cur);

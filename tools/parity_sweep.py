@@ -14,7 +14,8 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read(); cb = T.Codebook.from_bytes(cbb)
-lats = S.make_latents(seed, Q); gal = S.make_packed_gallery(seed, G, cb); S.plant_mates(seed, gal, cb, lats, G=G)
+wl = S.WORKLOADS[os.environ.get("AFIS_SWEEP_WORKLOAD", "headline")]                 # AFIS_SWEEP_WORKLOAD=wide: the off-envelope shapes of bench.py --workload wide
+lats = S.make_latents(seed, Q, **wl["latent"]); gal = S.make_packed_gallery(seed, G, cb, **wl["gallery"]); S.plant_mates(seed, gal, cb, lats, G=G)
 m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0)
 if os.environ.get("AFIS_ADC_VARIANT"): m.set_option("adc_variant", int(os.environ["AFIS_ADC_VARIANT"]))
 r = m.search(lats, k=0, want_parts=True)
@@ -39,6 +40,10 @@ for qi, L in enumerate(lats):
         a = np.lexsort((np.arange(G), -s0.astype(np.float64)))[:24]; b = np.lexsort((np.arange(G), -gs.astype(np.float64)))[:24]
         npos = int(min((s0[a] > 0).sum(), (gs[b] > 0).sum()))
         top0 += int(not np.array_equal(a[:npos], b[:npos]))
+tmr = m.timing()
 print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
+print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_any_differing_bit": bad,
+      "candidate_task_routing": {k: int(v) for k, v in tmr.items() if k.startswith("minu_") and k.endswith("tasks")}}))
 if TIE0:
     print(f"  vs tie_mode=0 (reference sort order): {pos0} positive pairs, {bit0} with a differing bit, {far0} beyond 1e-3, queries whose positive top-24 order changes: {top0}")
+    print("TIE0_JSON " + __import__("json").dumps({"seed": seed, "pairs": Q * G, "positive_pairs": pos0, "positive_pairs_with_a_differing_bit": bit0, "pairs_beyond_1e-3": far0, "queries_whose_positive_top24_changes": top0}))
