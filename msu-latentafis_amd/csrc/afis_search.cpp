@@ -309,6 +309,8 @@ int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t aft
 int adc_refine_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, bool compact)
 {
     if (grp.n_lt_rows <= 0 || ctx->gal.G <= 0) return AFIS_OK;
+    static const bool skip = getenv("AFIS_ABLATE_SKIP_TEXTURE_TAIL") != nullptr;    // timing experiments with ablated bound-pass builds (tools/r05_run10.sh): their records are garbage, the kernels behind the pass must not read them
+    if (skip) return AFIS_OK;
     const int R_pad = (grp.n_lt_rows + 31) / 32 * 32;
     HIPCHK(ctx, launch_tex_refine(grp.dev, ctx->gal, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
                                   ctx->rm_arg.as<int32_t>(), ctx->mf_collect_stats ? ctx->mf_stats.as<unsigned long long>() : nullptr,
@@ -384,6 +386,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     size_t gi = 0;
     SideStreamGuard side_guard(ctx);
     bool any_overlap = false;
+    static const bool skip_tex_tail = getenv("AFIS_ABLATE_SKIP_TEXTURE_TAIL") != nullptr;   // timing experiments only (see adc_refine_mfma)
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
@@ -457,7 +460,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 rc9 = adc_refine_mfma(ctx, grp, false, true);
                 if (rc9 != AFIS_OK) return rc9;
                 HIPCHK(ctx, hipEventRecord(ev[2], s));
-                HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
+                if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
                 HIPCHK(ctx, hipEventRecord(ev[3], s));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[7], 0));                              // every candidate list exists: help with whatever lists are left
                 HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s, true));
@@ -487,7 +490,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
 #endif
             }
             HIPCHK(ctx, hipEventRecord(ev[2], s));
-            HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), compact9 ? ctx->rm_cv.as<float>() : nullptr,
+            if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), compact9 ? ctx->rm_cv.as<float>() : nullptr,
                                              compact9 ? ctx->rm_n.as<int32_t>() : nullptr, ctx->parts.as<float>(), nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
             { int rcm = minutiae_stage(); if (rcm != AFIS_OK) return rcm; }
