@@ -446,7 +446,7 @@ def main():
                                          "fast_kernel_large_class": int(tm_acc.get("minu_tasks_large", 0) // a.steps), "any_shape_fallback_kernel": int(tm_acc.get("minu_fallback_tasks", 0) // a.steps),
                                          "fallback_share": round(tm_acc.get("minu_fallback_tasks", 0) / max(1, tm_acc.get("minu_tasks", 0)), 6),
                                          "fast_kernel_limits": {k_: m.get_option(k_) for k_ in ("minu_fast_max_latent", "minu_fast_max_rolled", "minu_fast_max_cells")},
-                                         "how": "counted by the kernels of this run (afis_timing.minu_*): small = <= 64 x 128 minutiae (256-thread workgroups), medium = <= 16 384 similarities (512), large = <= 39 168 incl. the stride padding (1024)"},
+                                         "how": "counted by the kernels of this run (afis_timing.minu_*): small = <= 64 x 128 minutiae (256-thread workgroups), medium = <= 16 384 similarities (512), large = <= 512 rolled minutiae and <= 38 912 similarities incl. the stride padding (1024)"},
             "refine_stats": m.refine_stats() if a.refine_stats else None,
             "per_rank_ms_per_step": {"search": {"min": round(float(pr_min[0]), 3), "max": round(float(pr_max[0]), 3)},
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},

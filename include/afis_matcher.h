@@ -89,7 +89,7 @@ typedef struct afis_timing {
     int64_t minu_fallback_tasks; /* of those: tasks the shape-class kernels handed to the any-shape kernel (k_minu_cands)             */
     int64_t minu_tasks_small;    /* tasks done by the small  shape class of the fast kernel (k_minu_cands_rt<1>: 256 threads, <= 64 x 128) */
     int64_t minu_tasks_medium;   /* ... by the medium class (k_minu_cands_rt<2>: 512 threads, <= 16 384 similarities)                     */
-    int64_t minu_tasks_large;    /* ... by the large  class (k_minu_cands_rt<4>: 1024 threads, <= 39 168 similarities incl. the stride padding, <= 256 x 256) */
+    int64_t minu_tasks_large;    /* ... by the large  class (k_minu_cands_rt<4>: 1024 threads, <= 38 912 similarities incl. the stride padding, <= 256 latent x 512 rolled) */
     float   bound_clock_ghz;     /* shader clock under the bound pass: s_memtime ticks / s_memrealtime (100 MHz) over workgroup lifetimes, mean of the sampled workgroups; 0 = not sampled */
     float   cands_clock_ghz;     /* the same under the candidate kernel (a kernel that is not power-limited, for comparison)          */
 } afis_timing;
@@ -231,8 +231,8 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * opt-in 16-bit tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */
 int afis_set_option(afis_ctx* ctx, const char* name, int64_t value);
-/* The value an option has now (0 = automatic where the table says so).  Read-only: "minu_fast_max_latent" (256), "minu_fast_max_rolled" (256), "minu_fast_max_cells"
- * (39 168, counted with the odd row stride's padding column): the largest minutiae counts / latent x rolled similarities a candidate task may have to run in the matrix-core kernel's shape classes; larger tasks (the
+/* The value an option has now (0 = automatic where the table says so).  Read-only: "minu_fast_max_latent" (256), "minu_fast_max_rolled" (512), "minu_fast_max_cells"
+ * (38 912, counted with the odd row stride's padding column): the largest minutiae counts / latent x rolled similarities a candidate task may have to run in the matrix-core kernel's shape classes; larger tasks (the
  * reference's reader allows 2000 minutiae per template, matcher.cpp:788-790) go to the any-shape kernel — same results, slower (afis_timing.minu_fallback_tasks counts them).  "bound_cus": 128 by default — the bound pass runs on a stream confined to half of the chip's CUs
  * (hipExtStreamCreateWithCUMask) with the minutiae stage beside it on the other half: the pass is power-limited, half the CUs deliver 0.64 of its throughput;
  * 0 = one stream, kernels back to back; 32 ... 224 in steps of 32; the environment variable AFIS_BOUND_CUS sets the initial value. */

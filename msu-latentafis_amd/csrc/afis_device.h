@@ -136,11 +136,11 @@ struct MinuCand { float sim; short li, ri; };
 #else
 #define AFIS_HOST_DEVICE
 #endif
-AFIS_HOST_DEVICE constexpr int rt_class_max_rolled(int S) { return S == 1 ? 128 : 256; }
+AFIS_HOST_DEVICE constexpr int rt_class_max_rolled(int S) { return S == 1 ? 128 : S == 2 ? 256 : 512; }
 AFIS_HOST_DEVICE constexpr int rt_class_max_latent(int S) { return S == 1 ? 64 : 256; }
 // floats of the similarity matrix in LDS: 32 similarities per thread (+ the odd stride's padding column) for S = 1, 2; the large class takes what a CU's 160 KB leave
-// beside the other arrays (39 168 floats = 153 KB) and walks the rows beyond its threads' 32 register keys a second time (k_minu_cands_rt: "key blocks")
-AFIS_HOST_DEVICE constexpr int rt_class_simi_floats(int S) { return S == 1 ? 8192 : S == 2 ? 8192 * 2 + 256 : 39168; }
+// beside the other arrays (38 912 floats = 152 KB) and walks the rows beyond its threads' 32 register keys a second time (k_minu_cands_rt: "key blocks")
+AFIS_HOST_DEVICE constexpr int rt_class_simi_floats(int S) { return S == 1 ? 8192 : S == 2 ? 8192 * 2 + 256 : 38912; }
 AFIS_HOST_DEVICE constexpr int rt_class_keys_per_thread(int S) { return S == 4 ? 64 : 32; }
 AFIS_HOST_DEVICE inline int rt_row_stride(int S, int nR) { return S == 1 ? (((nR & 1) || nR == 128) ? nR : nR + 1) : (nR | 1); }
 AFIS_HOST_DEVICE inline int rt_max_rows(int S, int nR)            // the largest latent minutiae count class S takes against nR rolled minutiae (0: none); non-decreasing in S
@@ -163,7 +163,7 @@ enum { kDiagFallback = 0,       // candidate tasks handed to the any-shape kerne
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
                                 const float* rm_val, const int32_t* rm_arg, const float* rm_cv, const int32_t* rm_n, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
-// (task = (q*3+s)*G + g).  Pairs of up to 256 x 256 minutiae and 39 168 similarities go through the rolled-template-stationary MFMA kernel in one of its
+// (task = (q*3+s)*G + g).  Pairs of up to 256 latent x 512 rolled minutiae and 38 912 similarities go through the rolled-template-stationary MFMA kernel in one of its
 // three shape classes (above); what it cannot take (other shapes, degenerate key distributions) it appends to `fallback` (count, task ids), which the
 // generic kernel then works off.  force_generic: the generic kernel does every task.  max_nL / max_nR: the longest latent list of the launch and the
 // longest rolled minutiae template of the gallery (which classes can have work at all).

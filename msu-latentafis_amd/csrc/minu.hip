@@ -276,11 +276,11 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
 //     out for few instructions per element (thread = column x row phase; <= 32 keys per thread stay in registers between the passes).
 //   * the classes: what bounds a task is its similarity matrix in LDS and the 32 keys per thread.  S = 1 (round 2's kernel): <= 64 latent x
 //     <= 128 rolled minutiae, 37.7 KB, four workgroups per CU; S = 2: <= 16 384 similarities (128 x 128, 64 x 256 ...), 73 KB, two per CU;
-//     S = 4: <= 39 168 incl. the padding column (152 x 256, 160 x 240, 256 x 150 ...), 159 KB, one 16-wave workgroup per CU; its threads keep 32 keys each
+//     S = 4: <= 512 rolled minutiae, <= 38 912 similarities incl. the padding column (151 x 256, 97 x 400, 75 x 512, 256 x 150 ...), 159 KB, one 16-wave workgroup per CU; its threads keep 32 keys each
 //     and recompute the keys of the rows beyond (a second key block).  rt_max_rows(S, nR) (afis_device.h) is the
 //     rule; a task goes to the smallest class that takes it (k_minu_classify lists, per class, the rolled templates that have such tasks in
 //     this launch).
-//   * anything else — more than 256 minutiae on either side or more than 39 168 similarities (the reference's reader allows 2000 per
+//   * anything else — more than 256 latent / 512 rolled minutiae or more than 38 912 similarities (the reference's reader allows 2000 per
 //     template, matcher.cpp:788-790), fewer than 512 entries, a threshold in the two lowest bins (fewer than 120 similarities with a
 //     norm of at least 2^-15), more than 256 candidates — is appended to a fallback list that k_minu_cands (exact threshold
 //     search on exact keys, any shape) works off afterwards.
@@ -312,7 +312,7 @@ template <int S> struct __attribute__((aligned(16))) RtSmem {
     float colsum[RtCfg<S>::kMaxR];
     uint32_t hist[kSelBins];                         // bin b >= 1: approximate keys with bits 30..19 == kBinBase + b (top bin: and above)
     u64 cand[kCandCap + 8];                          // exact composite keys of the candidates (+ zero padding: the ranking reads eight at a time)
-    uint32_t cand_e[kCandCap];                       // their (bin << 16 | row << 8 | column)
+    uint32_t cand_e[kCandCap];                       // their (bin << 17 | row << 9 | column)
     int pad_[4];
     int thr_bin, ticket;
     uint32_t sink[64];                               // where the histogram adds of entries that no bin counts go (one word per lane: conflict free): no branch around the atomic
@@ -518,7 +518,6 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                     }
                 }
             }
-            if (S < 4)                                                               // (16 waves hold every column tile of <= 256 rolled minutiae)
             for (int item = wave; item < (n_jt - kW) * n_it; item += kW) {           // column tiles kW ..: dealt round-robin
                 const int jt = kW + item / n_it, it = item - (jt - kW) * n_it;
                 float af[24], bf[24];
@@ -668,7 +667,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                     const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs);
                     const int bin = max(min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1), B);
                     const uint32_t p = atomicAdd(&sm.hist[bin], 1u);
-                    if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 16) | (i << 8) | cj);
+                    if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 17) | (i << 9) | cj);
                 }
                 if (S == 4 && n_rows > 32) {                                         // the second key block's entries: keys recomputed
                     for (int t = 32; t < my_rows; ++t) {
@@ -677,7 +676,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                         if (key + kKeySlack >= edge) {
                             const int bin = max(min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1), B);
                             const uint32_t p = atomicAdd(&sm.hist[bin], 1u);
-                            if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 16) | (i << 8) | cj);
+                            if (p < (uint32_t)kCandCap) sm.cand_e[p] = (uint32_t)((bin << 17) | (i << 9) | cj);
                         }
                     }
                 }
@@ -690,7 +689,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             uint32_t ke = 0u;
             if (tid < n_c) {                                                         // one exact (double-precision) key per candidate
                 const uint32_t pe = sm.cand_e[tid];
-                cbin = (int)(pe >> 16); ci = (int)((pe >> 8) & 255u); cj2 = (int)(pe & 255u);
+                cbin = (int)(pe >> 17); ci = (int)((pe >> 9) & 255u); cj2 = (int)(pe & 511u);
                 ke = exact_norm_key(sm.simi[ci * ld + cj2], sm.rowsum[ci], sm.colsum[cj2]);
                 sm.cand[tid] = ((u64)ke << 16) | (u64)(65535 - (ci * nR + cj2));
             }
@@ -775,7 +774,7 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
         if (max_nL > rt_class_max_latent(1) || max_nR > rt_class_max_rolled(1)) {
             e = launch_rt_class<2>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
             if (e != hipSuccess) return e;
-            if (max_nL > rt_max_rows(2, mr)) {
+            if (max_nR > rt_class_max_rolled(2) || max_nL > rt_max_rows(2, mr)) {
                 e = launch_rt_class<4>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
                 if (e != hipSuccess) return e;
             }

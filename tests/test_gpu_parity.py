@@ -1297,14 +1297,15 @@ def test_off_envelope_shapes_against_oracle(codebook_bytes, cb, oracle):
 
 def test_candidate_shape_classes_lists_match_oracle_traces(codebook_bytes, cb, oracle):
     """The candidate list (S3: members, order, similarity bits) of pairs in every shape class of k_minu_cands_rt — small (<= 64 x 128), medium (<= 16 384 similarities),
-    large (<= 39 168 incl. the padding column), at the classes' own borders (rt_max_rows) — and just beyond them (any-shape kernel), against the oracle's stage-0 trace; then the same pairs'
+    large (<= 512 rolled minutiae, <= 38 912 similarities incl. the padding column), at the classes' own borders (rt_max_rows) — and just beyond them (any-shape kernel), against the oracle's stage-0 trace; then the same pairs'
     scores through the generic kernel alone (option minu_generic) must be the same bits.  matcher.cpp:440-488."""
     rng = np.random.default_rng(314)
     # (latent minutiae, rolled minutiae) at the class borders of rt_max_rows(): 64 x 128 | 65 x 128, 64 x 129 | 128 x 128 (S = 2: 16 640 / 129 = 128) | 129 x 128 |
-    # 64 x 256 (S = 2: two row phases) | 65 x 256 (S = 4) | 128 x 256 (the last shape whose keys all stay in registers) | 129 x 256, 152 x 256 (S = 4 with a second key block;
-    # 39 168 / 257 = 152) | 153 x 256 (any-shape kernel) | 256 x 128 | 256 x 150, 200 x 190 (second key block, six / five row phases) | 257 x 100, 40 x 300 (any-shape kernel) | 30 x 17 (tiny)
-    shapes = [(64, 128), (65, 128), (64, 129), (128, 128), (129, 128), (64, 256), (65, 256), (128, 256), (129, 256), (152, 256), (153, 256), (256, 128), (256, 150), (200, 190),
-              (257, 100), (40, 300), (30, 17)]
+    # 64 x 256 (S = 2: two row phases) | 65 x 256 (S = 4) | 128 x 256 (the last shape whose keys all stay in registers) | 129 x 256, 151 x 256 (S = 4 with a second key block;
+    # 38 912 / 257 = 151) | 152 x 256 (any-shape kernel) | 256 x 128 | 256 x 150, 200 x 190 (second key block, six / five row phases) | 60 x 300, 97 x 400, 75 x 512 (S = 4 with more column
+    # tiles than waves; 38 912 / 401 = 97, / 513 = 75) | 98 x 400, 40 x 513, 257 x 100 (any-shape kernel) | 30 x 17 (tiny)
+    shapes = [(64, 128), (65, 128), (64, 129), (128, 128), (129, 128), (64, 256), (65, 256), (128, 256), (129, 256), (151, 256), (152, 256), (256, 128), (256, 150), (200, 190),
+              (60, 300), (97, 400), (75, 512), (98, 400), (40, 513), (257, 100), (30, 17)]
     lat_sizes = sorted({s[0] for s in shapes})
     lats = {}
     for nl in lat_sizes:
@@ -1336,5 +1337,5 @@ def test_candidate_shape_classes_lists_match_oracle_traces(codebook_bytes, cb, o
     m.set_option("minu_generic", 1)
     gen = m.search(L, k=0, want_parts=True)
     assert np.array_equal(fast["parts"].view(np.uint32), gen["parts"].view(np.uint32))
-    assert m.get_option("minu_fast_max_latent") == 256 and m.get_option("minu_fast_max_rolled") == 256 and m.get_option("minu_fast_max_cells") == 39168
+    assert m.get_option("minu_fast_max_latent") == 256 and m.get_option("minu_fast_max_rolled") == 512 and m.get_option("minu_fast_max_cells") == 38912
     m.close()
