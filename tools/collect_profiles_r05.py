@@ -81,7 +81,7 @@ b, r = units["k_adc_mfma"], units["k_tex_refine"]
 sq = pick(sqb, "k_adc_mfma")
 xcd = sq["GRBM_GUI_ACTIVE"] / 8
 fetch_b = 2 * b["fetch_KB_raw"] * 1024; write_b = b["write_KB_raw"] * 1024
-r_fetch_lo = r["fetch_KB_raw"] * 1024; r_fetch_hi = 2 * r_fetch_lo; r_write = r["write_KB_raw"] * 1024
+r_raw = r["fetch_KB_raw"] * 1024; r_fetch_lo = r_raw + 0.5 * write_b; r_fetch_hi = r_raw + 1.0 * write_b; r_write = r["write_KB_raw"] * 1024     # the records (= the bound pass's writes) are an 8 B/lane coalesced stream, tallied at half (profiles/r05_fetch_calibration.json), read once or twice from the fabric
 alg_bytes = bench["roofline"]["hbm_view"]["alg_bytes_per_launch"]
 bound_cus = bench["config"].get("bound_cus", 0)
 out = {
@@ -98,8 +98,8 @@ out = {
                        "(round 3: two, one per lane half: 17.9 GB per launch)",
     "stage_traffic": {"what": "bound pass + selection / recomputation kernel, HBM-side bytes per launch", "bound_pass": fetch_b + write_b,
                       "refine_fetch_x1": r_fetch_lo, "refine_fetch_x2": r_fetch_hi, "refine_write": r_write,
-                      "refine_fetch_note": "the recomputation kernel mixes coalesced 8 B / 16 B per lane streams (records, row constants: reported at half) with 16-byte gathers of code words (64-byte requests, "
-                                           "reported in full): its true fetch lies between FETCH_SIZE x 1 and x 2",
+                      "refine_fetch_note": "FETCH_SIZE as reported + the untallied half of the record stream (8 B per lane, coalesced: tallied at exactly half, profiles/r05_fetch_calibration.json) for one (x1 key) or two (x2 key) reads of the records that reach the fabric; "
+                                           "the 16-byte code-word gathers are 64-byte requests tallied in full",
                       "total_low": fetch_b + write_b + r_fetch_lo + r_write, "total_high": fetch_b + write_b + r_fetch_hi + r_write, "algorithmic_bytes_per_launch": alg_bytes,
                       "ratio_low": round((fetch_b + write_b + r_fetch_lo + r_write) / alg_bytes, 3), "ratio_high": round((fetch_b + write_b + r_fetch_hi + r_write) / alg_bytes, 3)},
     "fractions": {
@@ -175,7 +175,7 @@ for key, what in KERNELS:
 s_ = out["stage_traffic"]
 L.append(f"\n## HBM-side traffic of the ADC stage per launch (PMC passes; bound pass FETCH_SIZE x 2)\n")
 L.append("| term | GB |\n|---|---|")
-L.append(f"| bound pass reads | {fetch_b / 1e9:.1f} |\n| bound pass writes (one 8-byte record per row and template) | {write_b / 1e9:.1f} |\n| recomputation reads (FETCH_SIZE x 1 ... x 2) | {r_fetch_lo / 1e9:.1f} ... {r_fetch_hi / 1e9:.1f} |"
+L.append(f"| bound pass reads | {fetch_b / 1e9:.1f} |\n| bound pass writes (one 8-byte record per row and template) | {write_b / 1e9:.1f} |\n| recomputation reads (FETCH_SIZE + the untallied half of the record stream, read once ... twice from the fabric) | {r_fetch_lo / 1e9:.1f} ... {r_fetch_hi / 1e9:.1f} |"
          f"\n| recomputation writes | {r_write / 1e9:.1f} |\n| stage total | {s_['total_low'] / 1e9:.1f} ... {s_['total_high'] / 1e9:.1f} |\n| algorithmic (24 B per rolled point per latent) | {alg_bytes / 1e9:.1f} |"
          f"\n| ratio | {s_['ratio_low']:.2f} ... {s_['ratio_high']:.2f} |\n")
 rs = rstats["refine_stats"]

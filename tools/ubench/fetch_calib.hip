@@ -4,6 +4,7 @@
 //                    gathers per lane in flight (the refine of k_adc_rowmin_q: 16 dependent-free look-ups per candidate)
 //                    table >> L2 + Infinity Cache (e.g. 16384 MiB): nearly every gather misses everything -> one fabric request each
 //                    table = 86 MiB (one query group's fp32 table): the Infinity Cache absorbs most of them
+//   mode 2  stream8: every lane reads 8 B, fully coalesced (the recomputation kernel's record stream: 512 contiguous bytes per wave load), once       -> known bytes = buffer size
 // Run each mode under  rocprofv3 --pmc FETCH_SIZE --kernel-trace  and under  --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum ; this program prints the
 // known counts as JSON, tools/profile_round3.sh joins them with the counters.
 //   hipcc --offload-arch=gfx950 -O3 fetch_calib.hip -o fetch_calib && ./fetch_calib <mode> <mb> [n_gathers]
@@ -14,6 +15,12 @@ __global__ void k_stream(const uint4* __restrict__ p, size_t n16, unsigned* out)
 {
     unsigned acc = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = p[i]; acc += v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) out[0] = acc;
+}
+__global__ void k_stream8(const uint2* __restrict__ p, size_t n8, unsigned* out)
+{
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) { const uint2 v = p[i]; acc += v.x ^ v.y; }
     if (acc == 0x12345678u) out[0] = acc;
 }
 __device__ __forceinline__ unsigned hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
@@ -45,10 +52,12 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
     if (mode == 0) hipLaunchKernelGGL(k_stream, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)d, bytes / 16, out);
+    else if (mode == 2) hipLaunchKernelGGL(k_stream8, dim3(256 * 16), dim3(256), 0, 0, (const uint2*)d, bytes / 8, out);
     else hipLaunchKernelGGL(k_gather4, dim3(256 * 16), dim3(256), 0, 0, (const unsigned*)d, (unsigned long long)(bytes / 4), n, out);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-    if (mode == 0) printf("{\"mode\": \"stream16\", \"kernel\": \"k_stream\", \"buffer_mib\": %zu, \"known_bytes\": %zu, \"ms\": %.3f, \"GBps\": %.1f}\n", mb, bytes, ms, bytes / (ms * 1e-3) / 1e9);
+    if (mode == 2) printf("{\"mode\": \"stream8\", \"kernel\": \"k_stream8\", \"buffer_mib\": %zu, \"known_bytes\": %zu, \"ms\": %.3f, \"GBps\": %.1f}\n", mb, bytes, ms, bytes / (ms * 1e-3) / 1e9);
+    else if (mode == 0) printf("{\"mode\": \"stream16\", \"kernel\": \"k_stream\", \"buffer_mib\": %zu, \"known_bytes\": %zu, \"ms\": %.3f, \"GBps\": %.1f}\n", mb, bytes, ms, bytes / (ms * 1e-3) / 1e9);
     else printf("{\"mode\": \"gather4\", \"kernel\": \"k_gather4\", \"table_mib\": %zu, \"gathers\": %llu, \"useful_bytes\": %llu, \"bytes_if_64B_per_gather\": %llu, \"ms\": %.3f, \"gathers_per_s\": %.3e}\n",
                 mb, n, n * 4ull, n * 64ull, ms, n / (ms * 1e-3));
     return 0;
