@@ -86,15 +86,28 @@ void afis_destroy(afis_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    static const bool trace = getenv("AFIS_DESTROY_TRACE") != nullptr;       // development aid: where a destroy spends its time, on stderr
+    auto lap = [&](const char* what) { if (trace) { fprintf(stderr, "afis_destroy: %s\n", what); fflush(stderr); } };
+    // the side streams first, the context's stream last: work on the context's stream may wait for events of the side streams, and a blocking wait on it alone has been seen
+    // not to return while they had not been waited for themselves (tools/repro/README.md)
+    lap("waiting for the side streams");
+    for (hipStream_t* ps : {&c->stream_lo, &c->stream_hi}) if (*ps) (void)hipStreamSynchronize(*ps);
+    lap("waiting for the context's stream");
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (hipStream_t* ps : {&c->stream_lo, &c->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
+    lap("destroying the side streams");
+    for (hipStream_t* ps : {&c->stream_lo, &c->stream_hi}) if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
+    lap("freeing device memory");
+    if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_bytes = 0; }
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release(); c->rm_cv.release(); c->rm_n.release();
     c->parts.release(); c->scores.release(); c->scratch.release(); c->cands.release(); c->cand_n.release(); c->minu_fb.release(); c->diag.release(); c->topk_idx.release(); c->topk_score.release(); c->lutq.release(); c->lutq_min.release(); c->lutq_rng.release(); c->lutq_rowc.release(); c->lut32.release();
     c->mf_cw16.release(); c->mf_cwn.release(); c->mf_bfrag.release(); c->mf_rowk.release(); c->mf_rec.release(); c->mf_stats.release();
+    lap("destroying events and the context's stream");
     for (auto& e : c->evpool) if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    lap("joining the staging thread");
     if (c->staging_reaper.joinable()) c->staging_reaper.join();
+    lap("done");
     delete c;
 }
 

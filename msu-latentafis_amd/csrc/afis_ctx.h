@@ -106,6 +106,7 @@ struct afis_ctx {
     DevBuf lut, rm_val, rm_arg, rm_cv, rm_n, parts, scores, scratch, cands, cand_n, minu_fb, topk_idx, topk_score;
     DevBuf diag;                         // kDiagWords unsigned 64-bit counters per launch group of a search (afis_device.h): zeroed when the search starts, read back with its results
     std::vector<unsigned long long> h_diag;
+    void* h_pin = nullptr; size_t h_pin_bytes = 0;   // pinned host buffer for what a search reads back inside its wait (rank lists, diagnostics)
     std::vector<float> h_scores, h_parts;
     int adc_variant = 9;                 // 9: fp16 matrix-core bound pass + exact recomputation (default); 8: 16-bit LDS-table bound pass + exact refine; 7: direct exact kernel; 0-3, 6: earlier direct kernels
     int tile_share = 0;                  // adc_variant 8: consecutive chunks per tile on an XCD; 0 = 4 (the refine's fp32 table stays in L2)
