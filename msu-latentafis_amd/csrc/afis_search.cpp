@@ -357,7 +357,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         if (n_pairs > 0) {
             HIPCHK(ctx, ctx->rm_val.ensure(n_pairs * lt_cap * 4));
             HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * lt_cap * 4));
-            HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
+            HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));   // per-part scores on request: every group's block stays on the device until the search is done
             HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
@@ -401,7 +401,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
             HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
             if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
-            HIPCHK(ctx, ctx->parts.ensure(n_pairs * 16));
+            HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));
             // minutiae scratch per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs the fast kernel cannot take use it)
             size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
             int n_wg = 1024;
@@ -411,6 +411,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
             float* grp_scores = ctx->scores.as<float>() + (size_t)q0 * G;
+            float* const grp_parts = ctx->parts.as<float>() + (parts ? (size_t)q0 * G * 4 : 0);
             // One ADC workgroup fills a CU (128 KB LUT tile), so nothing overlaps its tile load: chunks of ~640 templates keep that
             // under 3 % of a workgroup's life.  The blocks of XCD x are the chunks c % 8 == x, so the chunk COUNT is a multiple of 8
             // (measured at a 12.5k shard: 98 chunks of 128 -> 24 of 521: -9 % ADC time; at 100k: 196 of 512 -> 160 of 625: -2.5 %).
@@ -435,7 +436,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             auto minutiae_stage = [&]() -> int {
                 HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, s));
                 HIPCHK(ctx, hipEventRecord(ev[7], s));
-                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2, s));
                 return AFIS_OK;
             };
             if (overlap) {
@@ -453,17 +454,17 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, sh));
                 HIPCHK(ctx, hipMemsetAsync(g.task_ctr + 1, 0, 4, sh));                     // the list counter both instances of the list kernel draw from: reset BEFORE either may start
                 HIPCHK(ctx, hipEventRecord(ev[7], sh));
-                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, sh, true));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2, sh, true));
                 HIPCHK(ctx, hipEventRecord(ev[4], sh));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[6], 0));
                 HIPCHK(ctx, hipEventRecord(ev[8], s));                                     // the bound pass is done
                 rc9 = adc_refine_mfma(ctx, grp, false, true);
                 if (rc9 != AFIS_OK) return rc9;
                 HIPCHK(ctx, hipEventRecord(ev[2], s));
-                if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, 2, s));
+                if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), grp_parts, nullptr, nullptr, 2, s));
                 HIPCHK(ctx, hipEventRecord(ev[3], s));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[7], 0));                              // every candidate list exists: help with whatever lists are left
-                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr, nullptr, nullptr, 2, s, true));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2, s, true));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[4], 0));
                 // No host wait here: the groups of a search follow one another on the three streams through events alone, and the search's final wait polls ALL THREE streams
                 // (wait_streams).  Round 4 blocked on the two side streams after every group because hipStreamSynchronize of the context's stream alone never returned with
@@ -491,16 +492,14 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             }
             HIPCHK(ctx, hipEventRecord(ev[2], s));
             if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), compact9 ? ctx->rm_cv.as<float>() : nullptr,
-                                             compact9 ? ctx->rm_n.as<int32_t>() : nullptr, ctx->parts.as<float>(), nullptr, nullptr, 2, s));
+                                             compact9 ? ctx->rm_n.as<int32_t>() : nullptr, grp_parts, nullptr, nullptr, 2, s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
             { int rcm = minutiae_stage(); if (rcm != AFIS_OK) return rcm; }
             HIPCHK(ctx, hipEventRecord(ev[4], s));
             }
             HIPCHK(ctx, hipEventRecord(ev[9], s));
-            HIPCHK(ctx, launch_fuse(d, g, ctx->parts.as<float>(), grp_scores, s));
+            HIPCHK(ctx, launch_fuse(d, g, grp_parts, grp_scores, s));
             HIPCHK(ctx, hipEventRecord(ev[5], s));
-            // per-part scores only on request (tests, the all-templates mode); stream order keeps the buffer intact until the copy is done
-            if (parts) HIPCHK(ctx, hipMemcpyAsync(parts + (size_t)q0 * G * 4, ctx->parts.p, n_pairs * 16, hipMemcpyDeviceToHost, s));
             if (d.n_tiles > 0) {
                 tm.adc_launches += 1;
                 const int tile_rows = ctx->adc_variant == 8 ? 16 : kTileRows;   // rows the launched kernel pads a latent to (variant 9 does no table look-ups: the count is nominal there)
@@ -545,6 +544,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     if (dev_topk) { memcpy(topk_idx, pin, (size_t)nq_all * k * 8); memcpy(topk_score, pin + (size_t)nq_all * k * 8, (size_t)nq_all * k * 4); }
     ctx->h_diag.assign(std::max<size_t>(n_groups, 1) * kDiagWords, 0ull);
     memcpy(ctx->h_diag.data(), pin + pin_topk, pin_diag);
+    if (parts && G > 0 && nq_all > 0) HIPCHK(ctx, hipMemcpy(parts, ctx->parts.p, (size_t)nq_all * G * 16, hipMemcpyDeviceToHost));   // per-part scores on request (tests, the all-templates mode)
     const bool host_topk = k > 0 && !dev_topk;
     float* h_sc = scores;
     if (G > 0 && nq_all > 0 && (scores || host_topk)) {                    // the device is idle now: a plain copy
