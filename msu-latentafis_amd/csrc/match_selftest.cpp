@@ -5,9 +5,11 @@
 //   match_selftest -selftest-shards <weights file> -world N  shard cut rule (rank_exchange.cpp) — equals host/sharding.py
 //   match_selftest -selftest-exchange                        rendezvous: rank 0's 128 bytes reach every rank (RANK/WORLD_SIZE/MASTER_* env)
 //   match_selftest -selftest-allgather                       AFIS_EXCHANGE=tcp all-gather + the agreement point, N local ranks
+//   match_selftest -selftest-classes                         the candidate kernel's shape-class rule (afis_device.h: rt_max_rows) as a table: nR  L1 L2 L4  stride1 stride2 stride4
 #include <cstring>
 #include <iostream>
 
+#include "afis_device.h"
 #include "cli_util.h"
 #include "rank_exchange.h"
 
@@ -16,6 +18,13 @@ using namespace afis;
 int main(int argc, char** argv)
 {
     ArgParser args(argc, argv);
+    if (args.cmdOptionExists("-selftest-classes")) {                            // host-side class rule of k_minu_cands_rt (no GPU): tests/test_host.py checks its invariants
+        std::cout << rt_class_simi_floats(1) << " " << rt_class_simi_floats(2) << " " << rt_class_simi_floats(4) << " " << rt_class_keys_per_thread(1) << " " << rt_class_keys_per_thread(2) << " "
+                  << rt_class_keys_per_thread(4) << " " << rt_class_max_rolled(4) << " " << rt_class_max_latent(4) << std::endl;
+        for (int nR = 0; nR <= 2000; ++nR)
+            std::cout << nR << " " << rt_max_rows(1, nR) << " " << rt_max_rows(2, nR) << " " << rt_max_rows(4, nR) << " " << rt_row_stride(1, nR) << " " << rt_row_stride(2, nR) << " " << rt_row_stride(4, nR) << std::endl;
+        return 0;
+    }
     if (args.cmdOptionExists("-selftest-exchange")) {                           // rendezvous only (no GPU): rank 0's 128 bytes reach every rank
         RankWorld w; world_from_env(w);
         unsigned char id[128];

@@ -320,3 +320,34 @@ def test_device_atan2f_restatement_equals_libm_on_the_host(tmp_path):
     out = subprocess.run([str(exe), "700"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "1962801 points, 0 mismatches" in out.stdout and "16000000 points, 0 mismatches" in out.stdout
+
+
+def test_candidate_shape_class_rule_keeps_every_task_inside_its_class_limits():
+    """The rule that routes a minutiae candidate task (nL latent x nR rolled minutiae) to a shape class of k_minu_cands_rt (afis_device.h: rt_max_rows) is host-side arithmetic the
+    kernels TRUST: a task admitted to class S must fit the class's similarity matrix in LDS with its row stride, its rows must be covered by the keys a thread holds (32, the large
+    class twice that) times the row phases 256 S / nR, the stride must be odd (conflict-free sums; the one exception is the small class's 128), and a larger class must take at least
+    what a smaller one takes.  Checked for every nR the reader accepts (matcher.cpp:788-790: up to 2000)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "msu-latentafis_amd", "csrc")
+    exe = os.path.join(csrc, "match_selftest")
+    subprocess.run(["make", "-s", "-C", csrc, "match_selftest"], check=True)
+    out = subprocess.run([exe, "-selftest-classes"], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    simi1, simi2, simi4, k1, k2, k4, max_r, max_l = (int(x) for x in out[0].split())
+    simi = {1: simi1, 2: simi2, 4: simi4}; keys = {1: k1, 2: k2, 4: k4}
+    assert (simi1, k1, k2, k4, max_r, max_l) == (8192, 32, 32, 64, 512, 256)
+    assert 4 * simi4 + 7192 <= 160 * 1024                      # the large class's matrix + its other LDS arrays fit a CU's 160 KB
+    rows = [[int(x) for x in l.split()] for l in out[1:]]
+    assert [r[0] for r in rows] == list(range(2001))
+    for nR, L1, L2, L4, s1, s2, s4 in rows:
+        L = {1: L1, 2: L2, 4: L4}; st = {1: s1, 2: s2, 4: s4}
+        assert 0 <= L1 <= L2 <= L4 <= 256, nR
+        if nR == 0 or nR > 512: assert L4 == 0, nR
+        for S_ in (1, 2, 4):
+            if L[S_] == 0: continue
+            assert st[S_] >= nR and (st[S_] % 2 == 1 or (S_ == 1 and nR == 128)), (S_, nR)
+            assert L[S_] * st[S_] <= simi[S_], (S_, nR)                                   # the matrix fits
+            assert L[S_] <= keys[S_] * ((256 * S_) // nR), (S_, nR)                         # every row has a key slot
+            assert (256 * S_) // nR >= 2, (S_, nR)                                          # at least two row phases: the selection's thread mapping
+            max_rolled = {1: 128, 2: 256, 4: 512}[S_]
+            assert nR <= max_rolled and max_rolled + L[S_] <= 256 * S_, (S_, nR)               # thread j sums column j, thread max_rolled + i sums row i: both exist
+    assert rows[128][1] == 64 and rows[129][1] == 0 and rows[128][2] == 128 and rows[129][2] == 96 and rows[256][2] == 64 and rows[256][3] == 151 and rows[257][2] == 0 and rows[400][3] == 97 and rows[512][3] == 75 and rows[513][3] == 0
