@@ -114,6 +114,7 @@ struct afis_ctx {
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     double search_timeout_s = 600.0;     // bound on every host wait of a search (AFIS_SEARCH_TIMEOUT_S; <= 0: plain hipStreamSynchronize, unbounded)
+    bool search_abandoned = false;       // the last search returned at its deadline: the device may still be working on it (the next search waits for it first)
     bool overlap_failed = false;         // a wait of the overlapped schedule timed out: later searches keep to one stream
     double overlap_cell_ratio = 0.037;   // a launch group runs the overlapped schedule while (latent x rolled minutiae cells) <= this x (latent texture rows x rolled texture points); AFIS_OVERLAP_CELL_RATIO
     int64_t rowmax_budget_bytes = 0;     // device memory a launch group's per-pair buffers may take (option rowmax_budget_mb); 0 = 60 % of what hipMemGetInfo reports free
@@ -200,5 +201,6 @@ int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t aft
 int ensure_codes_cf(afis_ctx* ctx, int variant);       // the direct kernels' lane-ordered code stream (adc_variant 6 / 7), laid out at first use
 #endif
 int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, const char* what);
+int drain_abandoned(afis_ctx* ctx);                     // waits (bounded) for a search that returned at its deadline
 
 }  // namespace afis

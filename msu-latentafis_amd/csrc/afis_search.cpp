@@ -49,6 +49,7 @@ int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, cons
         if (all) return AFIS_OK;
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->search_timeout_s) {     // (every round: a hipStreamQuery of a busy stream takes milliseconds on this runtime, not microseconds)
             if (streams.size() > 1) ctx->overlap_failed = true;
+            ctx->search_abandoned = true;
             char msg[256];
             snprintf(msg, sizeof msg, "%s: the device did not finish within %.3g s (AFIS_SEARCH_TIMEOUT_S)%s", what, ctx->search_timeout_s,
                      streams.size() > 1 ? "; the overlapped schedule is switched off for this context (bound_cus 0)" : "");
@@ -56,6 +57,15 @@ int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, cons
         }
         if (spins < 20000) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
+}
+
+// A search that left at its deadline may still be running on the device: what it queued must be done before its buffers (device, pinned) are touched again and before anything
+// blocks on the context's stream alone.  Called at the top of the entry points that queue work.
+int drain_abandoned(afis_ctx* ctx)
+{
+    if (!ctx->search_abandoned) return AFIS_OK;
+    ctx->search_abandoned = false;
+    return wait_streams(ctx, {ctx->stream_lo, ctx->stream_hi, ctx->stream}, "waiting for the search that timed out");   // (a second timeout sets the flag again)
 }
 
 // Work queued on the side streams must not outlive a failing search (it reads and writes the context's buffers): armed when the first kernel goes to a side stream,
@@ -150,6 +160,7 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     if (!ctx || !out || n_q < 0 || (n_q > 0 && !queries)) return fail(ctx, AFIS_EINVAL, "afis_queries_upload: bad argument");
     if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_queries_upload: commit the gallery first");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rcd = drain_abandoned(ctx); if (rcd != AFIS_OK) return rcd; }
     // group size: bounded by the option and by the memory budget of a group's per-pair buffers
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
     const int64_t by_mem = group_budget_bytes(ctx) / group_bytes_per_query(ctx, G);
@@ -332,6 +343,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_search: commit the gallery first");
     if (k < 0 || (k > 0 && (!topk_idx || !topk_score))) return fail(ctx, AFIS_EINVAL, "afis_search: k > 0 needs topk_idx and topk_score");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rcd = drain_abandoned(ctx); if (rcd != AFIS_OK) return rcd; }
     const GalleryDev& g = ctx->gal;
     const int64_t G = g.G;
     const int nq_all = q->n_q;
@@ -609,6 +621,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
     if (!ctx->committed) return fail(ctx, AFIS_ESTATE, "afis_correspondences: commit the gallery first");
     if (n == 0) return AFIS_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rcd = drain_abandoned(ctx); if (rcd != AFIS_OK) return rcd; }
     const GalleryDev& g = ctx->gal;
     for (int i = 0; i < n; ++i)
         if (gallery_idx[i] < ctx->index_base || gallery_idx[i] >= ctx->index_base + g.G) return fail(ctx, AFIS_EINVAL, "afis_correspondences: gallery index outside this shard");
@@ -683,6 +696,7 @@ int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, flo
     for (size_t i = 0; i < (size_t)G * width; ++i) scores[i] = 0.0f;                                             // :342-343
     if (width == 0 || G == 0) return AFIS_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    { const int rcd = drain_abandoned(ctx); if (rcd != AFIS_OK) return rcd; }
     const int n_pq = std::max((n_minu + 2) / 3, n_tex);
     const int64_t by_mem = std::max<int64_t>(1, group_budget_bytes(ctx) / group_bytes_per_query(ctx, G));
     const int per = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->query_batch > 0 ? ctx->query_batch : 10, by_mem));

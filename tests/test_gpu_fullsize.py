@@ -271,7 +271,7 @@ def test_a_search_that_outlasts_its_deadline_returns_an_error_and_the_context_re
         m.search_resident(qh, k=0)
     assert time.time() - t0 < 2.0                                        # it came back at the deadline, not when the device was done
     assert m.get_option("bound_cus") == 0                                # the overlapped schedule is off for this context
-    time.sleep(6.0)                                                      # the device drains what the failed call had queued
+    time.sleep(0.5)                                                      # (the next call waits for what the failed one had queued: no need to)
     m.set_option("search_timeout_s", 600)
     sub = [5, 50]
     r = m.search([lats[i] for i in sub], k=24)                           # one stream now
