@@ -725,7 +725,9 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             }
             if (tid == 0) cand_n[task] = kTopMinu;
             ++n_done;
+#if AFIS_MC_ABLATE != 3                                                  // (3: timing experiment only — no barrier at the end of a task: what dropping it could give at most)
             RT_SYNC();
+#endif
             PHASE(20);
         }
     }
