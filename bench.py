@@ -382,7 +382,7 @@ def main():
             ck_b, ck_c = clock["bound_pass_ghz"], clock["candidate_kernel_ghz"]
             if alone and alone.get("bound_clock_ghz", 0) > 0:
                 limiting = ("measured in this run: alone on the chip the bound pass holds %.2f GHz against %.2f GHz under the candidate kernel (ratio %.2f) — the chip lowers its clock under this kernel's matrix work; "
-                            "in the timed schedule (%s) it holds %.2f GHz. What the kernel's own loop can reach with tracking / decode compiled out is a row of profiles/r04_bound_pass_ablation.json (not re-measured here)"
+                            "in the timed schedule (%s) it holds %.2f GHz. What the kernel's own loop can reach with tracking / decode compiled out is a row of profiles/r05_bound_pass_ablation.json / r04_bound_pass_ablation.json (timing-only ablations; not re-measured here)"
                             % (alone["bound_clock_ghz"], alone["cands_clock_ghz"], alone["bound_clock_ghz"] / max(1e-9, alone["cands_clock_ghz"]),
                                ("confined to %d CUs" % bound_cus) if bound_cus > 0 else "all CUs", ck_b))
             else:
