@@ -25,8 +25,9 @@ int64_t group_budget_bytes(const afis_ctx* ctx)
     return std::max<int64_t>(1ll << 30, (int64_t)((double)(free_b + held) * 0.6));
 }
 
-// Host wait for streams with a deadline: hipStreamQuery on each of them in turn (which also keeps every one of them submitting: with ROCm 7.2 a hipStreamSynchronize
-// of the context's stream ALONE never returned while work it depends on sat on the CU-masked side streams — tools/repro/side_stream_hang.hip), a yield between rounds
+// Host wait for streams with a deadline: hipStreamQuery on each of them in turn (which also keeps every one of them submitting: with ROCm 7.2 a blocking hipStreamSynchronize
+// of the context's stream ALONE was seen not to return while work it depended on sat on the CU-masked side streams — round 4; round 5 saw it once more, in afis_destroy after an
+// early return; tools/repro/README.md), a yield between rounds
 // and a short sleep once the wait is long.  A device that does not come back within search_timeout_s is reported as AFIS_EDEVICE instead of holding the caller's
 // thread for ever; when that happens with side streams in use, the context stops using them (bound_cus off: one stream, the kernels back to back).
 int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, const char* what)
@@ -47,7 +48,7 @@ int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, cons
             else if (e != hipSuccess) return fail(ctx, AFIS_EDEVICE, std::string(what) + ": hipStreamQuery: " + hipGetErrorString(e));
         }
         if (all) return AFIS_OK;
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->search_timeout_s) {     // (every round: a hipStreamQuery of a busy stream takes milliseconds on this runtime, not microseconds)
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > ctx->search_timeout_s) {     // (looked at every round: hipStreamQuery itself returns in microseconds — tools/repro/side_stream_hang.hip, mode 5)
             if (streams.size() > 1) ctx->overlap_failed = true;
             ctx->search_abandoned = true;
             char msg[256];
