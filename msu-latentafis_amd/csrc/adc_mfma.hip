@@ -23,6 +23,9 @@
 #ifndef AFIS_MF_ABLATE
 #define AFIS_MF_ABLATE 0
 #endif
+#ifndef AFIS_MF_PREFETCH
+#define AFIS_MF_PREFETCH 1
+#endif
 
 namespace afis {
 
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
     const int n_stages = (n_tiles + kStageTiles - 1) / kStageTiles;
     // The clock the chip holds under THIS kernel (afis_timing.bound_clock_ghz): one lane of every 64th workgroup reads the shader-cycle counter (s_memtime) and the
     // constant 100 MHz counter (s_memrealtime) when its workgroup starts and when it ends; the sums of the differences go to the launch group's diagnostics row.
-    const bool sampler = diag != nullptr && (blockIdx.x & 63) == 0 && tid == 0;
+    const bool sampler = diag != nullptr && (blockIdx.x & 63) == 0 && wave == 0;      // wave-uniform: the two counters stay in scalar registers; lane 0 adds them up at the end
     unsigned long long clk0 = 0, wall0 = 0;
     if (sampler) { clk0 = __builtin_readcyclecounter(); wall0 = wall_clock64(); }
     for (int i = tid; i < kM * kK; i += kThreads) s_cw[i] = cw16[i];
@@ -239,6 +242,16 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
         fetch(s + 2, pf_nxt);
         const M12Stage<kStageTiles>& st = s_st[s & 1];
         if (wave_ok) {
+            // The operand groups of tile j + 1 are read from LDS while tile j's results are still on their way out of the matrix pipe and being tracked (round 5): a wave's chain used to be
+            // read operands -> 12 MFMAs -> track -> read operands ..., each link waiting for the one before (with the operands read once per stage, a timing-only ablation, the pass took
+            // 24 % less).  The reads are issued right behind the last MFMA of tile j into the SAME registers — an MFMA has read its A operand long before the LDS answers — so the
+            // prefetch costs no register; only a stage's first tile still waits for its operands.  (The two forms of rounds 3-4 that broke the chain kept two operand AND two accumulator
+            // sets: 236 registers, two waves per SIMD, slower.)
+            half8 af[6];
+#if AFIS_MF_PREFETCH
+#pragma unroll
+            for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[0][2 * kk + h][col]);
+#endif
 #pragma unroll
             for (int j = 0; j < kStageTiles; ++j) {
 #if AFIS_MF_ABLATE == 5 || AFIS_MF_ABLATE == 7          // timing experiments only: the operands are read from LDS once per stage, not per tile
@@ -258,9 +271,10 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
                 }
 #endif
                 const int2 mv = st.meta[j];
-                half8 af[6];
+#if !AFIS_MF_PREFETCH
 #pragma unroll
                 for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[jr][2 * kk + h][col]);
+#endif
                 floatx16 X[NB];
 #pragma unroll
                 for (int blk = 0; blk < NB; ++blk) X[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0], bf[blk][0], nrm, 0, 0, 0);
@@ -269,6 +283,14 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
 #pragma unroll
                     for (int blk = 0; blk < NB; ++blk) X[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bf[blk][kk], X[blk], 0, 0, 0);
                 }
+#if AFIS_MF_PREFETCH
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < kStageTiles) {
+#pragma unroll
+                    for (int kk = 0; kk < 6; ++kk) af[kk] = __builtin_bit_cast(half8, st.a[j + 1][2 * kk + h][col]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 const int my = __builtin_amdgcn_readfirstlane(mv.y);
                 const uint32_t gid = (uint32_t)(2 * (my & 255));
 #if AFIS_MF_ABLATE == 1 || (AFIS_MF_ABLATE >= 4 && AFIS_MF_ABLATE <= 7)          // timing experiments only (wrong results): no tracking
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
         __syncthreads();
 #endif
     }
-    if (sampler) { atomicAdd(&diag[kDiagBoundClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagBoundWall], (unsigned long long)wall_clock64() - wall0); }
+    if (sampler && lane == 0) { atomicAdd(&diag[kDiagBoundClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagBoundWall], (unsigned long long)wall_clock64() - wall0); }
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------------
