@@ -165,11 +165,13 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     // group size: bounded by the option and by the memory budget of a group's per-pair buffers
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
     const int64_t by_mem = group_budget_bytes(ctx) / group_bytes_per_query(ctx, G);
-    // latents per launch group: the option, or (0 = auto) as many as keep about two million (latent, rolled) pairs in a launch — 20 at a 100k-template
+    // latents per launch group: the option, or (0 = auto) as many as keep about five million (latent, rolled) pairs in a launch (round 5; two million before) — 50 at a 100k-template
     // shard, 128 at <= 15k (a 12.5k-template shard: 100 latents in one launch 310.7 ms, in 64 + 36: 315.1): the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
     // each cost 1.2 x their share of a 100k-template step; 2 launches do not).  Measured at 100k templates, 100 latents: 7 per launch 2 495 ms, 10: 2 486,
-    // 15: 2 466, 20: 2 463, 34: 2 468.
-    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : std::min<int64_t>(128, std::max<int64_t>(10, (2000000 + G / 2) / G));
+    // 15: 2 466, 20: 2 463, 34: 2 468.  Round 5, in the overlapped schedule (a launch group's bound pass beside its minutiae stage, the whole chip for what follows: every group ends in a
+    // hand-over between the three streams): 12 per launch 2 059.8 ms, 17: 2 049.8, 20 (the dynamic programme cuts 100 latents into 6 x 16.7): 2 045.4, 25: 2 043.4, 34: 2 037.6, 50: 2 029.3 / 2 035.4,
+    // 64 (64 + 36): 2 048.1, 100: 2 047.5 (profiles/r05_group_size_sweep.txt; two boxes, two passes each) — about five million pairs per launch now: 50 at a 100k-template shard.
+    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : std::min<int64_t>(128, std::max<int64_t>(10, (5000000 + G / 2) / G));
     int per = (int)std::max<int64_t>(1, std::min<int64_t>(want, by_mem));
     afis_queries* q = new afis_queries();
     q->n_q = n_q;
