@@ -162,7 +162,10 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
         st.a[pj][3 * pQ + 0][pp] = make_uint4(w[0].x, w[0].y, w[0].z, w[1].x);
         st.a[pj][3 * pQ + 1][pp] = make_uint4(w[1].y, w[1].z, w[2].x, w[2].y);
         st.a[pj][3 * pQ + 2][pp] = make_uint4(w[2].z, w[3].x, w[3].y, w[3].z);
-        if (pQ == 0) st.nrm[pj][pp] = f.nrm;
+        if (pQ == 0) {                                                   // the address is rebuilt from the thread index here: hoisted out of the stage loop it was two more live registers than the kernel has (168 at three waves per SIMD) and went to scratch
+            int t = tid; asm volatile("" : "+v"(t));
+            st.nrm[t >> 7][t & 31] = f.nrm;
+        }
         if (meta_thread) st.meta[pj] = f.meta;
     };
     Pf pf_cur, pf_nxt;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
         __syncthreads();
 #endif
     }
-    if (sampler && lane == 0) { atomicAdd(&diag[kDiagBoundClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagBoundWall], (unsigned long long)wall_clock64() - wall0); }
+    if (sampler && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) { atomicAdd(&diag[kDiagBoundClk], (unsigned long long)__builtin_readcyclecounter() - clk0); atomicAdd(&diag[kDiagBoundWall], (unsigned long long)wall_clock64() - wall0); }
 }
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------------
