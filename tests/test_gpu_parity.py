@@ -1100,6 +1100,40 @@ def test_results_do_not_depend_on_the_schedule(codebook_bytes, cb, medium):
     m.close()
 
 
+def test_results_do_not_depend_on_the_launch_groups(codebook_bytes, cb, oracle, medium):
+    """A search's latents are cut into launch groups (option query_batch; 0 = about five million pairs per launch, and with adc_variant 9 the cuts are placed where the bound pass's
+    row groups of 768 latent texture rows are fewest: afis_queries_upload).  One latent per launch, 2, 5, 7 (ragged last group), 24 and the automatic rule give the same bits in
+    scores, per-part scores and rank lists, in the overlapped schedule and back to back; one latent's row of the result equals the oracle's."""
+    lats, gal, planted = medium
+    m = M.Matcher(codebook_bytes)
+    m.gallery_add_packed(gal); m.gallery_commit(0)
+    many = list(lats) * 4
+    assert len(many) * gal.G >= 65536
+    want = None
+    for bc in (128, 0):
+        m.set_option("bound_cus", bc)
+        for qb in (0, 1, 2, 5, 7, 24, 256):
+            m.set_option("query_batch", qb)
+            assert m.get_option("query_batch") == qb
+            got = m.search(many, k=24, want_parts=True)
+            if want is None: want = got
+            for key in ("scores", "parts", "topk_idx", "topk_score"):
+                assert np.array_equal(np.asarray(got[key]).view(np.uint8), np.asarray(want[key]).view(np.uint8)), (bc, qb, key)
+    with pytest.raises(M.AfisError):
+        m.set_option("query_batch", 257)
+    m.set_option("query_batch", 0)
+    m.close()
+    qi = 1                                                               # one latent's row against the oracle (every 37th template; the planted mates of the latent with them)
+    picks = sorted(set(range(0, gal.G, 37)) | {g for g, _ in planted[qi]})
+    ocb = oracle.codebook(codebook_bytes)
+    hr = [oracle.rolled(T.write_rolled(gal.template(t)))[0] for t in picks]
+    hl, _ = oracle.latent(ocb, T.write_latent(lats[qi]))
+    rc, sc, parts = oracle.search(ocb, hl, hr, tie_mode=1, want_parts=True)
+    got = np.concatenate([np.asarray(want["parts"])[qi][picks], np.asarray(want["scores"])[qi][picks][:, None]], axis=1).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), parts.astype(np.float32).view(np.uint32))
+    assert float(np.asarray(want["scores"])[qi][planted[qi][0][0]]) > 50
+
+
 def test_bound_pass_kernel_forms_are_bit_identical(codebook_bytes, cb, oracle, small):
     """The matrix-core bound pass exists in two forms — two row blocks per wave (default) and three (mf_blocks 3: a third less LDS operand traffic per MFMA; test
     library only) — which differ only in when a wave does what (round 4's third form, a two-stage software pipeline, measured 6 % slower and was deleted in round 5).
