@@ -102,7 +102,7 @@ template <int NB>
 __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryDev g, const uint4* __restrict__ codes_p, const float* __restrict__ nrm_p,
                                                             const int2* __restrict__ tile_meta, const int32_t* __restrict__ tile0, const uint4* __restrict__ cw16,
                                                             const uint4* __restrict__ bfrag, const float4* __restrict__ rowk, int n_rows, int n_rb, int R_pad,
-                                                            int n_rg, int chunk, uint2* __restrict__ rec, unsigned long long* __restrict__ diag)
+                                                            int n_rg, int chunk, uint2* __restrict__ rec, unsigned long long* __restrict__ diag, int xcd_map)
 {
     constexpr int kWaves = kM12RowBlocks / NB, kThreads = 64 * kWaves, kStageTiles = kThreads / 128;
     static_assert(kWaves * NB == kM12RowBlocks && kStageTiles * 128 == kThreads, "row blocks per wave must divide 24, and the threads must decode whole tiles");
@@ -110,7 +110,10 @@ __global__ __launch_bounds__(64 * (kM12RowBlocks / NB)) void k_adc_mfma(GalleryD
     __shared__ M12Stage<kStageTiles> s_st[2];                           // 2 x 6.3 KB per tile of the stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = blockIdx.x % n_rg, chunk_id = blockIdx.x / n_rg;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2: the row groups of ONE gallery chunk go to ONE XCD, one after the other, so that a chunk's codes
+    // cross the fabric once per round of row groups instead of once per XCD (the launcher rounds the chunk count up to a multiple of 8; chunks beyond the shard return at once).
+    const int slot = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int rg = slot % n_rg, chunk_id = xcd_map ? (slot / n_rg) * 8 + (int)(blockIdx.x & 7) : slot / n_rg;
     const int t_lo = chunk_id * chunk, t_hi = min(g.G, t_lo + chunk);
     if (t_lo >= t_hi) return;
     const int tile_lo = tile0[t_lo], tile_hi = tile0[t_hi];                // tiles of 32 rolled points; a template owns ceil(n/32) of them
@@ -340,17 +343,18 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
     if (n_rb <= 0 || g.G <= 0) return hipSuccess;
     const int n_chunks = (g.G + chunk - 1) / chunk;
     const int n_rg = (n_rb + kM12RowBlocks - 1) / kM12RowBlocks;
-    const long long blocks = (long long)n_rg * n_chunks;
+    static const bool xcd_map = getenv("AFIS_MF_NO_XCD_MAP") == nullptr;       // experiment knob: round-robin chunks as in rounds 3-4
+    const long long blocks = (long long)n_rg * (xcd_map ? (n_chunks + 7) / 8 * 8 : n_chunks);
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 #ifdef AFIS_EXPERIMENTAL_KERNELS                                          // three row blocks per wave (8 waves, 224 registers): -1 % alone on the chip, +2 % in the default schedule; test library only
     if (blocks_per_wave == 3) {
         hipLaunchKernelGGL(k_adc_mfma<3>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 3)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
-                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag);
+                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag, xcd_map ? 1 : 0);
         return hipGetLastError();
     }
 #endif
     hipLaunchKernelGGL(k_adc_mfma<2>, dim3((unsigned)blocks), dim3(64 * (kM12RowBlocks / 2)), 0, stream, g, (const uint4*)codes_p, nrm_p, (const int2*)tile_meta, tile0,
-                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag);
+                           (const uint4*)cw16, (const uint4*)bfrag, (const float4*)rowk, n_rows, n_rb, R_pad, n_rg, chunk, (uint2*)rec, diag, xcd_map ? 1 : 0);
     return hipGetLastError();
 }
 

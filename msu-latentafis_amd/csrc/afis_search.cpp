@@ -312,7 +312,7 @@ int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t aft
     // a chunk never below 8 templates
     const int wg_rb = 24;                                              // row blocks per workgroup (adc_mfma.hip)
     const int n_rg = (n_rb + wg_rb - 1) / wg_rb;
-    const long long want_chunks = std::max<long long>(1, (256 * 24) / n_rg);
+    const long long want_chunks = (std::max<long long>(1, (256 * 24) / n_rg) + 7) / 8 * 8;   // a multiple of 8: the kernel gives every XCD its own chunks (adc_mfma.hip), an uneven count would leave XCDs idle at the end
     const int chunk = ctx->chunk > 0 ? ctx->chunk : (int)std::max<long long>(8, ((long long)g.G + want_chunks - 1) / want_chunks);
     HIPCHK(ctx, launch_adc_mfma(g, ctx->g_codes_p.p, ctx->g_nrm_p.as<float>(), ctx->g_tile_meta.p, ctx->g_tex_t32_blk.as<int32_t>(), ctx->mf_cw16.p,
                                 ctx->mf_bfrag.p, ctx->mf_rowk.p, n_rows, n_rb, R_pad, chunk, ctx->mf_blocks, ctx->mf_rec.p, diag, s));
