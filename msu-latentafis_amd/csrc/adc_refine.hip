@@ -315,8 +315,9 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                         const float v = W.val[j]; const int p = W.pt[j];
                         if (v > bv || (v == bv && p < bp)) { bv = v; bp = p; }
                     }
-                    rm_val[o + row] = bv;
-                    if (compact) { const int sl = W.slot[it]; rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else rm_arg[o + row] = bp;
+                    // compact form: ONE store of the value, in the pair's list of the rows that matter — S7 and the list's sums read it there through the row's slot (graph.hip);
+                    // rounds 3-5 also stored it at its row of the dense array (a scattered 4-byte store per evaluated row: a third of this kernel's HBM writes)
+                    if (compact) { const int sl = W.slot[it]; rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else { rm_val[o + row] = bv; rm_arg[o + row] = bp; }
                     if (stats) {                                        // self-check of the bounds: the exact row maximum must lie inside them
                         float lo, hi; bounds(row, rec0[row], lo, hi);
                         if (!(bv >= lo && bv <= hi)) atomicAdd(stats + 5, 1ull);
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 const float s0 = __shfl(v_first, 0);                    // n_rt >= 1: lane 0 evaluated point 0
                 if (s0 != s0 || bp == 0x7fffffff) { bv = s0; bp = 0; }
                 const int sl = __shfl(my_slot, src);
-                if (lane == 0) { rm_val[o + row] = bv; if (compact) { rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else rm_arg[o + row] = bp; }
+                if (lane == 0) { if (compact) { rm_cv[o + sl] = bv; rm_arg[o + sl] = row | (bp << 16); } else { rm_val[o + row] = bv; rm_arg[o + row] = bp; } }
                 ++st_full;
             }
             // append this round's items, rows in ascending order (a row's items stay adjacent)

@@ -7,11 +7,11 @@ using namespace afis;
 
 namespace afis {
 
-// Device bytes one latent of a launch group costs at worst (1000 texture rows): row maxima (value, point, compact list: 12 B per (pair, row)),
+// Device bytes one latent of a launch group costs at worst (1000 texture rows): row maxima (value + point: 8 B per (pair, row) — adc_variant 9 keeps them in the compact list only, the others in the dense arrays),
 // adc_variant 9's bound-pass records (kMfRecBytes per (template, row)), the minutiae candidate lists and the per-part scores.
 int64_t group_bytes_per_query(const afis_ctx* ctx, int64_t G)
 {
-    const int64_t per_pair = (int64_t)kTexMax * 12 + (ctx->adc_variant == 9 ? (int64_t)kTexMax * kMfRecBytesPerRow : 0) + 3 * (int64_t)kTopMinu * (int64_t)sizeof(MinuCand) + 3 * 4 + 16 + 8;
+    const int64_t per_pair = (int64_t)kTexMax * 8 + (ctx->adc_variant == 9 ? (int64_t)kTexMax * kMfRecBytesPerRow : 0) + 3 * (int64_t)kTopMinu * (int64_t)sizeof(MinuCand) + 3 * 4 + 16 + 8;
     return std::max<int64_t>(1, G) * per_pair;
 }
 
@@ -370,7 +370,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         const size_t n_pairs = (size_t)nq_max * G;
         const size_t lt_cap = std::max<size_t>((size_t)lt_pad_max, ((size_t)kTexMax + kTileRows - 1) / kTileRows * kTileRows);
         if (n_pairs > 0) {
-            HIPCHK(ctx, ctx->rm_val.ensure(n_pairs * lt_cap * 4));
+            if (ctx->adc_variant != 9) HIPCHK(ctx, ctx->rm_val.ensure(n_pairs * lt_cap * 4));      // variant 9: the values live in the compact list (rm_cv) only
             HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * lt_cap * 4));
             HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));   // per-part scores on request: every group's block stays on the device until the search is done
             HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
@@ -413,7 +413,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
 #endif
             const size_t lt_cap = std::max<size_t>((size_t)d.lt_pad, ((size_t)kTexMax + kTileRows - 1) / kTileRows * kTileRows);    // worst case, as budgeted: no re-allocation when a later group's longest latent is longer (adc_stage_mfma)
-            HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
+            if (ctx->adc_variant != 9) HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
             HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
             if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
             HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));

@@ -126,12 +126,20 @@ struct __attribute__((aligned(16))) WaveSmem : SimStore<NMAX_, OWN_SIM_> {
     u64 ph[16];
 #endif
 };
-// similarity of list entry t; ext: the texture list's row maxima (rm_val + the pair's offset), indexed by latent row
+// Texture lists (OWN_SIM false) carry, in the spare bits of li / ri (latent row and rolled point are both < 1024: the 1000-row clamp, matcher.cpp:544-547), the SLOT of the row in the
+// pair's array of row maxima: li = row | (slot & 31) << 10, ri = point | (slot >> 5) << 10.  With adc_variant 9 that array is the compact list the recomputation kernel wrote (the rows
+// that can be among the 200, side by side in row order), otherwise the dense one (slot = row).  Minutiae lists hold plain indices.
+template <class SM> __device__ __forceinline__ int l_row(int v) { if constexpr (SM::OWN_SIM) return v; else return v & 1023; }
+template <class SM> __device__ __forceinline__ int r_pt(int v) { if constexpr (SM::OWN_SIM) return v; else return v & 1023; }
+__device__ __forceinline__ int tex_slot_of(int li, int ri) { return ((li >> 10) & 31) | (((ri >> 10) & 31) << 5); }
+__device__ __forceinline__ short tex_pack_l(int row, int slot) { return (short)(row | ((slot & 31) << 10)); }
+__device__ __forceinline__ short tex_pack_r(int pt, int slot) { return (short)(pt | ((slot >> 5) << 10)); }
+// similarity of list entry t; ext: the texture list's row maxima (the pair's compact or dense array), indexed by the entry's slot
 template <class SM>
 __device__ __forceinline__ float list_sim(const SM& sm, const float* __restrict__ ext, int t)
 {
     if constexpr (SM::OWN_SIM) return sm.simv[t];
-    else return ext[sm.li[t]];
+    else return ext[tex_slot_of(sm.li[t], sm.ri[t])];
 }
 
 // The wave's next task: a ticket from a global counter, one draw per list (a list costs 50-2000 us).  Every lane takes part in the
@@ -254,7 +262,7 @@ __device__ int greedy(SM& sm, int num, double thr, Compat compatible)
         idx[u] = 0; li[u] = -1; ri[u] = -1; alive[u] = false;
         if (p < num) {
             idx[u] = sm.y.os.order[p];
-            li[u] = sm.li[idx[u]]; ri[u] = sm.ri[idx[u]];
+            li[u] = l_row<SM>(sm.li[idx[u]]); ri[u] = r_pt<SM>(sm.ri[idx[u]]);
             alive[u] = !((double)sm.b[idx[u]] < thr);          // sorted descending: everything after the first S < thr is < thr too
         }
     }
@@ -770,10 +778,10 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
     const int lane = threadIdx.x;
     // texture lists: the orientations are needed while the boolean H is built, b[] and cc[] only by the iterations after it: they share the storage
     if constexpr (SM::ALIAS_ORI) {
-        for (int t = lane; t < num; t += 64) { sm.b[t] = lori[sm.li[t]]; sm.y.cc[t] = rori[sm.ri[t]]; }
+        for (int t = lane; t < num; t += 64) { sm.b[t] = lori[l_row<SM>(sm.li[t])]; sm.y.cc[t] = rori[r_pt<SM>(sm.ri[t])]; }
         for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
     } else {
-        for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[sm.li[t]]; sm.x.s.ro[t] = rori[sm.ri[t]]; }
+        for (int t = lane; t < num; t += 64) { sm.x.s.lo[t] = lori[l_row<SM>(sm.li[t])]; sm.x.s.ro[t] = rori[r_pt<SM>(sm.ri[t])]; }
         for (int i = lane; i < num * W; i += 64) sm.hb[i / W][i % W] = 0u;
         const float s0 = (float)(1.0 / num);                                   // :1558
         for (int t = lane; t < SM::N4; t += 64) { sm.b[t] = t < num ? s0 : 0.0f; sm.y.cc[t] = 0.0f; }
@@ -884,7 +892,7 @@ struct GraphTap { MinuCand* out; int32_t* n; int stage; };
 template <class SM>
 __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, const float* __restrict__ ext, long long task, int n, int cap)
 {
-    for (int t = threadIdx.x; t < n; t += 64) { MinuCand c; c.sim = list_sim(sm, ext, t); c.li = sm.li[t]; c.ri = sm.ri[t]; tap.out[(size_t)task * cap + t] = c; }
+    for (int t = threadIdx.x; t < n; t += 64) { MinuCand c; c.sim = list_sim(sm, ext, t); c.li = l_row<SM>(sm.li[t]); c.ri = r_pt<SM>(sm.ri[t]); tap.out[(size_t)task * cap + t] = c; }
     if (threadIdx.x == 0) tap.n[task] = n;
 }
 
@@ -962,7 +970,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
                     int pos = -1;
                     if (gt) pos = base_gt + g_lane_prefix(mg);
                     else if (eq) { const int r = base_eq + g_lane_prefix(me); if (r < need) pos = n_gt + r; }
-                    if (pos >= 0) { key32[pos] = key[u]; sm.x.pick.te[pos] = (short)(compact ? arg[u] & 0xffff : e); sm.x.pick.targ[pos] = (short)(compact ? arg[u] >> 16 : arg[u]); }
+                    if (pos >= 0) { key32[pos] = key[u]; sm.x.pick.te[pos] = tex_pack_l(compact ? arg[u] & 0xffff : e, e); sm.x.pick.targ[pos] = tex_pack_r(compact ? arg[u] >> 16 : arg[u], e); }   // e = the row's slot in the array the values came from
                     base_gt += __popcll(mg); base_eq += __popcll(me);
                 }
             }
@@ -1022,9 +1030,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
             if (g_wave_sum(rsum) != kTopTex * (kTopTex - 1) / 2) {
                 u64 mine[TexSmem::U];
 #pragma unroll
-                for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? ((u64)key32[t] << 32) | (uint32_t)(~(uint32_t)sm.x.pick.te[t]) : 0ull; r[u] = 0; }
+                for (int u = 0; u < TexSmem::U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? ((u64)key32[t] << 32) | (uint32_t)(~(uint32_t)(sm.x.pick.te[t] & 1023)) : 0ull; r[u] = 0; }
                 for (int k = 0; k < num; ++k) {
-                    const u64 kk = ((u64)key32[k] << 32) | (uint32_t)(~(uint32_t)sm.x.pick.te[k]);
+                    const u64 kk = ((u64)key32[k] << 32) | (uint32_t)(~(uint32_t)(sm.x.pick.te[k] & 1023));
 #pragma unroll
                     for (int u = 0; u < TexSmem::U; ++u) r[u] += kk > mine[u];
                 }
@@ -1036,7 +1044,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
             }
         } else {                                                         // :748-749 rows stay in index order
             num = n_lt;
-            for (int t = lane; t < num; t += 64) { sm.li[t] = (short)t; sm.ri[t] = (short)(rm_n ? rm_arg[o + t] >> 16 : rm_arg[o + t]); }   // compact form: every row is listed, slot = row
+            for (int t = lane; t < num; t += 64) { sm.li[t] = tex_pack_l(t, t); sm.ri[t] = tex_pack_r(rm_n ? rm_arg[o + t] >> 16 : rm_arg[o + t], t); }   // compact form: every row is listed, slot = row
         }
         WSYNC();
         int out_of_range = 0, not_small = 0;                             // any block coordinate outside [0, 2047]: generic arithmetic for this list;
@@ -1046,7 +1054,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
             const int t = lane + 64 * u;
             lp4[u] = make_short2(0, 0); rp4[u] = make_short2(0, 0);
             if (t < num) {
-                lp4[u] = q.lt_xy[l0 + sm.li[t]]; rp4[u] = g.tex_xy[r0 + sm.ri[t]];
+                lp4[u] = q.lt_xy[l0 + (sm.li[t] & 1023)]; rp4[u] = g.tex_xy[r0 + (sm.ri[t] & 1023)];
                 out_of_range |= (lp4[u].x | lp4[u].y | rp4[u].x | rp4[u].y) & ~2047;
                 not_small |= ((unsigned)lp4[u].x > 49u) | ((unsigned)lp4[u].y > 49u) | ((unsigned)rp4[u].x > 49u) | ((unsigned)rp4[u].y > 49u);
             }
@@ -1060,9 +1068,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
         WSYNC();
         GPH_K(15);                                                       // S7 + list build
         int n_surv;
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, rm_val + o, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
+        const float* const row_max = (rm_n ? rm_cv : rm_val) + o;           // the array the entries' slots index
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, row_max, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
         if (lane == 0) *out = score;
-        if (tap.out) tap_write(tap, sm, rm_val + o, task, n_surv, kTopTex);
+        if (tap.out) tap_write(tap, sm, row_max, task, n_surv, kTopTex);
         WSYNC();
     }
     GPH_FLUSH();
