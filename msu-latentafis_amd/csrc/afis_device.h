@@ -114,8 +114,9 @@ hipError_t launch_adc_rowmax_q(const QueryDev& q, const GalleryDev& g, const voi
 // adc_variant 9 (adc_mfma.hip): fp16 matrix-core bound pass + exact recomputation.  launch_mf_codebook: fp16 codebook (16-byte entries) and
 // |cw|^2 table, once per context.  launch_mf_tiles: tile-aligned (32 points) codes / point terms / tile directory of the gallery (first use).
 // launch_mf_rows: per latent row of a query group the fp16 B fragments and (c, Es, Tg, force).  launch_adc_mfma: the bound pass ->
-// rec[(template * 2 + half) * R_pad + row].  launch_tex_refine: bounds -> the rows that can reach the top 200 -> exact (max, first arg-max)
-// into rm_val / rm_arg, -inf for the other rows (all_rows != 0: every row exactly; the parity taps use it).
+// rec[template * R_pad + row].  launch_tex_refine: bounds -> the rows that can reach the top 200 -> exact (max, first arg-max).  Two output forms: compact (rm_n != NULL: what a
+// search uses) — per pair the evaluated rows side by side in row order, value in rm_cv[pair * lt_pad + slot], (row | point << 16) in rm_arg[pair * lt_pad + slot], their count in rm_n[pair];
+// rm_val is not touched — or dense (rm_n == NULL): value and point at rm_val / rm_arg[pair * lt_pad + row], -inf for the other rows (all_rows != 0: every row exactly; the parity taps use it).
 hipError_t launch_mf_codebook(const float* codewords, void* cw16, float* cwn, hipStream_t stream);
 hipError_t launch_mf_tiles(const GalleryDev& g, const int32_t* t32_blk, const float* cwn, void* codes_p, float* nrm_p, void* tile_meta, hipStream_t stream);
 hipError_t launch_mf_rows(const float* lt_des, int n_rows, int n_rb, const float* codewords, const float* cwn, void* bfrag, void* rowk, hipStream_t stream);
@@ -159,7 +160,7 @@ enum { kDiagFallback = 0,       // candidate tasks handed to the any-shape kerne
        kDiagCandsClk = 4, kDiagCandsWall = 5,      // sampled workgroups of the candidate kernel: shader cycles and 100 MHz ticks they lived
        kDiagBoundClk = 6, kDiagBoundWall = 7,      // the same for the bound pass
        kDiagWords = 16 };
-// S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]
+// S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]; rm_n != NULL: the compact form above (rm_val unused), otherwise the dense one (rm_cv unused)
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
                                 const float* rm_val, const int32_t* rm_arg, const float* rm_cv, const int32_t* rm_n, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
