@@ -13,11 +13,12 @@ f = glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("afis::", "").replace("void ", ""), r["Queue_Id"]) for r in rows]
 ks.sort()
-# the timed step = the last 6 launches of the bound pass and everything from the first of them on
+# the timed step = the last N launches of the bound pass (N = launch groups per step: half of the trace's launches, warm-up + one timed step) and everything from the first of them on
 b = [i for i, k in enumerate(ks) if k[2].startswith("k_adc_mfma")]
-first = b[-6]
+N = max(1, len(b) // 2)
+first = b[-N]
 # start a little earlier: the row-constant kernels of that group
-while first > 0 and ks[first - 1][0] > ks[b[-6]][0] - 2_000_000: first -= 1
+while first > 0 and ks[first - 1][0] > ks[b[-N]][0] - 2_000_000: first -= 1
 t0 = ks[first][0]
 with open(out + "/timeline.txt", "w") as w:
     w.write("# begin_ms end_ms dur_ms queue kernel   (one bench step, default schedule; t = 0 at the step's first kernel; kernels under 0.05 ms omitted)\n")
