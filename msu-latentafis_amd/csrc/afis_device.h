@@ -152,6 +152,34 @@ AFIS_HOST_DEVICE inline int rt_max_rows(int S, int nR)            // the largest
     m = m < cap ? m : cap;
     return m < rt_class_max_latent(S) ? m : rt_class_max_latent(S);
 }
+// ---- launch groups (host): the latents of a search are cut into contiguous runs that are launched together (afis_search.cpp::afis_queries_upload).
+// launch_group_latents: latents per launch at most when the option is 0 — about five million (latent, rolled) pairs, between 10 and 128 latents.
+// launch_group_cuts: the group ends (exclusive) for n = rows_prefix.size() - 1 latents, at most `per` latents each.  by_row_groups (adc_variant 9): the bound pass works in row
+// groups of 768 latent texture rows and a launch pays for its last one in full, so the cuts are placed where the total number of row groups is smallest (dynamic programme
+// over the cut positions; ties: fewer launches, then the earliest last cut); otherwise runs of `per`.  rows_prefix[i] = latent texture rows of latents 0 .. i-1.  Results never depend on the cuts.
+inline long long launch_group_latents(long long G) { if (G < 1) G = 1; const long long w = (5000000 + G / 2) / G; return w < 10 ? 10 : w > 128 ? 128 : w; }
+inline void launch_group_cuts(const long long* rows_prefix, int n, int per, bool by_row_groups, int* cuts /* [n] at most */, int* n_cuts)
+{
+    *n_cuts = 0;
+    if (n <= 0) return;
+    if (per < 1) per = 1;
+    if (!by_row_groups || n == 1) { for (int i = per; i < n; i += per) cuts[(*n_cuts)++] = i; cuts[(*n_cuts)++] = n; return; }
+    const long long kInf = 1ll << 60, rg_rows = 768;
+    long long* best = new long long[(size_t)n + 1]; int* from = new int[(size_t)n + 1]; int* cnt = new int[(size_t)n + 1];
+    best[0] = 0; from[0] = 0; cnt[0] = 0;
+    for (int i = 1; i <= n; ++i) {
+        best[i] = kInf; from[i] = 0; cnt[i] = 0;
+        for (int j = (i - per > 0 ? i - per : 0); j < i; ++j) {
+            const long long c = best[j] + (rows_prefix[i] - rows_prefix[j] + rg_rows - 1) / rg_rows;
+            if (c < best[i] || (c == best[i] && cnt[j] + 1 < cnt[i])) { best[i] = c; from[i] = j; cnt[i] = cnt[j] + 1; }
+        }
+    }
+    int m = 0;
+    for (int i = n; i > 0; i = from[i]) cuts[m++] = i;
+    for (int a = 0, b = m - 1; a < b; ++a, --b) { const int t = cuts[a]; cuts[a] = cuts[b]; cuts[b] = t; }
+    *n_cuts = m;
+    delete[] best; delete[] from; delete[] cnt;
+}
 // ints of the candidate stage's control buffer: [fallback count | n_tasks fallback task ids | 8 control words | 3 G work-list entries]
 inline size_t minu_fb_ints(size_t n_tasks, size_t G) { return 1 + n_tasks + 8 + 3 * G; }
 // One row of 16 unsigned 64-bit diagnostics per launch group, zeroed at the start of a search and read back with its results (afis_timing):

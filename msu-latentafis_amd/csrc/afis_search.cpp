@@ -166,41 +166,27 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     const int64_t G = std::max<int64_t>(1, ctx->gal.G);
     const int64_t by_mem = group_budget_bytes(ctx) / group_bytes_per_query(ctx, G);
     // latents per launch group: the option, or (0 = auto) as many as keep about five million (latent, rolled) pairs in a launch (round 5; two million before) — 50 at a 100k-template
-    // shard, 128 at <= 15k (a 12.5k-template shard: 100 latents in one launch 310.7 ms, in 64 + 36: 315.1): the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
+    // shard, 128 at <= 39k (round 3, a 12.5k-template shard: 100 latents in one launch 310.7 ms, in 64 + 36: 315.1): the persistent per-pair kernels lose their tails once per launch, which shows on small shards (12 launches of 100k pairs
     // each cost 1.2 x their share of a 100k-template step; 2 launches do not).  Measured at 100k templates, 100 latents: 7 per launch 2 495 ms, 10: 2 486,
     // 15: 2 466, 20: 2 463, 34: 2 468.  Round 5, in the overlapped schedule (a launch group's bound pass beside its minutiae stage, the whole chip for what follows: every group ends in a
     // hand-over between the three streams): 12 per launch 2 059.8 ms, 17: 2 049.8, 20 (the dynamic programme cuts 100 latents into 6 x 16.7): 2 045.4, 25: 2 043.4, 34: 2 037.6, 50: 2 029.3 / 2 035.4,
     // 64 (64 + 36): 2 048.1, 100: 2 047.5 (profiles/r05_group_size_sweep.txt; two boxes, two passes each) — about five million pairs per launch now: 50 at a 100k-template shard.
-    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : std::min<int64_t>(128, std::max<int64_t>(10, (5000000 + G / 2) / G));
+    const int64_t want = ctx->query_batch > 0 ? ctx->query_batch : launch_group_latents(G);
     int per = (int)std::max<int64_t>(1, std::min<int64_t>(want, by_mem));
     afis_queries* q = new afis_queries();
     q->n_q = n_q;
-    // Launch groups are contiguous runs of at most `per` queries.  The matrix-core bound pass (adc_variant 9) works in row groups of 768 latent
-    // texture rows: a run whose rows fill its last row group only partly pays for the whole of it, so the cuts are placed where the total
-    // number of row groups is smallest (dynamic programme over the cut positions; ties: fewer launches).  Results do not depend on the cuts.
-    std::vector<int> cuts;                                                  // group ends (exclusive)
-    if (ctx->adc_variant == 9 && n_q > 1) {
-        std::vector<long long> rows((size_t)n_q + 1, 0);
-        for (int i = 0; i < n_q; ++i) {
-            const afis_template_view& t = queries[i];
-            const bool has = t.n_tex > 0 && t.tex && !(t.n_minu <= kSelected[0] && t.n_tex <= 0);
-            rows[(size_t)i + 1] = rows[(size_t)i] + (has ? std::min(std::max(t.tex[0].n, 0), kTexMax) : 0);
-        }
-        const long long kInf = 1ll << 60;
-        const long long rg_rows = 768;
-        std::vector<long long> best((size_t)n_q + 1, kInf); std::vector<int> from((size_t)n_q + 1, 0), cnt((size_t)n_q + 1, 0);
-        best[0] = 0;
-        for (int i = 1; i <= n_q; ++i)
-            for (int j = std::max(0, i - per); j < i; ++j) {
-                const long long c = best[(size_t)j] + (rows[(size_t)i] - rows[(size_t)j] + rg_rows - 1) / rg_rows;
-                if (c < best[(size_t)i] || (c == best[(size_t)i] && cnt[(size_t)j] + 1 < cnt[(size_t)i])) { best[(size_t)i] = c; from[(size_t)i] = j; cnt[(size_t)i] = cnt[(size_t)j] + 1; }
-            }
-        for (int i = n_q; i > 0; i = from[(size_t)i]) cuts.push_back(i);
-        std::reverse(cuts.begin(), cuts.end());
-    } else {
-        for (int i = per; i < n_q; i += per) cuts.push_back(i);
-        if (n_q > 0) cuts.push_back(n_q);
+    // Launch groups are contiguous runs of at most `per` queries; with the matrix-core bound pass (adc_variant 9) the cuts are placed where its row groups of 768 latent
+    // texture rows are fewest (launch_group_cuts, afis_device.h; tests/test_host.py checks the rule on the CPU).  Results do not depend on the cuts.
+    std::vector<long long> rows((size_t)n_q + 1, 0);
+    for (int i = 0; i < n_q; ++i) {
+        const afis_template_view& t = queries[i];
+        const bool has = t.n_tex > 0 && t.tex && !(t.n_minu <= kSelected[0] && t.n_tex <= 0);
+        rows[(size_t)i + 1] = rows[(size_t)i] + (has ? std::min(std::max(t.tex[0].n, 0), kTexMax) : 0);
     }
+    std::vector<int> cuts((size_t)std::max(n_q, 1));                        // group ends (exclusive)
+    int n_cuts = 0;
+    launch_group_cuts(rows.data(), n_q, per, ctx->adc_variant == 9, cuts.data(), &n_cuts);
+    cuts.resize((size_t)n_cuts);
     int g0 = 0;
     for (int end : cuts) {
         q->groups.emplace_back();

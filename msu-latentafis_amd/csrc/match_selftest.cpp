@@ -5,9 +5,12 @@
 //   match_selftest -selftest-shards <weights file> -world N  shard cut rule (rank_exchange.cpp) — equals host/sharding.py
 //   match_selftest -selftest-exchange                        rendezvous: rank 0's 128 bytes reach every rank (RANK/WORLD_SIZE/MASTER_* env)
 //   match_selftest -selftest-allgather                       AFIS_EXCHANGE=tcp all-gather + the agreement point, N local ranks
+//   match_selftest -selftest-groups <rows file> -per N [-plain]   the launch-group rule (afis_device.h: launch_group_cuts / launch_group_latents): cut positions for the listed latent texture row counts
 //   match_selftest -selftest-classes                         the candidate kernel's shape-class rule (afis_device.h: rt_max_rows) as a table: nR  L1 L2 L4  stride1 stride2 stride4
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <vector>
 
 #include "afis_device.h"
 #include "cli_util.h"
@@ -23,6 +26,19 @@ int main(int argc, char** argv)
                   << rt_class_keys_per_thread(4) << " " << rt_class_max_rolled(4) << " " << rt_class_max_latent(4) << std::endl;
         for (int nR = 0; nR <= 2000; ++nR)
             std::cout << nR << " " << rt_max_rows(1, nR) << " " << rt_max_rows(2, nR) << " " << rt_max_rows(4, nR) << " " << rt_row_stride(1, nR) << " " << rt_row_stride(2, nR) << " " << rt_row_stride(4, nR) << std::endl;
+        return 0;
+    }
+    if (args.cmdOptionExists("-selftest-groups")) {                             // the launch-group rule (no GPU): rows per latent (one int per line), latents per launch at most
+        std::ifstream f(args.getCmdOption("-selftest-groups"));
+        std::vector<long long> pre{0}; long long v;
+        while (f >> v) pre.push_back(pre.back() + v);
+        const int n = (int)pre.size() - 1, per = atoi(args.getCmdOption("-per").c_str());
+        std::vector<int> cuts((size_t)(n > 0 ? n : 1)); int m = 0;
+        launch_group_cuts(pre.data(), n, per, !args.cmdOptionExists("-plain"), cuts.data(), &m);
+        for (int i = 0; i < m; ++i) std::cout << cuts[(size_t)i] << (i + 1 < m ? " " : "");
+        std::cout << std::endl;
+        for (long long G : {1ll, 12500ll, 39000ll, 40000ll, 50000ll, 100000ll, 250000ll, 500000ll, 1000000ll}) std::cout << G << ":" << launch_group_latents(G) << " ";
+        std::cout << std::endl;
         return 0;
     }
     if (args.cmdOptionExists("-selftest-exchange")) {                           // rendezvous only (no GPU): rank 0's 128 bytes reach every rank

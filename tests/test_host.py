@@ -351,3 +351,53 @@ def test_candidate_shape_class_rule_keeps_every_task_inside_its_class_limits():
             max_rolled = {1: 128, 2: 256, 4: 512}[S_]
             assert nR <= max_rolled and max_rolled + L[S_] <= 256 * S_, (S_, nR)               # thread j sums column j, thread max_rolled + i sums row i: both exist
     assert rows[128][1] == 64 and rows[129][1] == 0 and rows[128][2] == 128 and rows[129][2] == 96 and rows[256][2] == 64 and rows[256][3] == 151 and rows[257][2] == 0 and rows[400][3] == 97 and rows[512][3] == 75 and rows[513][3] == 0
+
+
+def test_launch_group_rule_places_the_cuts_where_the_row_groups_are_fewest(tmp_path):
+    """The latents of a search are cut into launch groups on the host (afis_device.h: launch_group_cuts / launch_group_latents; used by afis_queries_upload).  With the matrix-core
+    bound pass a launch pays for row groups of 768 latent texture rows, so the rule must (1) cover the latents with contiguous runs of at most `per`, (2) reach the smallest total
+    number of row groups any such partition has — checked against an independent dynamic programme here —, (3) among those use the fewest launches; the plain form is runs of `per`.
+    The bench's 100 latents (seed 2024) become 2 + 49 + 49 at 50 per launch: 88 row groups, what ONE launch of all of them would need.  The automatic group size is about five
+    million pairs per launch, between 10 and 128 latents."""
+    import subprocess
+    import importlib
+    S = importlib.import_module("msu-latentafis_amd.host.synth")
+    csrc = os.path.join(ROOT, "msu-latentafis_amd", "csrc")
+    exe = os.path.join(csrc, "match_selftest")
+    subprocess.run(["make", "-s", "-C", csrc, "match_selftest"], check=True)
+
+    def run(rows, per, plain=False):
+        f = tmp_path / "rows.txt"
+        f.write_text("".join("%d\n" % r for r in rows))
+        out = subprocess.run([exe, "-selftest-groups", str(f), "-per", str(per)] + (["-plain"] if plain else []), capture_output=True, text=True, check=True).stdout.splitlines()
+        return [int(x) for x in out[0].split()], dict((int(a), int(b)) for a, b in (t.split(":") for t in out[1].split()))
+
+    def cost(rows, cuts):
+        c, prev = 0, 0
+        for e in cuts:
+            c += (sum(rows[prev:e]) + 767) // 768; prev = e
+        return c
+
+    def optimum(rows, per):                                              # (row groups, launches) of the best partition, independently
+        n = len(rows); pre = np.concatenate([[0], np.cumsum(rows)])
+        best = [(0, 0)] + [(1 << 60, 0)] * n
+        for i in range(1, n + 1):
+            best[i] = min((best[j][0] + (int(pre[i] - pre[j]) + 767) // 768, best[j][1] + 1) for j in range(max(0, i - per), i))
+        return best[n]
+
+    rng = np.random.default_rng(5)
+    cases = [([700], 50), ([0, 0, 0], 2), ([768] * 7, 3), ([1000] * 130, 128), ([1] * 40, 7)]
+    for _ in range(40):
+        n = int(rng.integers(1, 60))
+        cases.append((list(int(x) for x in rng.integers(0, 1001, n)), int(rng.integers(1, 20))))
+    for rows, per in cases:
+        cuts, _ = run(rows, per)
+        assert cuts == sorted(set(cuts)) and cuts[-1] == len(rows) and all(b - a <= per for a, b in zip([0] + cuts, cuts)), (rows, per, cuts)
+        assert (cost(rows, cuts), len(cuts)) == optimum(rows, per), (rows, per, cuts)
+        plain, _ = run(rows, per, plain=True)
+        assert plain == list(range(per, len(rows), per)) + [len(rows)]
+    lats = S.make_latents(2024, 100, **S.WORKLOADS["headline"]["latent"])
+    rows = [min(L.tex[0].n, 1000) for L in lats]
+    cuts, auto = run(rows, 50)
+    assert cuts == [2, 51, 100] and cost(rows, cuts) == (sum(rows) + 767) // 768 == 88
+    assert auto == {1: 128, 12500: 128, 39000: 128, 40000: 125, 50000: 100, 100000: 50, 250000: 20, 500000: 10, 1000000: 10}
