@@ -355,7 +355,9 @@ __global__ __launch_bounds__(256) void k_minu_classify(QueryDev q, GalleryDev g,
     const bool live = gi < g.G;
     const int nR = live ? g.minu_off[gi + 1] - g.minu_off[gi] : 0;
     const int L1 = rt_max_rows(1, nR), L2 = rt_max_rows(2, nR), L4 = rt_max_rows(4, nR);
-    const int has[3] = {live ? cnt[L1] : 0, live ? cnt[L2] - cnt[L1] : 0, live ? cnt[L4] - cnt[L2] : 0};
+    // a class that takes nothing against this nR has L == 0, and cnt[0] is the count of EMPTY lists, not a prefix sum: its share is zero lists
+    const int c1 = live && L1 > 0 ? cnt[L1] : 0, c2 = live && L2 > 0 ? cnt[L2] : c1, c4 = live && L4 > 0 ? cnt[L4] : c2;
+    const int has[3] = {c1, c2 - c1, c4 - c2};                                       // nR <= 0: all three zero (the template is never listed)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {                                                    // one atomic per wave and class
         const u64 m = __ballot(has[c] > 0);
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void k_minu_classify(QueryDev q, GalleryDev g,
             if (has[c] > 0) work[(size_t)c * g.G + base + lane_prefix(m)] = gi;
         }
     }
-    if (live && (nR <= 0 || cnt[0] > 0 || cnt[257] > cnt[L4])) {                     // some task of this rolled template belongs to no class
+    if (live && (nR <= 0 || cnt[0] > 0 || cnt[257] > c4)) {                     // some task of this rolled template belongs to no class
         for (int qs = 0; qs < nqs; ++qs) {
             const long long task = (long long)qs * g.G + gi;
             const int nL = q.lm_off[qs + 1] - q.lm_off[qs];

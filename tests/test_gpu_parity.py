@@ -553,10 +553,16 @@ def test_python_drivers_equal_cli(codebook_bytes, cb, small, tmp_path):
         m.close()
 
 
-def test_edge_fusion_rules(codebook_bytes, cb, oracle):
+@pytest.mark.parametrize("rolled_minu", [None, (200, 400, 600)])
+def test_edge_fusion_rules(codebook_bytes, cb, oracle, rolled_minu):
+    """Template selection and fusion (matcher.cpp:376-417, :188) on latents that lack some of templates 26 / 2 / 11, texture, or everything.  rolled_minu: the same
+    latents against rolled templates of 200 / 400 / 600 minutiae — shapes the small class of the candidate kernel does not take, so that a launch has EMPTY latent
+    lists next to lists of the medium / large class and of the any-shape kernel (k_minu_classify must count an empty list for no class)."""
     base, variants = cases.edge_latents(cb)
     rng = np.random.default_rng(11)
-    gal = [S.make_mate(rng, cb, base, frac=0.8, n_tex=400), S.make_mate(rng, cb, base, frac=0.4, n_tex=350), S.make_rolled(rng, cb, n_tex=300)]
+    nm = rolled_minu or (None, None, None)
+    kw = [dict(n_minu=n) if n else {} for n in nm]
+    gal = [S.make_mate(rng, cb, base, frac=0.8, n_tex=400, **kw[0]), S.make_mate(rng, cb, base, frac=0.4, n_tex=350, **kw[1]), S.make_rolled(rng, cb, n_tex=300, **kw[2])]
     no_tex = T.FPTemplate(minu=list(gal[0].minu), tex=[])
     no_minu = T.FPTemplate(minu=[], tex=list(gal[0].tex))
     empty = T.FPTemplate()
@@ -587,6 +593,18 @@ def test_edge_fusion_rules(codebook_bytes, cb, oracle):
                 continue
             # the oracle reports the texture score in slot 3 regardless of where the reference stores it
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (n, gi, got, want)      # bit for bit
+    if rolled_minu:                                            # every task accounted for, the larger classes and the any-shape kernel all used; all-template mode on the same shapes
+        tm = m.timing()
+        assert tm["minu_tasks_small"] + tm["minu_tasks_medium"] + tm["minu_tasks_large"] + tm["minu_fallback_tasks"] <= tm["minu_tasks"]
+        assert tm["minu_tasks_medium"] > 0 and tm["minu_tasks_large"] > 0 and tm["minu_fallback_tasks"] > 0, tm
+        for n in ("minu12_tex", "minu2_tex", "full28"):
+            L = variants[n]
+            qs, rs, sc = m.One2One_matching_all_templates(L)
+            hl = oracle.latent(ocb, T.write_latent(L))[0]
+            width = len(L.minu) + len(L.tex)
+            for gi in range(4):                                # the rolled templates a .dat can express
+                rc, want = oracle.all_templates(ocb, hl, oracle.rolled(T.write_rolled(gal[gi]))[0], width, tie_mode=1)
+                assert np.array_equal(sc[gi].view(np.uint32), want.view(np.uint32)), (n, gi, sc[gi], want)
     # structural expectations that do not need the oracle
     q28 = names.index("full28")
     assert res["scores"][q28, 5] == -1.0                       # empty rolled template (matcher.cpp:184-187)
