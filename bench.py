@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--workload", default="headline", choices=sorted(S.WORKLOADS), help="headline = BASELINE.json's shapes (rolled minutiae clip(N(80, 15), 20, 200), latent U{20..60}); "
                     "wide = the shapes the reference's reader also accepts but the synthetic envelope never produced (rolled clip(N(130, 40), 20, 400), latent U{20..150}): not the headline")
+    ap.add_argument("--dup", type=int, default=10, choices=[0, 10, 30], help="--workload structured: the share (%%) of a rolled template's texture points whose 16-byte code vector also occurs at another point of the template")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--k", type=int, default=24)
     ap.add_argument("--variant", type=int, default=-1)
@@ -197,6 +198,7 @@ def main():
     ap.add_argument("--tile-share", type=int, default=0)
     ap.add_argument("--bound-cus", type=int, default=-1, help="CUs the bound pass is confined to, the minutiae stage running beside it on the others (-1 = the library's default, 128; 0 = one stream, kernels back to back)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--score-stats", action="store_true", help="after the timed region: the share of non-mate pairs with a positive score (always reported for --workload structured)")
     ap.add_argument("--no-alone", action="store_true", help="skip the extra back-to-back steps after the timed region (roofline.alone_on_the_chip): for profiler runs, whose per-kernel averages they would mix into")
     ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (a few atomics per pair; not for timed runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
@@ -248,9 +250,22 @@ def main():
     nm_all, nt_all = S.gallery_counts(a.seed, G, **wl["gallery"])
     bounds = SH.shard_bounds(nt_all, world)                # balanced by rolled texture points, the cost driver
     lo, hi = bounds[rank]
-    lats = S.make_latents(a.seed, Q, **wl["latent"])
-    gal = S.make_packed_gallery(a.seed, G, cb, lo, hi, **wl["gallery"])
-    planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
+    dup_measured = None
+    if a.workload == "structured":
+        # templates with the structure of extracted prints; the descriptors are drawn on the GPU (torch: plumbing) and encoded by the library's own encoder (afis_pq_encode)
+        SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
+        sigma = SS.DUP_SIGMA[a.dup]
+        lats = SS.make_structured_latents(a.seed, Q, sigma=sigma, **wl["latent"])
+        m_enc = M.Matcher(cb_bytes, device=gpu)
+        gal = SS.make_packed_gallery_structured(a.seed, G, cb, lo, hi, sigma=sigma, encode=m_enc.pq_encode, device=torch.device("cuda", gpu), **wl["gallery"])
+        m_enc.close()
+        planted = SS.plant_structured_mates(a.seed, gal, cb, lats, G=G, lo=lo, sigma=sigma)
+        n_s = min(gal.G, 2000)
+        dup_measured = round(SS.dup_share(gal.tex_codes[:int(gal.tex_off[n_s])], gal.tex_off[:n_s + 1]), 4)
+    else:
+        lats = S.make_latents(a.seed, Q, **wl["latent"])
+        gal = S.make_packed_gallery(a.seed, G, cb, lo, hi, **wl["gallery"])
+        planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
     t_gen = time.perf_counter() - t_gen
 
     m = M.Matcher(cb_bytes, device=gpu, taps=a.refine_stats or 0 <= a.variant < 8)      # --refine-stats reads a parity tap, --variant 0..7 runs a reference kernel: libafis_hip_test.so
@@ -330,6 +345,12 @@ def main():
         ranks_info = [None] * world
         dist.all_gather_object(ranks_info, me)
 
+    refine_stats = None
+    if a.refine_stats:                                          # counters of the timed steps + the warm-up (ratios are what matters)
+        refine_stats = m.refine_stats()
+        rs_ = refine_stats
+        refine_stats.update({"share_of_rows_evaluated": round(rs_["rows_evaluated"] / max(1, rs_["rows"]), 5), "cells_per_evaluated_row": round(rs_["cells_evaluated"] / max(1, rs_["rows_evaluated"]), 4),
+                             "share_of_evaluated_rows_in_full": round(rs_["rows_evaluated_in_full"] / max(1, rs_["rows_evaluated"]), 6), "evaluated_rows_per_pair": round(rs_["rows_evaluated"] / max(1, rs_["pairs"]), 2)})
     # ---- rank-list sanity: the planted true mate must be rank 1 ------------------------------------------------------
     hits = sum(1 for q in range(Q) if int(idx[q, 0]) == planted[q][0][0])
 
@@ -347,6 +368,19 @@ def main():
         alone = {k_: (v / 2 if (k_.endswith("_ms") or k_.endswith("_ghz")) else v) for k_, v in acc.items()}
         m.set_option("bound_cus", bound_cus_opt)
 
+    # ---- outside the timed region: what share of the (latent, non-mate) pairs scores above zero (i.i.d. random templates: none; extracted prints: most) ----
+    score_stats = None
+    if world == 1 and (a.workload == "structured" or a.score_stats):
+        r_ = m.search_resident(qh, k=a.k, want_scores=True, want_parts=True)
+        sc_ = r_["scores"].copy(); pt_ = r_["parts"]
+        mate = np.zeros_like(sc_, bool)
+        for q_, lst in planted.items():
+            for g_, _f in lst: mate[q_, g_ - lo] = True
+        nm_ = ~mate & (sc_ >= 0)
+        score_stats = {"non_mate_pairs": int(nm_.sum()), "non_mates_with_positive_score": round(float((sc_[nm_] > 0).mean()), 5),
+                       "non_mates_with_positive_texture_score": round(float((pt_[..., 3][nm_] > 0).mean()), 5), "non_mates_with_positive_minutiae_score": round(float((pt_[..., :3][nm_] > 0).any(-1).mean()), 5),
+                       "non_mate_score_mean": round(float(sc_[nm_].mean()), 4), "non_mate_score_max": round(float(sc_[nm_].max()), 3),
+                       "true_mate_score_mean": round(float(np.mean([sc_[q_, planted[q_][0][0] - lo] for q_ in planted])), 2)}
     out = None
     if rank == 0 and a.dump_ranks:
         np.savez(a.dump_ranks, idx=np.asarray(idx), score=np.asarray(sc))
@@ -425,8 +459,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"batch {Q} latents vs {G}-template synthetic rolled gallery "
-                                   f"({'BASELINE.json configs[2]' if (Q, G, a.workload) == (100, 100000, 'headline') else 'NOT the headline: ' + ('workload wide — rolled minutiae clip(N(130, 40), 20, 400), latent minutiae U{20..150}, everything else as configs[2]' if a.workload == 'wide' else 'not the headline size')}); planted mates; top-{a.k} rank lists",
-                       "workload_name": a.workload, "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
+                                   f"({'BASELINE.json configs[2]' if (Q, G, a.workload) == (100, 100000, 'headline') else 'NOT the headline: ' + ('workload wide — rolled minutiae clip(N(130, 40), 20, 400), latent minutiae U{20..150}, everything else as configs[2]' if a.workload == 'wide' else ('workload structured — configs[2] sizes; texture points on the 16-px grid inside a foreground blob, smooth ridge flow, descriptors near a shared manifold PQ-encoded afterwards, --dup %d' % a.dup) if a.workload == 'structured' else 'not the headline size')}); planted mates; top-{a.k} rank lists",
+                       "workload_name": a.workload, "structured_dup_share_measured": dup_measured, "queries": Q, "gallery": G, "parallelism": f"gallery-shard x{world}",
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
@@ -447,7 +481,7 @@ def main():
                                          "fallback_share": round(tm_acc.get("minu_fallback_tasks", 0) / max(1, tm_acc.get("minu_tasks", 0)), 6),
                                          "fast_kernel_limits": {k_: m.get_option(k_) for k_ in ("minu_fast_max_latent", "minu_fast_max_rolled", "minu_fast_max_cells")},
                                          "how": "counted by the kernels of this run (afis_timing.minu_*): small = <= 64 x 128 minutiae (256-thread workgroups), medium = <= 16 384 similarities (512), large = <= 512 rolled minutiae and <= 38 912 similarities incl. the stride padding (1024)"},
-            "refine_stats": m.refine_stats() if a.refine_stats else None,
+            "refine_stats": refine_stats, "score_stats": score_stats,
             "per_rank_ms_per_step": {"search": {"min": round(float(pr_min[0]), 3), "max": round(float(pr_max[0]), 3)},
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},
                                      "note": "host wall time per rank; a rank that finishes its shard early waits in the exchange for the slowest: min(exchange) is the step's own cost"},

@@ -148,6 +148,9 @@ GEN_BLOCK = 1024   # templates per independently seeded block: any shard can be 
 WORKLOADS = {
     "headline": {"gallery": {}, "latent": {}},
     "wide": {"gallery": {"n_minu_mean": 130, "n_minu_sd": 40, "n_minu_max": 400}, "latent": {"n_minu_lo": 20, "n_minu_hi": 150}},
+    # the headline's template sizes with the STRUCTURE of extracted prints (host/synth_structured.py): grid coordinates inside a foreground blob, smooth ridge flow,
+    # descriptors near a shared manifold that are PQ-encoded afterwards (neighbouring points share codes; a chosen share of exact duplicates)
+    "structured": {"gallery": {}, "latent": {}},
 }
 
 
