@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--score-stats", action="store_true", help="after the timed region: the share of non-mate pairs with a positive score (always reported for --workload structured)")
     ap.add_argument("--no-alone", action="store_true", help="skip the extra back-to-back steps after the timed region (roofline.alone_on_the_chip): for profiler runs, whose per-kernel averages they would mix into")
-    ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (a few atomics per pair; not for timed runs)")
+    ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (one extra step after the timed region, in a second context on the test library)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
     ap.add_argument("--exchange", default="torch", choices=["torch", "cpp"], help="the rank-list exchange step: torch = torch.distributed all_gather (host/sharding.py); "
                     "cpp = the `match` host's own exchange (csrc/rank_exchange.cpp: ncclAllGather, or its TCP stand-in with AFIS_EXCHANGE=tcp) through libafis_exchange.so")
@@ -268,7 +268,7 @@ def main():
         planted = S.plant_mates(a.seed, gal, cb, lats, G=G, lo=lo)
     t_gen = time.perf_counter() - t_gen
 
-    m = M.Matcher(cb_bytes, device=gpu, taps=a.refine_stats or 0 <= a.variant < 8)      # --refine-stats reads a parity tap, --variant 0..7 runs a reference kernel: libafis_hip_test.so
+    m = M.Matcher(cb_bytes, device=gpu, taps=0 <= a.variant < 8)      # --variant 0..7 runs a reference kernel: libafis_hip_test.so
     if a.variant >= 0: m.set_option("adc_variant", a.variant)
     if a.query_batch > 0: m.set_option("query_batch", a.query_batch)
     if a.chunk > 0: m.set_option("chunk", a.chunk)
@@ -277,7 +277,6 @@ def main():
     bound_cus = m.get_option("bound_cus") if (a.variant < 0 or a.variant == 9) else 0
     if a.share_gpu and world > 1:                          # test mode: the ranks share one device, and each would otherwise budget its launch groups from all of its free memory
         m.set_option("rowmax_budget_mb", max(1024, int(0.5 * torch.cuda.mem_get_info(gpu)[1] / world) >> 20))
-    if a.refine_stats: m.set_option("mf_stats", 1)
     t_up = time.perf_counter()
     m.gallery_add_packed(gal)
     m.gallery_commit(lo)
@@ -346,8 +345,16 @@ def main():
         dist.all_gather_object(ranks_info, me)
 
     refine_stats = None
-    if a.refine_stats:                                          # counters of the timed steps + the warm-up (ratios are what matters)
-        refine_stats = m.refine_stats()
+    if a.refine_stats and rank == 0:
+        # a SECOND context on the test library (the counters are read through a parity tap) runs one step after the timed region: the counters cost five same-address atomics
+        # per pair (round 6 measured +480 ms per step with them on), so they are never collected inside it
+        m2 = M.Matcher(cb_bytes, device=gpu, taps=True)
+        if a.variant >= 0: m2.set_option("adc_variant", a.variant)
+        m2.set_option("mf_stats", 1); m2.set_option("rowmax_budget_mb", 16384)
+        m2.gallery_add_packed(gal); m2.gallery_commit(lo)
+        m2.search(lats, k=a.k, want_scores=False)
+        refine_stats = m2.refine_stats()
+        m2.close()
         rs_ = refine_stats
         refine_stats.update({"share_of_rows_evaluated": round(rs_["rows_evaluated"] / max(1, rs_["rows"]), 5), "cells_per_evaluated_row": round(rs_["cells_evaluated"] / max(1, rs_["rows_evaluated"]), 4),
                              "share_of_evaluated_rows_in_full": round(rs_["rows_evaluated_in_full"] / max(1, rs_["rows_evaluated"]), 6), "evaluated_rows_per_pair": round(rs_["rows_evaluated"] / max(1, rs_["pairs"]), 2)})

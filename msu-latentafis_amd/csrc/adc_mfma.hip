@@ -343,7 +343,7 @@ hipError_t launch_adc_mfma(const GalleryDev& g, const void* codes_p, const float
     if (n_rb <= 0 || g.G <= 0) return hipSuccess;
     const int n_chunks = (g.G + chunk - 1) / chunk;
     const int n_rg = (n_rb + kM12RowBlocks - 1) / kM12RowBlocks;
-    static const bool xcd_map = getenv("AFIS_MF_NO_XCD_MAP") == nullptr;       // experiment knob: round-robin chunks as in rounds 3-4
+    static const bool xcd_map = AFIS_EXPERIMENT_ENV("AFIS_MF_NO_XCD_MAP") == nullptr;       // experiment knob: round-robin chunks as in rounds 3-4
     const long long blocks = (long long)n_rg * (xcd_map ? (n_chunks + 7) / 8 * 8 : n_chunks);
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 #ifdef AFIS_EXPERIMENTAL_KERNELS                                          // three row blocks per wave (8 waves, 224 registers): -1 % alone on the chip, +2 % in the default schedule; test library only

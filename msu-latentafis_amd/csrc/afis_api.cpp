@@ -178,7 +178,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
         ctx->overlap_failed = false;
         if (value > 0) {
             uint32_t lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the runtime deals the mask's bits round-robin over the XCDs: the low N bits are N / 8 CUs of each
-            const bool whole_xcds = getenv("AFIS_BOUND_WHOLE_XCDS") != nullptr;   // experiment: value / 32 WHOLE XCDs for the bound pass instead of value / 8 CUs of each — measured: the pass takes 287 ms per group on 4 whole XCDs against 235 on 16 CUs of each of the 8 (the power limit acts per XCD); the step falls back to the back-to-back time
+            const bool whole_xcds = AFIS_EXPERIMENT_ENV("AFIS_BOUND_WHOLE_XCDS") != nullptr;   // experiment: value / 32 WHOLE XCDs for the bound pass instead of value / 8 CUs of each — measured: the pass takes 287 ms per group on 4 whole XCDs against 235 on 16 CUs of each of the 8 (the power limit acts per XCD); the step falls back to the back-to-back time
             for (int b = 0; b < std::min(256, ctx->n_cus); ++b) ((whole_xcds ? (b & 7) < (int)value / 32 : b < (int)value) ? lo : hi)[b >> 5] |= 1u << (b & 31);
             hipError_t e = hipExtStreamCreateWithCUMask(&ctx->stream_lo, 8, lo);
             if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->stream_hi, 8, hi);

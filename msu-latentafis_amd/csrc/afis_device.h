@@ -4,6 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Experiment knobs (environment variables that re-create an earlier round's schedule, or skip work for a timing-only run) exist in libafis_hip_test.so only
+// (-DAFIS_EXPERIMENTAL_KERNELS): the product library does not read them, and their names do not occur in it (tests/test_host.py compares `strings libafis_hip.so`
+// with the table of operational variables in INTEGRATION.md section E).
+#ifdef AFIS_EXPERIMENTAL_KERNELS
+#define AFIS_EXPERIMENT_ENV(name) (getenv(name))
+#else
+#define AFIS_EXPERIMENT_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace afis {
 
 constexpr int kM = 16;            // PQ sub-quantizers         (codebook header, matcher.cpp:74)

@@ -33,7 +33,7 @@ int64_t group_budget_bytes(const afis_ctx* ctx)
 int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, const char* what)
 {
     if (ctx->search_timeout_s <= 0) {                                      // unbounded: every stream of the list in turn (the side streams come first)
-        static const bool last_only = getenv("AFIS_WAIT_CTX_SYNC_ONLY") != nullptr;     // experiment (tools/repro/README.md): round 4's hanging form, a blocking wait on the context's stream alone
+        static const bool last_only = AFIS_EXPERIMENT_ENV("AFIS_WAIT_CTX_SYNC_ONLY") != nullptr;     // experiment (tools/repro/README.md): round 4's hanging form, a blocking wait on the context's stream alone
         hipStream_t last = nullptr; for (hipStream_t st : streams) last = st;
         for (hipStream_t st : streams) if (st && (!last_only || st == last)) HIPCHK(ctx, hipStreamSynchronize(st));
         return AFIS_OK;
@@ -309,7 +309,7 @@ int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t aft
 int adc_refine_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, bool compact)
 {
     if (grp.n_lt_rows <= 0 || ctx->gal.G <= 0) return AFIS_OK;
-    static const bool skip = getenv("AFIS_ABLATE_SKIP_TEXTURE_TAIL") != nullptr;    // timing experiments with ablated bound-pass builds (tools/r05_run10.sh): their records are garbage, the kernels behind the pass must not read them
+    static const bool skip = AFIS_EXPERIMENT_ENV("AFIS_ABLATE_SKIP_TEXTURE_TAIL") != nullptr;    // timing experiments with ablated bound-pass builds (tools/r05_run10.sh): their records are garbage, the kernels behind the pass must not read them
     if (skip) return AFIS_OK;
     const int R_pad = (grp.n_lt_rows + 31) / 32 * 32;
     HIPCHK(ctx, launch_tex_refine(grp.dev, ctx->gal, ctx->codewords.as<float>(), ctx->mf_rec.p, ctx->mf_rowk.p, R_pad, all_rows ? 1 : 0, ctx->rm_val.as<float>(),
@@ -387,7 +387,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     size_t gi = 0;
     SideStreamGuard side_guard(ctx);
     bool any_overlap = false;
-    static const bool skip_tex_tail = getenv("AFIS_ABLATE_SKIP_TEXTURE_TAIL") != nullptr;   // timing experiments only (see adc_refine_mfma)
+    static const bool skip_tex_tail = AFIS_EXPERIMENT_ENV("AFIS_ABLATE_SKIP_TEXTURE_TAIL") != nullptr;   // timing experiments only (see adc_refine_mfma)
     for (QueryGroup& grp : q->groups) {
         const QueryDev& d = grp.dev;
         const int nq = grp.nq;
@@ -471,7 +471,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 // (wait_streams).  Round 4 blocked on the two side streams after every group because hipStreamSynchronize of the context's stream alone never returned with
                 // ROCm 7.2 while work it depends on sat on the CU-masked side streams; a hipStreamQuery loop does return (profiles/r05_side_stream_waits.json: 46.11 / 46.09 / 46.03
                 // queries/s without the group wait polling one stream / all three / with the group wait), and it is bounded.  AFIS_GROUP_WAIT=1 restores the per-group wait.
-                static const bool group_wait = getenv("AFIS_GROUP_WAIT") != nullptr;
+                static const bool group_wait = AFIS_EXPERIMENT_ENV("AFIS_GROUP_WAIT") != nullptr;
                 if (group_wait) { const int rcw = wait_streams(ctx, {sl, sh}, "afis_search: side streams of a launch group"); side_guard.disarm(); if (rcw != AFIS_OK) return rcw; }
                 any_overlap = true;
             } else {

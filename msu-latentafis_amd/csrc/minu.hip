@@ -747,8 +747,10 @@ static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCa
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands_rt<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RtSmem<S>));
     if (e != hipSuccess) return e;
     const int per_cu = 4 / S;                                                      // 4 / 2 / 1 workgroups (16 waves) per CU, persistent: rolled templates are drawn from ctl[4 + class]
-    static const int grid_cap = getenv("AFIS_RT_GRID") ? atoi(getenv("AFIS_RT_GRID")) : 0;      // experiment: occupancy probe (512 = two small-class workgroups per CU, ...)
-    const int full = (grid_cap > 0 && S == 1) ? grid_cap : 256 * per_cu;
+#ifndef AFIS_RT_GRID_CAP
+#define AFIS_RT_GRID_CAP 0                                                         // occupancy probe (a build-time constant since round 6: 512 = two small-class workgroups per CU, ...)
+#endif
+    const int full = (AFIS_RT_GRID_CAP > 0 && S == 1) ? AFIS_RT_GRID_CAP : 256 * per_cu;
     const int grid = g.G < full ? g.G : full;
     hipLaunchKernelGGL(k_minu_cands_rt<S>, dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag);
     return hipGetLastError();

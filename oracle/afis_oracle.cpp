@@ -24,6 +24,8 @@
 // canonical order: k-ascending fmaf chain for the descriptor GEMM, index-ascending unfused
 // mul+add for mat-vecs and sums.  The HIP path uses the same canonical orders.
 //
+// Every scorer's `tie_mode` argument carries two fields: bits 0-3 the tie mode below, bits 4.. the accumulation
+// order of the Eigen-owned sums (0 = canonical; see "accumulation orders" further down).
 // tie_mode: 0 = std::sort on the reference's comparator (what the reference does; the order of
 //               equal keys is whatever libstdc++'s introsort yields),
 //           1 = canonical: equal keys ordered by ascending index (std::stable_sort).
@@ -83,9 +85,84 @@ typedef std::tuple<float, int, int> Corr;  // (similarity, latent idx, rolled id
 template <class Cmp>
 void sort_idx(std::vector<int>& y, Cmp cmp, int tie_mode)
 {
-    if (tie_mode == 0) std::sort(y.begin(), y.end(), cmp);
+    if ((tie_mode & 15) == 0) std::sort(y.begin(), y.end(), cmp);
     else std::stable_sort(y.begin(), y.end(), cmp);
 }
+
+// ---- accumulation orders (sum_order = bits 4.. of the `tie_mode` argument every scorer takes) ---------------------------------
+// The reference leaves three pieces of arithmetic to Eigen (version unpinned, not in the tree): the descriptor product of S1
+// (matcher.cpp:443), the row / column sums of S2 (:455-456) and the mat-vec + sum of the S8 power iteration (:1286-1288, :1408-1410).
+// Order 0 is the canonical one the HIP path implements.  The others exist to MEASURE how far a score can move when the same sums are
+// taken in the orders an Eigen build takes them (tools/order_sweep.py -> profiles/r06_order_sweep.json; the parity claim of DESIGN
+// section 2 rests on that measurement, not on an argument):
+//   0  canonical: S1 = k-ascending fmaf chain; every other sum index-ascending, multiply and add rounded separately
+//   1  S1 = k-ascending, multiply and add rounded separately (the GEBP kernel of the reference's own build flags, -O3 without -march:
+//      SSE2, no FMA; GEBP vectorises over OUTPUTS, each output's sum runs over k in order); the rest as 0
+//   2  as 1, and the contiguous reductions (S2's row sums, S8's mat-vec rows and its sum of c) as 4 strided partial sums reduced
+//      (l0 + l2) + (l1 + l3) at the end, scalar tail added last — Eigen's linear vectorised redux / row-major gemv with SSE packets;
+//      S2's column sums stay sequential (strided in memory: not vectorised along the sum)
+//   3  every sum, S1 included, as 4 strided partial sums (unfused)
+//   4  every sum as 8 strided partial sums with fused multiply-adds (an -march=native AVX2 + FMA build), reduced 8 -> 4 -> 2 -> 1
+//   5  every sum pairwise (recursive halving), unfused
+static inline float lanes_reduce(const float* l, int W)
+{
+    float q[4];
+    if (W == 8) { for (int i = 0; i < 4; ++i) q[i] = l[i] + l[i + 4]; } else { for (int i = 0; i < 4; ++i) q[i] = l[i]; }
+    float a = q[0] + q[2], b = q[1] + q[3];
+    return a + b;
+}
+static float pairwise_sum(const float* x, int n, int stride)
+{
+    if (n <= 0) return 0.f;
+    if (n == 1) return x[0];
+    if (n == 2) return x[0] + x[stride];
+    int h = n / 2;
+    float a = pairwise_sum(x, h, stride), b = pairwise_sum(x + (size_t)h * stride, n - h, stride);
+    return a + b;
+}
+// sum_i x[i * stride]; how: 0 sequential, 4 / 8 strided lanes, -1 pairwise
+static float sum_how(const float* x, int n, int stride, int how)
+{
+    if (how == -1) return pairwise_sum(x, n, stride);
+    if (how == 0) { float s = 0.f; for (int i = 0; i < n; ++i) s += x[(size_t)i * stride]; return s; }
+    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int W = how, full = n - n % W;
+    for (int i = 0; i < full; ++i) l[i % W] += x[(size_t)i * stride];
+    float s = lanes_reduce(l, W);
+    for (int i = full; i < n; ++i) s += x[(size_t)i * stride];
+    return s;
+}
+// sum_k a[k] * b[k]; fused: fmaf
+static float dot_how(const float* a, const float* b, int n, int how, bool fused)
+{
+    if (how == -1) { std::vector<float> p(n); for (int k = 0; k < n; ++k) p[k] = a[k] * b[k]; return pairwise_sum(p.data(), n, 1); }
+    if (how == 0) {
+        float acc = 0.f;
+        if (fused) { for (int k = 0; k < n; ++k) acc = fmaf(a[k], b[k], acc); }
+        else { for (int k = 0; k < n; ++k) { float p = a[k] * b[k]; acc += p; } }
+        return acc;
+    }
+    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int W = how, full = n - n % W;
+    for (int k = 0; k < full; ++k) { if (fused) l[k % W] = fmaf(a[k], b[k], l[k % W]); else { float p = a[k] * b[k]; l[k % W] += p; } }
+    float s = lanes_reduce(l, W);
+    for (int k = full; k < n; ++k) { if (fused) s = fmaf(a[k], b[k], s); else { float p = a[k] * b[k]; s += p; } }
+    return s;
+}
+struct SumOrder {
+    int s1_how, contiguous_how, strided_how; bool s1_fused, mv_fused;
+    explicit SumOrder(int tie_mode)
+    {
+        switch (tie_mode >> 4) {
+        default: case 0: s1_how = 0; contiguous_how = 0; strided_how = 0; s1_fused = true; mv_fused = false; break;
+        case 1: s1_how = 0; contiguous_how = 0; strided_how = 0; s1_fused = false; mv_fused = false; break;
+        case 2: s1_how = 0; contiguous_how = 4; strided_how = 0; s1_fused = false; mv_fused = false; break;
+        case 3: s1_how = 4; contiguous_how = 4; strided_how = 4; s1_fused = false; mv_fused = false; break;
+        case 4: s1_how = 8; contiguous_how = 8; strided_how = 8; s1_fused = true; mv_fused = true; break;
+        case 5: s1_how = -1; contiguous_how = -1; strided_how = -1; s1_fused = false; mv_fused = false; break;
+        }
+    }
+};
 
 // ---- byte reader with ifstream-like semantics -------------------------------------------------
 struct Reader {
@@ -337,17 +414,13 @@ std::vector<Corr> dist_filter(const std::vector<Corr>& corr, const std::vector<P
     // power iteration, :1279-1289 / :1401-1411.  Canonical order (Eigen's is unpinned): c_j = sum_k H[j][k]*b[k]
     // k ascending, unfused; sum = sum_j c_j ascending; the 1/(sum+1e-5) factor is computed in double and
     // narrowed to float before the multiply (Eigen narrows a double scalar to the vector's scalar type).
+    const SumOrder so(tie_mode);
     std::vector<float> b(num), c(num);
     for (int i = 0; i < num; ++i) b[i] = std::get<0>(corr[i]);
     for (int it = 0; it < iters; ++it) {
         float sum = 0.0f;
-        for (int j = 0; j < num; ++j) {
-            float acc = 0.0f;
-            const float* hr = &H[(size_t)j * num];
-            for (int k = 0; k < num; ++k) { float p = hr[k] * b[k]; acc += p; }
-            c[j] = acc;
-        }
-        for (int j = 0; j < num; ++j) sum += c[j];
+        for (int j = 0; j < num; ++j) c[j] = dot_how(&H[(size_t)j * num], b.data(), num, so.contiguous_how, so.mv_fused);
+        sum = sum_how(c.data(), num, 1, so.contiguous_how);
         float scale = (float)(1. / (sum + 0.00001));
         for (int j = 0; j < num; ++j) b[j] = c[j] * scale;
     }
@@ -428,19 +501,19 @@ float minutiae_score(const MinuTpl& L, const MinuTpl& R, const Codebook& cb, int
     int nL = L.n, nR = R.n, D = R.des_len;
     if (D != L.des_len) return NAN;                                    // assert at :433
     std::vector<float> simi((size_t)nL * nR);
+    const SumOrder so(tie_mode);
     // S1 (:440-452).  Canonical order: fmaf chain, k ascending (Eigen's order is unpinned).
     for (int i = 0; i < nL; ++i)
         for (int j = 0; j < nR; ++j) {
-            float acc = 0.0f;
             const float* a = &L.des[(size_t)i * D]; const float* b = &R.des[(size_t)j * D];
-            for (int k = 0; k < D; ++k) acc = fmaf(a[k], b[k], acc);
+            float acc = dot_how(a, b, D, so.s1_how, so.s1_fused);
             if (acc < 0) acc = 0;
             simi[(size_t)i * nR + j] = acc;
         }
     // S2 (:455-470): column sums (rolled) and row sums (latent), index ascending.
     std::vector<float> rs(nR, 0.f), ls(nL, 0.f);
-    for (int j = 0; j < nR; ++j) { float s = 0.f; for (int i = 0; i < nL; ++i) s += simi[(size_t)i * nR + j]; rs[j] = s; }
-    for (int i = 0; i < nL; ++i) { float s = 0.f; for (int j = 0; j < nR; ++j) s += simi[(size_t)i * nR + j]; ls[i] = s; }
+    for (int j = 0; j < nR; ++j) rs[j] = sum_how(&simi[j], nL, nR, so.strided_how);
+    for (int i = 0; i < nL; ++i) ls[i] = sum_how(&simi[(size_t)i * nR], nR, 1, so.contiguous_how);
     std::vector<float> norm((size_t)nL * nR);
     for (int i = 0; i < nL; ++i)
         for (int j = 0; j < nR; ++j) {
