@@ -42,22 +42,43 @@ __global__ __launch_bounds__(256) void k_mf_codebook(const float* __restrict__ c
 // Tile-aligned copy of the gallery's texture codes: template t owns ceil(n/32) tiles (32 entries of 16 code bytes, zero beyond the template's
 // points) starting at tile t_blk[t]; per entry also G's point term -|b_j|^2 / 2 (kMfNeg beyond the points), and per tile
 // (template, tile index in the template | 256 on the template's last tile).  grid = G, block = 64.
+//
+// Repeated code vectors.  Texture descriptors of neighbouring grid points come from overlapping patches (extraction_rolled.py:112-141) and are PQ-encoded
+// afterwards: in smooth regions several points of a template carry the SAME 16 code bytes.  Such points have the same similarity to every latent row, bit for bit
+// (the same table entries in the same order, matcher.cpp:571-592), and std::max_element (matcher.cpp:730) takes the first: a later occurrence can never be a row's
+// arg-max and never changes a row's maximum.  So only the FIRST occurrence of a code vector takes part in the bound pass — the others get the point term of a
+// padding point (kMfNeg) and zero codes.  Without this a row whose best vector occurs three times has three cells within any tolerance of its maximum, the bound
+// pass gives up on it ("many") and the recomputation evaluates every point of the template for it: at 30 % repeated points that was 4 % of the evaluated rows and
+// most of the recomputation's time (profiles/r06_bench_structured.json).  (A row evaluated in full still walks all points, repeated ones included: same result.)
 __global__ __launch_bounds__(64) void k_mf_tiles(GalleryDev g, const int32_t* __restrict__ t_blk, const float* __restrict__ cwn,
                                                  uint4* __restrict__ codes_p, float* __restrict__ nrm_p, int2* __restrict__ tile_meta)
 {
+    __shared__ uint4 s_c[kTexMax];
+    __shared__ uint32_t s_hash[kTexMax];
     const int t = blockIdx.x, lane = threadIdx.x;
-    const int p0 = g.tex_off[t], n = g.tex_off[t + 1] - p0;
+    const int p0 = g.tex_off[t], n = min(g.tex_off[t + 1] - p0, kTexMax);
     const int nt = (n + 31) >> 5;
+    for (int p = lane; p < n; p += 64) {
+        const uint4 c = g.tex_codes[p0 + p];
+        s_c[p] = c; s_hash[p] = (c.x * 0x9E3779B1u) ^ (c.y * 0x85EBCA77u) ^ (c.z * 0xC2B2AE3Du) ^ (c.w * 0x27D4EB2Fu);
+    }
+    __syncthreads();
     for (int p = lane; p < nt * 32; p += 64) {
         uint4 c = make_uint4(0, 0, 0, 0);
         float nrm = kMfNeg;
         if (p < n) {
-            c = g.tex_codes[p0 + p];
-            const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-            float s = 0.0f;
+            c = s_c[p];
+            const uint32_t hp = s_hash[p];
+            bool repeated = false;
+            for (int q = 0; q < p && !repeated; ++q)                                // (the wave walks to its largest p: broadcast reads of s_hash[q]; the 16-byte compare only behind a hash match)
+                if (s_hash[q] == hp) { const uint4 d = s_c[q]; repeated = d.x == c.x && d.y == c.y && d.z == c.z && d.w == c.w; }
+            if (!repeated) {
+                const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+                float s = 0.0f;
 #pragma unroll
-            for (int m = 0; m < kM; ++m) s += cwn[m * kK + ((w[m >> 2] >> (8 * (m & 3))) & 255u)];
-            nrm = -0.5f * s;
+                for (int m = 0; m < kM; ++m) s += cwn[m * kK + ((w[m >> 2] >> (8 * (m & 3))) & 255u)];
+                nrm = -0.5f * s;
+            } else c = make_uint4(0, 0, 0, 0);
         }
         const size_t e = (size_t)t_blk[t] * 32 + p;
         codes_p[e] = c; nrm_p[e] = nrm;

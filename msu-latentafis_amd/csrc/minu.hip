@@ -650,9 +650,57 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             PHASE(30);
             const int B = __builtin_amdgcn_readfirstlane(sm.thr_bin);               // (uniform: one LDS word)
             if (B < 2) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
-            // ---- the candidates: approximate key >= edge(B) - 2E ----
+            // ---- a crowded threshold bin: a second histogram inside it ----
+            // Descriptors of extracted prints lie near a common manifold: a pair's norm keys then crowd into an octave or less, and the threshold bin alone (1/16 octave) can hold
+            // more entries than the candidate list (bench.py --workload structured: 8 % of the tasks went to the any-shape kernel for this reason, at 30 x the time).  The bin's keys
+            // are counted again by their next 8 bits (bits 18..11: 256 sub-bins of 2048 ordered-key units, still >> 2E); the sub-bin B2 holding the 120th largest key moves the
+            // candidate edge up to edge(B) + B2 * 2^11.  The argument of the header holds with Ta >= the new edge; the candidates' grouping by bin is unchanged (group B = the last).
+            uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
             {
-                const uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
+                const int above = (int)sm.hist[B], inbin = (int)sm.hist[B - 1] - above;     // uniform (after the scan hist[b] = the entries in the bins above b)
+                if (above + inbin > kCandCap - 32 && B < kSelBins - 1) {                 // (the top bin also holds everything above it: its keys' lower bits say nothing)
+                    uint32_t* const h2 = reinterpret_cast<uint32_t*>(sm.cand);             // the composites' array is free until the candidates are keyed
+                    if (tid < 256) h2[tid] = 0u;
+                    RT_SYNC();
+                    const uint32_t bin_bits = edge >> 19;
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) {
+                        const bool inb = (rk[t] >> 19) == bin_bits;
+                        atomicAdd(inb ? &h2[(rk[t] >> 11) & 255u] : &sm.sink[lane], 1u);
+                    }
+                    if (S == 4 && n_rows > 32) {
+                        const float cs2 = sm.colsum[cj];
+                        for (int t = 32; t < my_rows; ++t) {
+                            const int i = cr + R * t;
+                            const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs2);
+                            if ((key >> 19) == bin_bits) atomicAdd(&h2[(key >> 11) & 255u], 1u);
+                        }
+                    }
+                    RT_SYNC();
+                    if (wave == 0) {                                                     // the scan of the first histogram, over the sub-bins: the (120 - above)-th largest key of the bin
+                        const int need = kTopMinu - above;                               // 1 <= need <= inbin: exactly one sub-bin qualifies
+                        if (lane == 0) sm.thr_bin = 0;                                   // (were none to qualify, the edge stays the bin's own)
+                        const uint4 h = reinterpret_cast<const uint4*>(h2)[lane];
+                        const int s0 = (int)(h.x + h.y + h.z + h.w);
+                        int suf = s0;
+                        suf += __builtin_amdgcn_update_dpp(0, suf, 0x101, 0xf, 0xf, true);
+                        suf += __builtin_amdgcn_update_dpp(0, suf, 0x102, 0xf, 0xf, true);
+                        suf += __builtin_amdgcn_update_dpp(0, suf, 0x104, 0xf, 0xf, true);
+                        suf += __builtin_amdgcn_update_dpp(0, suf, 0x108, 0xf, 0xf, true);
+                        const int r1 = __builtin_amdgcn_readlane(suf, 16), r2 = __builtin_amdgcn_readlane(suf, 32), r3 = __builtin_amdgcn_readlane(suf, 48);
+                        suf += lane < 16 ? r1 + r2 + r3 : lane < 32 ? r2 + r3 : lane < 48 ? r3 : 0;
+                        const int a3 = suf - s0, a2 = a3 + (int)h.w, a1 = a2 + (int)h.z, a0 = a1 + (int)h.y;
+                        if (a3 < need && a3 + (int)h.w >= need) sm.thr_bin = 4 * lane + 3;
+                        if (a2 < need && a2 + (int)h.z >= need) sm.thr_bin = 4 * lane + 2;
+                        if (a1 < need && a1 + (int)h.y >= need) sm.thr_bin = 4 * lane + 1;
+                        if (a0 < need && a0 + (int)h.x >= need) sm.thr_bin = 4 * lane;
+                    }
+                    RT_SYNC();
+                    edge |= (uint32_t)__builtin_amdgcn_readfirstlane(sm.thr_bin) << 11;
+                }
+            }
+            // ---- the candidates: approximate key >= edge - 2E ----
+            {
                 const uint32_t edge_s = edge - kKeySlack;                            // key + slack >= edge  <=>  key >= edge - slack (no wrap: keys of real entries are below 0xff800000, unused slots hold 0)
                 uint32_t hits = 0;
 #pragma unroll

@@ -1391,3 +1391,48 @@ def test_candidate_shape_classes_lists_match_oracle_traces(codebook_bytes, cb, o
     assert np.array_equal(fast["parts"].view(np.uint32), gen["parts"].view(np.uint32))
     assert m.get_option("minu_fast_max_latent") == 256 and m.get_option("minu_fast_max_rolled") == 512 and m.get_option("minu_fast_max_cells") == 38912
     m.close()
+
+
+def test_structured_templates_against_oracle(codebook_bytes, cb, oracle):
+    """A 200-pair slice of the structured sweep (tools/parity_sweep.py with AFIS_SWEEP_WORKLOAD=structured; host/synth_structured.py): rolled texture points on the extractor's
+    16-px grid inside a foreground blob (unique coordinates, scan order: extraction_rolled.py:112-128), orientations from a smooth ridge-flow field (:125), descriptors near a
+    shared manifold that are PQ-encoded afterwards — neighbouring points share most of their 16 codes and about 10 % / 30 % of a template's points carry a code vector that
+    occurs twice in it (the case `std::max_element`'s first-maximum rule exists for, matcher.cpp:730) — latents with two orientations per grid point (extraction_latent.py:204-205).
+    Unlike the i.i.d. templates most NON-mates score above zero here (smooth fields survive the angle tests of matcher.cpp:1503-1540), so every pair exercises the graph stages.
+    Every per-part and fused score bit for bit; the candidate lists of a few pairs after every stage; the crowded-threshold-bin route of the candidate kernel must have kept the
+    tasks away from the any-shape kernel."""
+    SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
+    n_pos = n_pairs = 0
+    for dup, n_lat, n_gal in ((10, 4, 30), (30, 2, 40)):
+        sg = SS.DUP_SIGMA[dup]
+        rng = np.random.default_rng(600 + dup)
+        lats = [SS.make_structured_latent(rng, sigma=sg) for _ in range(n_lat)]
+        gal = [SS.make_structured_mate(rng, cb, L, frac=f, sigma=sg) for L in lats for f in (0.8, 0.3)]
+        while len(gal) < n_gal: gal.append(SS.make_structured_rolled(rng, cb, sigma=sg))
+        off = np.concatenate([[0], np.cumsum([g.tex[0].n for g in gal])])
+        share = SS.dup_share(np.concatenate([g.tex[0].codes for g in gal]), off)
+        assert 0.5 * dup / 100 <= share <= 2.0 * dup / 100, share
+        m = M.Matcher(codebook_bytes, taps=True)
+        m.gallery_add(gal); m.gallery_commit(0)
+        res = m.search(lats, k=0, want_parts=True); tm = m.timing()
+        assert tm["minu_fallback_tasks"] <= 0.02 * tm["minu_tasks"], tm
+        ocb = oracle.codebook(codebook_bytes)
+        hl, hr = cases.to_orc(oracle, ocb, lats, gal)
+        for qi in range(n_lat):
+            rc, sc, parts = oracle.search(ocb, hl[qi], hr, tie_mode=1, want_parts=True)
+            got = np.concatenate([res["parts"][qi], res["scores"][qi][:, None]], axis=1)
+            diff = got.view(np.uint32) != parts.view(np.uint32)
+            assert not diff.any(), (dup, qi, np.argwhere(diff)[:4], got[diff][:4], parts[diff][:4])
+            n_pos += int((sc > 0).sum()); n_pairs += len(gal)
+            assert sc[2 * qi] > 50 and int(np.argmax(sc)) == 2 * qi
+        for qi, gi in ((0, 0), (0, n_gal - 1), (1, n_gal - 2)):               # a mate and two non-mates: the lists after every stage
+            for which in range(4):
+                for stage in range(3):
+                    want = oracle.trace(ocb, hl[qi], hr[gi], which=which, stage=stage, tie_mode=1)
+                    gotl = m.debug_stage_list(lats[qi], gi, which, stage)
+                    assert (want is None) == (gotl is None)
+                    if want is None: continue
+                    assert np.array_equal(gotl[1], want[1]) and np.array_equal(gotl[2], want[2]), (dup, qi, gi, which, stage)
+                    assert np.array_equal(gotl[0].view(np.uint32), want[0].view(np.uint32)), (dup, qi, gi, which, stage)
+        m.close()
+    assert n_pairs == 200 and n_pos >= 100, (n_pairs, n_pos)                   # most non-mates score above zero

@@ -15,8 +15,14 @@ Q = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read(); cb = T.Codebook.from_bytes(cbb)
 wl = S.WORKLOADS[os.environ.get("AFIS_SWEEP_WORKLOAD", "headline")]                 # AFIS_SWEEP_WORKLOAD=wide: the off-envelope shapes of bench.py --workload wide
-lats = S.make_latents(seed, Q, **wl["latent"]); gal = S.make_packed_gallery(seed, G, cb, **wl["gallery"]); S.plant_mates(seed, gal, cb, lats, G=G)
-m = M.Matcher(cbb); m.gallery_add_packed(gal); m.gallery_commit(0)
+m = M.Matcher(cbb)
+if os.environ.get("AFIS_SWEEP_WORKLOAD") == "structured":                            # AFIS_SWEEP_WORKLOAD=structured [AFIS_SWEEP_DUP=0|10|30]: templates with the structure of extracted prints (host/synth_structured.py)
+    SS = importlib.import_module("msu-latentafis_amd.host.synth_structured"); sg = SS.DUP_SIGMA[int(os.environ.get("AFIS_SWEEP_DUP", "10"))]
+    lats = SS.make_structured_latents(seed, Q, sigma=sg); gal = SS.make_packed_gallery_structured(seed, G, cb, sigma=sg, encode=m.pq_encode); SS.plant_structured_mates(seed, gal, cb, lats, G=G, sigma=sg)
+    print("structured: share of texture points whose code vector occurs twice in their template:", round(SS.dup_share(gal.tex_codes, gal.tex_off), 4))
+else:
+    lats = S.make_latents(seed, Q, **wl["latent"]); gal = S.make_packed_gallery(seed, G, cb, **wl["gallery"]); S.plant_mates(seed, gal, cb, lats, G=G)
+m.gallery_add_packed(gal); m.gallery_commit(0)
 if os.environ.get("AFIS_ADC_VARIANT"): m.set_option("adc_variant", int(os.environ["AFIS_ADC_VARIANT"]))
 r = m.search(lats, k=0, want_parts=True)
 orc = Oracle(); ocb = orc.codebook(cbb)
@@ -41,8 +47,9 @@ for qi, L in enumerate(lats):
         npos = int(min((s0[a] > 0).sum(), (gs[b] > 0).sum()))
         top0 += int(not np.array_equal(a[:npos], b[:npos]))
 tmr = m.timing()
-print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
-print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_any_differing_bit": bad,
+npos_pairs = int((r["scores"] > 0).sum())
+print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, {npos_pairs} pairs with a positive score, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
+print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_a_positive_score": npos_pairs, "dup": os.environ.get("AFIS_SWEEP_DUP"), "pairs_with_any_differing_bit": bad,
       "candidate_task_routing": {k: int(v) for k, v in tmr.items() if k.startswith("minu_") and k.endswith("tasks")}}))
 if TIE0:
     print(f"  vs tie_mode=0 (reference sort order): {pos0} positive pairs, {bit0} with a differing bit, {far0} beyond 1e-3, queries whose positive top-24 order changes: {top0}")
