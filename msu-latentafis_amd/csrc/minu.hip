@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                             const uint32_t key = approx_norm_key(sv[u], rs[u], cs) & (uint32_t)-(int)(tb + u < my_rows);   // (a mask, not a select: the compiler turns the select into a branch region)
                             rk[tb + u] = key;
                             const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
-                            atomicAdd(bin > 0 ? &sm.hist[bin] : &sm.sink[lane], 1u);  // zero similarities, norms < 2^-15 and absent rows are not counted
+                            const bool cnt0 = bin <= 0 && (key & 0x7fffffffu) != 0u;                // a positive norm below 2^-15: counted in bin 0 (never a threshold bin; it decides whether a list short of 120 positive keys can be filled up here)
+                            atomicAdd((bin > 0 || cnt0) ? &sm.hist[max(bin, 0)] : &sm.sink[lane], 1u);  // zero similarities and absent rows are not counted
                         }
                         a += 4 * a_step; i += 4 * R;
                     }
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                         if (t < my_rows) {
                             const uint32_t key = approx_norm_key(sm.simi[a], sm.rowsum[i], cs);
                             const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
-                            if (bin > 0) atomicAdd(&sm.hist[bin], 1u);
+                            if (bin > 0 || (key & 0x7fffffffu) != 0u) atomicAdd(&sm.hist[max(bin, 0)], 1u);
                         }
                         a += R * ld; i += R;
                     }
@@ -640,6 +641,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 const int r1 = __builtin_amdgcn_readlane(suf, 16), r2 = __builtin_amdgcn_readlane(suf, 32), r3 = __builtin_amdgcn_readlane(suf, 48);   // ... and the totals of the rows above
                 suf += lane < 16 ? r1 + r2 + r3 : lane < 32 ? r2 + r3 : lane < 48 ? r3 : 0;
                 const int a3 = suf - s0, a2 = a3 + (int)h.w, a1 = a2 + (int)h.z, a0 = a1 + (int)h.y;     // entries in the bins ABOVE each of the four
+                if (lane == 0) sm.pad_[0] = (int)h.x;                                // positive norms below 2^-15
                 if (a3 < kTopMinu && a3 + (int)h.w >= kTopMinu) sm.thr_bin = 4 * lane + 3;
                 if (a2 < kTopMinu && a2 + (int)h.z >= kTopMinu) sm.thr_bin = 4 * lane + 2;
                 if (a1 < kTopMinu && a1 + (int)h.y >= kTopMinu) sm.thr_bin = 4 * lane + 1;
@@ -648,15 +650,20 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             }
             RT_SYNC();
             PHASE(30);
-            const int B = __builtin_amdgcn_readfirstlane(sm.thr_bin);               // (uniform: one LDS word)
-            if (B < 2) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // fewer than 120 counted keys, or a threshold next to the uncounted bin
+            const int Braw = __builtin_amdgcn_readfirstlane(sm.thr_bin);            // (uniform: one LDS word)
+            // Fewer than 120 positive norms, every one of them at least 2^-15 (a latent and a rolled print whose descriptors point away from each other: nearly every similarity is
+            // clamped to zero, matcher.cpp:447-451 — 8 % of the pairs of bench.py --workload structured, which the any-shape kernel did at 30 x the time): the positive entries are all
+            // candidates and are ranked as always; the rest of the 120 are zero entries, which tie, in ascending element order (tie rule) — filled in below.
+            const bool fill = Braw < 0 && __builtin_amdgcn_readfirstlane(sm.pad_[0]) == 0;
+            if (Braw < 2 && !fill) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // a threshold in or next to bin 0, or tiny positive norms among fewer than 120
+            const int B = fill ? 0 : Braw;
             // ---- a crowded threshold bin: a second histogram inside it ----
             // Descriptors of extracted prints lie near a common manifold: a pair's norm keys then crowd into an octave or less, and the threshold bin alone (1/16 octave) can hold
             // more entries than the candidate list (bench.py --workload structured: 8 % of the tasks went to the any-shape kernel for this reason, at 30 x the time).  The bin's keys
             // are counted again by their next 8 bits (bits 18..11: 256 sub-bins of 2048 ordered-key units, still >> 2E); the sub-bin B2 holding the 120th largest key moves the
             // candidate edge up to edge(B) + B2 * 2^11.  The argument of the header holds with Ta >= the new edge; the candidates' grouping by bin is unchanged (group B = the last).
-            uint32_t edge = 0x80000000u | ((uint32_t)(B + kBinBase) << 19);
-            {
+            uint32_t edge = fill ? 0x80000001u + kKeySlack : 0x80000000u | ((uint32_t)(B + kBinBase) << 19);     // fill: every positive key
+            if (!fill) {
                 const int above = (int)sm.hist[B], inbin = (int)sm.hist[B - 1] - above;     // uniform (after the scan hist[b] = the entries in the bins above b)
                 if (above + inbin > kCandCap - 32 && B < kSelBins - 1) {                 // (the top bin also holds everything above it: its keys' lower bits say nothing)
                     uint32_t* const h2 = reinterpret_cast<uint32_t*>(sm.cand);             // the composites' array is free until the candidates are keyed
@@ -771,6 +778,18 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 if (r < kTopMinu) {
                     MinuCand cd; cd.sim = sm.simi[ci * ld + cj2]; cd.li = (short)ci; cd.ri = (short)cj2;
                     cands[(size_t)task * kTopMinu + r] = cd;
+                }
+            }
+            if (fill && wave == 0) {                                                 // ranks n_c .. 119: the first zero similarities in element order (n >= 512 entries, fewer than 120 of them positive: there are enough)
+                int rank = n_c;
+                for (int e0 = 0; e0 < n && rank < kTopMinu; e0 += 64) {
+                    const int e = e0 + lane;
+                    const int i = e / nR, j = e - i * nR;
+                    const bool z = e < n && sm.simi[i * ld + j] == 0.0f;
+                    const u64 zm = __ballot(z);
+                    const int r = rank + lane_prefix(zm);
+                    if (z && r < kTopMinu) { MinuCand cd; cd.sim = 0.0f; cd.li = (short)i; cd.ri = (short)j; cands[(size_t)task * kTopMinu + r] = cd; }
+                    rank += (int)__popcll(zm);
                 }
             }
             if (tid == 0) cand_n[task] = kTopMinu;

@@ -401,3 +401,61 @@ def test_launch_group_rule_places_the_cuts_where_the_row_groups_are_fewest(tmp_p
     cuts, auto = run(rows, 50)
     assert cuts == [2, 51, 100] and cost(rows, cuts) == (sum(rows) + 767) // 768 == 88
     assert auto == {1: 128, 12500: 128, 39000: 128, 40000: 125, 50000: 100, 100000: 50, 250000: 20, 500000: 10, 1000000: 10}
+
+
+def test_product_library_reads_only_the_operational_variables():
+    """INTEGRATION.md section E lists the environment variables the product library reads ("Operational"); experiment knobs (result-changing or known-bad ones among
+    them) live in the test library only.  `strings libafis_hip.so | grep ^AFIS_` must be exactly the library's part of that table."""
+    def env_names(path):
+        data = open(path, "rb").read()
+        return set(m.decode() for m in re.findall(rb"(?<![A-Z_])AFIS_[A-Z0-9_]+(?=\x00)", data))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("### Environment variables"):doc.index("That table is the whole list")]
+    listed = set(re.findall(r"`(AFIS_[A-Z0-9_]+)`", "\n".join(row.split("|")[1] for row in table.splitlines() if row.startswith("| `AFIS_"))))   # first column of the table's rows
+    not_the_library = {"AFIS_EXCHANGE", "AFIS_EXCHANGE_TIMEOUT_S", "AFIS_FORCE_EXCHANGE", "AFIS_MATCH_TIMING"}      # read by `match` / libafis_exchange.so (same table, their own rows)
+    assert env_names(os.path.join(CSRC, "libafis_hip.so")) == listed - not_the_library
+    experiments = {"AFIS_MF_NO_XCD_MAP", "AFIS_BOUND_WHOLE_XCDS", "AFIS_GROUP_WAIT", "AFIS_WAIT_CTX_SYNC_ONLY", "AFIS_ABLATE_SKIP_TEXTURE_TAIL"}
+    assert env_names(os.path.join(CSRC, "libafis_hip_test.so")) == (listed - not_the_library) | experiments
+    for name in experiments:
+        assert name in doc[doc.index("That table is the whole list"):doc.index("## F.")], name
+
+
+def test_structured_generator_has_the_structure_it_claims(cb):
+    """host/synth_structured.py: unique grid coordinates in scan order (extraction_rolled.py:112-128), orientation = minus a smooth flow direction (:125), codes from a
+    smooth field (neighbours share most codes; the named duplicate shares), latents with two orientations per grid point (extraction_latent.py:204-205), and shard
+    consistency (a shard's content depends on (seed, template index) only)."""
+    SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
+    G = 1300
+    full = SS.make_packed_gallery_structured(5, G, cb, sigma=SS.DUP_SIGMA[10], n_tex_lo=300, n_tex_hi=500)
+    part = SS.make_packed_gallery_structured(5, G, cb, 900, 1200, sigma=SS.DUP_SIGMA[10], n_tex_lo=300, n_tex_hi=500)
+    a, b = int(full.tex_off[900]), int(full.tex_off[1200])
+    assert np.array_equal(full.tex_codes[a:b], part.tex_codes) and np.array_equal(full.tex_x[a:b], part.tex_x) and np.array_equal(full.tex_ori[a:b], part.tex_ori)
+    ma, mb = int(full.minu_off[900]), int(full.minu_off[1200])
+    assert np.array_equal(full.minu_des[ma:mb], part.minu_des) and np.array_equal(full.minu_x[ma:mb], part.minu_x)
+    nm, nt = S.gallery_counts(5, G, n_tex_lo=300, n_tex_hi=500)
+    assert np.array_equal(np.diff(full.tex_off), nt) and np.array_equal(np.diff(full.minu_off), nm)
+    n_smooth = n_nb = 0
+    for g in range(0, 200):
+        t = full.template(g).tex[0]
+        cell = t.y.astype(np.int64) * SS.BLK_W + t.x
+        assert np.all(np.diff(cell) > 0)                                            # unique, y-major / x-minor
+        assert t.x.min() >= 0 and t.x.max() < SS.BLK_W and t.y.max() < SS.BLK_H
+        assert np.all(np.abs(t.ori) <= np.pi / 2 + 1e-6)
+        nb = (t.y[1:] == t.y[:-1]) & (t.x[1:] == t.x[:-1] + 1)
+        d = np.abs(t.ori[1:] - t.ori[:-1])[nb]; d = np.minimum(d, np.pi - d)        # orientation mod pi
+        n_smooth += int((d < 0.35).sum()); n_nb += int(nb.sum())
+    assert n_smooth > 0.97 * n_nb                                                   # smooth but for the few blocks next to a singular point
+    share = {d: SS.dup_share(*(lambda gl: (gl.tex_codes, gl.tex_off))(SS.make_packed_gallery_structured(6, 64, cb, sigma=SS.DUP_SIGMA[d]))) for d in (0, 10, 30)}
+    assert share[0] < 0.01 and 0.05 < share[10] < 0.16 and 0.22 < share[30] < 0.40, share
+    same = (full.tex_y[1:] == full.tex_y[:-1]) & (full.tex_x[1:] == full.tex_x[:-1] + 1)
+    assert (full.tex_codes[1:] == full.tex_codes[:-1]).sum(1)[same].mean() > 9      # of 16 codes, with the right-hand neighbour
+    L = SS.make_structured_latent(np.random.default_rng(3))
+    lt = L.tex[0]
+    assert lt.n % 2 == 0 and np.array_equal(lt.x[0::2], lt.x[1::2]) and np.array_equal(lt.y[0::2], lt.y[1::2])
+    assert np.allclose(lt.ori[1::2] - lt.ori[0::2], np.pi, atol=1e-6)
+    assert len(L.minu) == 28 and np.allclose(np.linalg.norm(lt.des, axis=1), T.DESCRIPTOR_NORM, atol=1e-4)
+    R = SS.make_structured_mate(np.random.default_rng(4), cb, L, frac=0.8)
+    rc = R.tex[0].y.astype(np.int64) * SS.BLK_W + R.tex[0].x
+    assert len(np.unique(rc)) == len(rc)                                            # a mate keeps unique coordinates
+    rc2, back = T.read_rolled(T.write_rolled(R))
+    assert rc2 == 0 and np.array_equal(back.tex[0].codes, R.tex[0].codes)
