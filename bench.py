@@ -202,8 +202,9 @@ def main():
     ap.add_argument("--no-alone", action="store_true", help="skip the extra back-to-back steps after the timed region (roofline.alone_on_the_chip): for profiler runs, whose per-kernel averages they would mix into")
     ap.add_argument("--refine-stats", action="store_true", help="adc_variant 9: report what the selection / exact-recomputation kernel did (one extra step after the timed region, in a second context on the test library)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rank-list exchange (nccl = RCCL; gloo for tests)")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "cpp"], help="the rank-list exchange step: torch = torch.distributed all_gather (host/sharding.py); "
-                    "cpp = the `match` host's own exchange (csrc/rank_exchange.cpp: ncclAllGather, or its TCP stand-in with AFIS_EXCHANGE=tcp) through libafis_exchange.so")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "torch", "cpp"], help="the rank-list exchange step: cpp = the `match` host's own exchange (csrc/rank_exchange.cpp: ONE ncclAllGather of the "
+                    "(index, score) block per step, or its TCP stand-in with AFIS_EXCHANGE=tcp) through libafis_exchange.so; torch = torch.distributed all_gather (host/sharding.py); "
+                    "auto (default) = cpp when there is more than one rank and the backend is nccl (the timed step then contains the repository's own collective), torch otherwise")
     ap.add_argument("--share-gpu", action="store_true", help="test mode: every rank uses GPU 0 (validates the N>1 path on a 1-GPU box)")
     ap.add_argument("--dump-ranks", default="", help="rank 0 writes the merged rank lists of the last step to this .npz (tests)")
     ap.add_argument("--force-dist", action="store_true", help="test mode: initialise torch.distributed and run the exchange step even when WORLD_SIZE is 1")
@@ -283,7 +284,26 @@ def main():
     qh = m.upload_queries(lats)
     t_up = time.perf_counter() - t_up
 
-    xch = SH.CppExchange(gpu) if (a.exchange == "cpp" and use_dist) else None     # rendezvous on MASTER_PORT + 1 (torch's store owns MASTER_PORT)
+    exchange_note = None
+    if a.exchange == "auto" and world > 1 and a.backend == "nccl":
+        # the repository's own collective, unless its rendezvous (one TCP connection per rank on MASTER_PORT + 1 for the ncclUniqueId) fails on ANY rank: then every rank
+        # uses torch.distributed instead (the ranks agree through a MIN all-reduce), and the line says so — the driver's 8-GPU run must not die of a busy port
+        xch, why = None, ""
+        try:
+            xch = SH.CppExchange(gpu)
+        except Exception as e_:                                             # noqa: BLE001
+            why = str(e_)
+        okt = torch.tensor([1 if xch is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 1:
+            a.exchange = "cpp"
+        else:
+            if xch is not None: xch.close()
+            xch = None; a.exchange = "torch"
+            exchange_note = "auto: the C++ exchange could not be set up on every rank (%s); torch.distributed carries the exchange" % (why or "another rank failed")
+    else:
+        if a.exchange == "auto": a.exchange = "torch"
+        xch = SH.CppExchange(gpu) if (a.exchange == "cpp" and use_dist) else None     # rendezvous on MASTER_PORT + 1 (torch's store owns MASTER_PORT)
 
     wall = {"search": 0.0, "exchange": 0.0}                 # host wall time of this rank's two halves of a step (reset after the warm-up)
 
@@ -375,6 +395,26 @@ def main():
         alone = {k_: (v / 2 if (k_.endswith("_ms") or k_.endswith("_ghz")) else v) for k_, v in acc.items()}
         m.set_option("bound_cus", bound_cus_opt)
 
+    # ---- outside the timed region: the OTHER exchange of the path — `match -ldir` writes every score (matcher.cpp:201-204), so each rank contributes its shard's score
+    # columns [Q][shard] (padded to the largest shard: 100 x 12 500 x 4 B = 5 MB per rank at 8 ranks) to one all-gather.  Three exchanges after one warm-up. ----
+    exchange_ldir = None
+    if use_dist:
+        r_ = m.search_resident(qh, k=a.k, want_scores=True)
+        widest = max(hi_ - lo_ for lo_, hi_ in bounds)
+        blk = np.full((Q, widest), -1.0, np.float32); blk[:, :hi - lo] = r_["scores"]
+        def ldir_exchange():
+            if xch is not None: return xch.all_gather(blk)
+            tb = torch.from_numpy(blk).to(dev); outl = [torch.empty_like(tb) for _ in range(world)]
+            dist.all_gather(outl, tb); return torch.stack(outl).cpu().numpy()
+        allb = ldir_exchange(); sync()
+        t_l = time.perf_counter()
+        for _ in range(3): allb = ldir_exchange()
+        t_l = (time.perf_counter() - t_l) / 3
+        full_scores = np.concatenate([allb[r__, :, :bounds[r__][1] - bounds[r__][0]] for r__ in range(world)], axis=1)      # [Q][G]: what rank 0 of `match -ldir` writes
+        ok_top = all(int(np.lexsort((np.arange(G), -full_scores[q_].astype(np.float64)))[0]) == int(idx[q_, 0]) for q_ in range(Q))
+        exchange_ldir = {"ms": round(t_l * 1000.0, 3), "bytes_per_rank": int(blk.nbytes), "what": "one all-gather of the per-shard score columns [Q][largest shard] f32 per rank, as `match -ldir` does (host buffers in, host buffers out: staging copies included)",
+                         "rank1_of_the_gathered_scores_equals_the_rank_lists": bool(ok_top)}
+        sync()
     # ---- outside the timed region: what share of the (latent, non-mate) pairs scores above zero (i.i.d. random templates: none; extracted prints: most) ----
     score_stats = None
     if world == 1 and (a.workload == "structured" or a.score_stats):
@@ -471,7 +511,7 @@ def main():
                        "exchange": ("none (one rank)" if not use_dist else
                                     ("cpp: csrc/rank_exchange.cpp " + ("ncclAllGather (RCCL)" if xch.is_rccl else "TCP stand-in (AFIS_EXCHANGE=tcp)")) if xch is not None
                                     else f"torch: torch.distributed all_gather, backend {a.backend}"),
-                       "adc_variant": variant, "bound_cus": bound_cus, "bound_cus_option": bound_cus_opt,
+                       "exchange_note": exchange_note, "adc_variant": variant, "bound_cus": bound_cus, "bound_cus_option": bound_cus_opt,
                        "schedule": ("bound pass on %d CUs, minutiae stage (candidates + lists) beside it on the other %d, then recomputation + texture lists on the whole chip; stage times overlap: their sum exceeds ms_per_step" % (bound_cus, 256 - bound_cus))
                                    if bound_cus > 0 else
                                    ("one stream, the kernels of a launch group back to back" + (" (the library chose it for this workload: the minutiae stage outweighs the bound pass, option bound_cus %d notwithstanding)" % bound_cus_opt if bound_cus_opt > 0 else "")),
@@ -492,7 +532,7 @@ def main():
             "per_rank_ms_per_step": {"search": {"min": round(float(pr_min[0]), 3), "max": round(float(pr_max[0]), 3)},
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},
                                      "note": "host wall time per rank; a rank that finishes its shard early waits in the exchange for the slowest: min(exchange) is the step's own cost"},
-            "exchange_ms_per_step": round(float(pr_min[1]), 3),
+            "exchange_ms_per_step": round(float(pr_min[1]), 3), "exchange_ldir": exchange_ldir,
             "ranks": ranks_info,
             "distinct_devices": len({(r_["uuid"] or r_["pci_bus_id"]) for r_ in ranks_info}),
             "shared_gpu": bool(a.share_gpu) or len({(r_["uuid"] or r_["pci_bus_id"]) for r_ in ranks_info}) < world,

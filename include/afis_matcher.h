@@ -172,7 +172,8 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q);
  * afis_gallery_load   appends templates [first, first+count) of the file (count < 0: to the end) to the staged gallery.  Into an EMPTY staging
  *                     area (the usual case: one container, or one shard of it per rank) the file is validated and kept mapped, and
  *                     afis_gallery_commit uploads the range straight from the mapping (no host copy of its 50 KB per template): the
- *                     file must not be truncated or rewritten between the two calls.  Any other staging call in between first copies
+ *                     file must not be truncated or rewritten between the two calls (a truncation found at commit time is AFIS_EFORMAT; one that happens WHILE the commit copies from the mapping
+ *                     faults in the host process, as for any mapped file).  Any other staging call in between first copies
  *                     the range into host memory, as every load into a non-empty staging area does.
  * afis_gallery_file_info  template / point totals, and (optional) the texture point count of every template, the quantity shards
  *                     are balanced by.
@@ -221,12 +222,14 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * 9 [default] = an fp16 matrix-core pass over all (latent row, rolled point) cells bounds every row maximum and pins its candidate points; the rows that can
  * reach a pair's top 200 then get the exact fp32 value of their candidates, the table entries recomputed in the reference's arithmetic and order
  * (adc_mfma.hip, adc_refine.hip); 8 = a 16-bit fixed-point LDS-table pass bounds the candidates, which are then evaluated exactly from an fp32 table in HBM/L2
- * (the north_star's LDS-LUT design; 1.6 x the time of 9); 7 = direct exact kernel, conflict-free lane classes, 1024-thread workgroups (2.9 x); 6 = the same with 512;
- * 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — kept as references (4 and 5 were earlier forms of 6/7 and are rejected).
- * "mf_blocks" (form of variant 9's bound pass: 2 [default] / 3 row blocks per wave, 102 = software-pipelined; bit-identical), "bound_cus" (below), "query_batch" (latents per launch group),
+ * (the north_star's LDS-LUT design; 1.6 x the time of 9).  libafis_hip.so (the product) accepts 9 and 8 only; the direct exact kernels of rounds 1-2 — 7 = conflict-free lane classes, 1024-thread
+ * workgroups (2.9 x); 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — are reference kernels built into libafis_hip_test.so only.
+ * "mf_blocks" (form of variant 9's bound pass, bit-identical: 2 = two row blocks per wave, the only value of the product library; libafis_hip_test.so also takes 3), "bound_cus" (below), "query_batch" (latents per launch group),
  * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
  * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded; "search_timeout_ms" sets the same bound in
- * milliseconds.  After such a timeout the device may still be working on the call: the caller's output buffers must stay valid until afis_destroy, or until a later call on the context succeeds), "rowmax_budget_mb" (device memory of a launch group's per-pair
+ * milliseconds; afis_get_option reads "search_timeout_s" rounded UP to whole seconds and "search_timeout_ms" exactly.  After such a timeout the device may still be working on the call: the caller's output
+ * buffers must stay valid until afis_destroy, or until a later call on the context succeeds; afis_queries_free then only parks the handle (its device buffers are released by the next call that finds the device idle),
+ * and afis_destroy — which has to wait for the device — may block where the search did), "rowmax_budget_mb" (device memory of a launch group's per-pair
  * buffers; default 60 % of the free memory), "mf_stats" (adc_variant 9: collect the counters the parity tap afis_debug_refine_stats reads).  ("lut_dtype" accepts only 32: the
  * opt-in 16-bit tolerance path of rounds 1-2 did not meet its stated tolerance and was removed; every remaining path is bit-exact.)
  * Returns AFIS_EINVAL for unknown names. */

@@ -97,6 +97,8 @@ void afis_destroy(afis_ctx* c)
     lap("destroying the side streams");
     for (hipStream_t* ps : {&c->stream_lo, &c->stream_hi}) if (*ps) { (void)hipStreamDestroy(*ps); *ps = nullptr; }
     lap("freeing device memory");
+    for (afis_queries* q : c->parked_queries) { for (QueryGroup& g : q->groups) g.release(); delete q; }     // query groups of a search that timed out (the streams have been waited for above: this destroy may block where that search did)
+    c->parked_queries.clear();
     if (c->h_pin) { (void)hipHostFree(c->h_pin); c->h_pin = nullptr; c->h_pin_bytes = 0; }
     free_gallery_dev(c);
     c->codewords.release(); c->table.release(); c->lut.release(); c->rm_val.release(); c->rm_arg.release(); c->rm_cv.release(); c->rm_n.release();
@@ -132,7 +134,8 @@ int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
     const std::string n(name);
     if (n == "adc_variant") *value = ctx->adc_variant;
     else if (n == "bound_cus") *value = (ctx->stream_lo && !ctx->overlap_failed) ? ctx->bound_cus : 0;
-    else if (n == "search_timeout_s") *value = (int64_t)ctx->search_timeout_s;
+    else if (n == "search_timeout_s") *value = ctx->search_timeout_s <= 0 ? 0 : (int64_t)std::ceil(ctx->search_timeout_s);     // rounded up: a bound set in milliseconds must not read back as 0 = "unbounded"
+    else if (n == "search_timeout_ms") *value = ctx->search_timeout_s <= 0 ? 0 : (int64_t)std::llround(ctx->search_timeout_s * 1e3);
     else if (n == "mf_blocks") *value = ctx->mf_blocks;
     else if (n == "query_batch") *value = ctx->query_batch;
     else if (n == "chunk") *value = ctx->chunk;
@@ -173,6 +176,7 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
         if (value < 0 || value > 224 || (value & 31)) return fail(ctx, AFIS_EINVAL, "bound_cus must be 0 (off), 32, 64, ... 224 (the runtime honours CU masks in steps of 32 CUs: 4 per XCD)");
         if (value > 0 && value + 32 > ctx->n_cus) return fail(ctx, AFIS_EINVAL, "bound_cus must leave at least 32 of the device's CUs to the other stream");
         if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, AFIS_EDEVICE, "bound_cus: hipSetDevice failed");
+        { const int rcd = drain_abandoned(ctx); if (rcd != AFIS_OK) return rcd; }            // a search that timed out may still run on the side streams: bounded wait, not the blocking one below
         for (hipStream_t* ps : {&ctx->stream_lo, &ctx->stream_hi}) if (*ps) { (void)hipStreamSynchronize(*ps); (void)hipStreamDestroy(*ps); *ps = nullptr; }
         ctx->bound_cus = (int)value;
         ctx->overlap_failed = false;

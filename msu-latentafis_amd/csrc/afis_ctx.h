@@ -114,6 +114,7 @@ struct afis_ctx {
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     double search_timeout_s = 600.0;     // bound on every host wait of a search (AFIS_SEARCH_TIMEOUT_S; <= 0: plain hipStreamSynchronize, unbounded)
+    std::vector<afis_queries*> parked_queries;   // query groups a timed-out search may still be reading: freed by drain_abandoned() once the device is back (afis_queries_free parks them here)
     bool search_abandoned = false;       // the last search returned at its deadline: the device may still be working on it (the next search waits for it first)
     bool overlap_failed = false;         // a wait of the overlapped schedule timed out: later searches keep to one stream
     double overlap_cell_ratio = 0.037;   // a launch group runs the overlapped schedule while (latent x rolled minutiae cells) <= this x (latent texture rows x rolled texture points); AFIS_OVERLAP_CELL_RATIO

@@ -421,7 +421,8 @@ static int commit_shard(afis_ctx* ctx, int64_t index_base)
     const uint8_t* s_empty = gm ? gm->empty + ctx->pend_first : hg.empty.data();
     if (G > 0x7fffffff / 8 || NM > 0x7fffffffull || NT > 0x7fffffffull)
         return fail(ctx, AFIS_EINVAL, "afis_gallery_commit: shard too large for 32-bit point offsets; split the gallery into more shards");
-    if (gm && gm->fd_ >= 0) {                                               // the arrays are read straight from the mapping, by several threads: a file truncated since afis_gallery_load would fault
+    if (gm && gm->fd_ >= 0) {                                               // the arrays are read straight from the mapping, by several threads: a file truncated since afis_gallery_load would fault.  This check catches a truncation that
+                                                                            // happened BEFORE the commit; one that happens while the copy below runs still faults (SIGBUS): a container must not be modified while a context has it loaded (include/afis_matcher.h says so)
         struct stat st;
         if (fstat(gm->fd_, &st) != 0 || (size_t)st.st_size < gm->len_) return fail(ctx, AFIS_EFORMAT, "gallery container: " + gm->path + " was truncated after it was loaded");
     }

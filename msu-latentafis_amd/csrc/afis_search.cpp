@@ -66,7 +66,13 @@ int drain_abandoned(afis_ctx* ctx)
 {
     if (!ctx->search_abandoned) return AFIS_OK;
     ctx->search_abandoned = false;
-    return wait_streams(ctx, {ctx->stream_lo, ctx->stream_hi, ctx->stream}, "waiting for the search that timed out");   // (a second timeout sets the flag again)
+    const int rc = wait_streams(ctx, {ctx->stream_lo, ctx->stream_hi, ctx->stream}, "waiting for the search that timed out");   // (a second timeout sets the flag again)
+    if (rc != AFIS_OK) return rc;
+    // the device is idle: the query groups the abandoned search was still reading can go now (freeing them at its deadline would have been a hipFree under running
+    // kernels — or an unbounded implicit device synchronisation, the very wait the deadline exists to avoid)
+    for (afis_queries* q : ctx->parked_queries) { for (QueryGroup& g : q->groups) g.release(); delete q; }
+    ctx->parked_queries.clear();
+    return AFIS_OK;
 }
 
 // Work queued on the side streams must not outlive a failing search (it reads and writes the context's buffers): armed when the first kernel goes to a side stream,
@@ -76,7 +82,17 @@ struct SideStreamGuard {
     explicit SideStreamGuard(afis_ctx* c) : ctx(c) {}
     void arm(hipStream_t x, hipStream_t y) { a = x; b = y; armed = true; }
     void disarm() { armed = false; }
-    ~SideStreamGuard() { if (armed) { const std::string keep = ctx->err; (void)wait_streams(ctx, {a, b}, "draining the side streams after a failed launch group"); ctx->err = keep; } }
+    // (its own short bound — the launch error is what the caller must see, not a second full deadline — and the drain's outcome appended to the message)
+    ~SideStreamGuard()
+    {
+        if (!armed) return;
+        const std::string keep = ctx->err;
+        const double full = ctx->search_timeout_s;
+        if (full > 0) ctx->search_timeout_s = std::min(full, 10.0);
+        const int rc = wait_streams(ctx, {a, b}, "draining the side streams after a failed launch group");
+        ctx->search_timeout_s = full;
+        ctx->err = rc == AFIS_OK ? keep : keep + " [and the side streams did not drain within 10 s: " + ctx->err + "]";
+    }
 };
 
 }  // namespace afis
@@ -202,6 +218,7 @@ void afis_queries_free(afis_ctx* ctx, afis_queries* q)
 {
     if (!q) return;
     if (ctx) (void)hipSetDevice(ctx->device);
+    if (ctx && ctx->search_abandoned) { ctx->parked_queries.push_back(q); return; }     // a search that left at its deadline may still read these buffers: freed once the device is back (drain_abandoned / afis_destroy)
     for (QueryGroup& g : q->groups) g.release();
     delete q;
 }
@@ -705,7 +722,9 @@ int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, flo
             parts.resize((size_t)nq * G * 4);
             rc = afis_search_resident(ctx, &q, nullptr, parts.data(), nullptr, 0, nullptr, nullptr);
         }
-        q.groups.back().release();
+        if (ctx->search_abandoned) {                                        // timed out: the kernels may still read the group — park it (see afis_queries_free)
+            afis_queries* keep = new afis_queries; keep->groups.swap(q.groups); ctx->parked_queries.push_back(keep);
+        } else q.groups.back().release();
         if (rc != AFIS_OK) return rc;
         for (int j = 0; j < nq; ++j)
             for (int64_t g = 0; g < G; ++g) {

@@ -21,7 +21,7 @@ This generator reproduces that structure:
     encode(latent descriptor + noise)); its own cells everywhere else.  Coordinates stay unique.
 
 Everything depends only on (seed, template index), as in synth.py; a block of templates is generated with a few vectorised numpy calls.  `encode` lets the caller
-supply the nearest-codeword encoder (the GPU's afis_pq_encode for 10^8 points; Codebook.encode on the CPU).
+supply the nearest-codeword encoder (the GPU's afis_pq_encode for 10^8 points; Codebook.encode_fast on the CPU).
 """
 from __future__ import annotations
 
@@ -150,7 +150,7 @@ def make_packed_gallery_structured(seed: int, G: int, cb: Codebook, lo: int = 0,
                                    encode: Optional[Callable[[np.ndarray], np.ndarray]] = None, device=None, **count_kw) -> PackedGallery:
     """Templates [lo, hi) of a structured G-template gallery (same counts as synth.make_packed_gallery with the same seed and count arguments)."""
     hi = G if hi is None else hi
-    encode = encode or cb.encode
+    encode = encode or cb.encode_fast
     nm_all, nt_all = gallery_counts(seed, G, **count_kw)
     nm, nt = nm_all[lo:hi], nt_all[lo:hi]
     mo = np.concatenate([[0], np.cumsum(nm)]); to = np.concatenate([[0], np.cumsum(nt)])
@@ -209,7 +209,7 @@ def make_structured_rolled(rng: np.random.Generator, cb: Codebook, n_minu: Optio
     cx = (cell % BLK_W).astype(np.int16); cy = (cell // BLK_W).astype(np.int16)
     zero = np.zeros(len(cell), np.int64)
     t = FPTemplate()
-    codes = cb.encode(_descriptors(coef, zero, cx, cy, sigma, rng)) if n_tex else np.zeros((0, cb.M), np.uint8)
+    codes = cb.encode_fast(_descriptors(coef, zero, cx, cy, sigma, rng)) if n_tex else np.zeros((0, cb.M), np.uint8)
     px, py = _minutiae_in_blob(rng, cell if len(cell) else np.arange(BLK_W * BLK_H), n_minu)
     fx = (px.astype(np.float32) - 24) / 16; fy = (py.astype(np.float32) - 24) / 16
     mo = -flow_direction(fp[0], fx, fy) + np.float32(np.pi) * rng.integers(0, 2, n_minu).astype(np.float32)
@@ -277,7 +277,7 @@ def make_structured_mate(rng: np.random.Generator, cb: Codebook, latent: FPTempl
     if both:
         ri = np.array([a for a, _ in both]); li = np.array([b for _, b in both])
         rt.ori[ri] = lt.ori[li]
-        rt.codes[ri] = cb.encode(lt.des[li] + rng.standard_normal((len(li), 96)).astype(np.float32) * (noise * 0.5))
+        rt.codes[ri] = cb.encode_fast(lt.des[li] + rng.standard_normal((len(li), 96)).astype(np.float32) * (noise * 0.5))
     return t
 
 

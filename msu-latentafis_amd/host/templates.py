@@ -71,6 +71,19 @@ class Codebook:
             codes[:, m] = d.argmin(1)
         return codes
 
+    def encode_fast(self, des: np.ndarray) -> np.ndarray:
+        """Nearest codeword per sub-space through |c|^2 - 2 x.c in float32 (one GEMM per sub-space): for GENERATORS of synthetic templates, where a different choice between
+        two all but equidistant codewords does not matter; `encode` is the reference's routine."""
+        des = np.asarray(des, dtype=np.float32)
+        codes = np.empty((des.shape[0], self.M), dtype=np.uint8)
+        for m in range(self.M):
+            w = self.words[m]
+            c2 = np.einsum("kd,kd->k", w, w)
+            for a in range(0, des.shape[0], 1 << 16):
+                x = des[a:a + (1 << 16), m * self.dsub:(m + 1) * self.dsub]
+                codes[a:a + (1 << 16), m] = (c2[None, :] - 2.0 * (x @ w.T)).argmin(1)
+        return codes
+
     @staticmethod
     def synthetic(seed: int = 0, M: int = 16, K: int = 256, dsub: int = 6) -> "Codebook":
         """Random codebook with the shipped file's statistics (values ~N(0, 0.164))."""
