@@ -32,11 +32,16 @@ import numpy as np
 from .synth import BLK_H, BLK_W, GEN_BLOCK, IMG_H, IMG_W, MATE_FRACS, PackedGallery, _unit, gallery_counts, mate_slots
 from .templates import DESCRIPTOR_NORM, Codebook, FPTemplate, MinutiaeTemplate, TextureTemplate
 
+# Weight of the field's constant term — what all descriptors of ONE print have in common — against 1/2, 1/3 ... for the orders of its variation over the print.  At 1.0 two prints
+# whose constant terms point away from each other have almost only NEGATIVE descriptor products: 8 % of the (latent, rolled) minutiae pairs then keep fewer than 120 positive
+# similarities after the clamp of matcher.cpp:447-451, and their candidate lists are filled up with zero entries (whose order is the sort's tie order: tools/tie_site_sweep.py).
+# A patch descriptor describes local ridge structure, not the finger: 0.3 (0.15 % such pairs) is the named workload; tests also run 1.0 for the sake of that path.
+IDENTITY_WEIGHT = 0.3
 MANIFOLD_DIMS = 12                       # D: dimensions of the descriptor manifold all templates share
 N_BASIS = 9                              # cosine basis functions of the per-template field: orders (0..2) x (0..2)
 # descriptor noise that leaves about this share of a rolled template's points with a code vector some other point of the template also has
 # (calibrated at the headline's template sizes with the shipped codebook: tools/structured_calibrate.py)
-DUP_SIGMA = {0: 0.030, 10: 0.0095, 30: 0.0057}
+DUP_SIGMA = {0: 0.030, 10: 0.0066, 30: 0.0017}
 
 
 def _network() -> np.ndarray:
@@ -59,7 +64,9 @@ def _field_coeffs(rng: np.random.Generator, n: int) -> np.ndarray:
     """[n, D, N_BASIS] coefficients of n templates' fields: the constant term carries a print's identity, the higher orders its variation over the print."""
     a = rng.standard_normal((n, MANIFOLD_DIMS, N_BASIS)).astype(np.float32)
     order = np.array([a_ + b_ for a_ in range(3) for b_ in range(3)], np.float32)
-    return a * (np.float32(1.0) / (np.float32(1.0) + order))[None, None, :]
+    w = np.float32(1.0) / (np.float32(1.0) + order)
+    w[0] = np.float32(IDENTITY_WEIGHT)
+    return a * w[None, None, :]
 
 
 def _flow_params(rng: np.random.Generator, n: int) -> np.ndarray:

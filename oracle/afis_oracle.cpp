@@ -82,10 +82,16 @@ struct Codebook {         // matcher.cpp:31-94
 typedef std::tuple<float, int, int> Corr;  // (similarity, latent idx, rolled idx)
 
 // ---- sorting helper -------------------------------------------------------------------------
+// site: which of the reference's sorts this is — 1 = S3 (:476), 2 = S7 (:741), 4 = S8's selection (:1301, :1423), 8 = S9's (:1590).  Tie modes 2..5 take the
+// reference's std::sort at SOME sites and the stable order at the others (2: S9; 3: S8 + S9; 4: S3; 5: S7): they exist to measure which site's tie order moves scores
+// (tools/tie_site_sweep.py), not as an order anything implements.
+enum { kSiteS3 = 1, kSiteS7 = 2, kSiteS8 = 4, kSiteS9 = 8 };
 template <class Cmp>
-void sort_idx(std::vector<int>& y, Cmp cmp, int tie_mode)
+void sort_idx(std::vector<int>& y, Cmp cmp, int tie_mode, int site)
 {
-    if ((tie_mode & 15) == 0) std::sort(y.begin(), y.end(), cmp);
+    const int t = tie_mode & 15;
+    const int unstable_sites = t == 0 ? 15 : t == 2 ? kSiteS9 : t == 3 ? (kSiteS8 | kSiteS9) : t == 4 ? kSiteS3 : t == 5 ? kSiteS7 : 0;
+    if (unstable_sites & site) std::sort(y.begin(), y.end(), cmp);
     else std::stable_sort(y.begin(), y.end(), cmp);
 }
 
@@ -346,12 +352,12 @@ static inline float adjust_angle(float angle)
 // true (S9); `s_thr` is 0.0001 (S8) or 0.001 (S9), compared in double.
 template <class Compat>
 std::vector<Corr> greedy_select(const std::vector<Corr>& corr, const std::vector<float>& S, int nL, int nR,
-                                double s_thr, Compat compatible, int tie_mode)
+                                double s_thr, Compat compatible, int tie_mode, int site)
 {
     int num = (int)corr.size();
     std::vector<int> y(num);
     std::iota(y.begin(), y.end(), 0);
-    sort_idx(y, [&S](int a, int b) { return S[a] > S[b]; }, tie_mode);
+    sort_idx(y, [&S](int a, int b) { return S[a] > S[b]; }, tie_mode, site);
     std::vector<short> flag_latent(nL, 0), flag_rolled(nR, 0);
     std::vector<Corr> out; std::vector<int> sel;
     for (int i = 0; i < num; ++i) {
@@ -425,7 +431,7 @@ std::vector<Corr> dist_filter(const std::vector<Corr>& corr, const std::vector<P
         for (int j = 0; j < num; ++j) b[j] = c[j] * scale;
     }
     auto compat = [&H, num](int a, int bb) { return !((double)H[(size_t)a * num + bb] < 0.00001); };
-    return greedy_select(corr, b, (int)Lp.size(), (int)Rp.size(), 0.0001, compat, tie_mode);
+    return greedy_select(corr, b, (int)Lp.size(), (int)Rp.size(), 0.0001, compat, tie_mode, kSiteS8);
 }
 
 // ---- S9: angle-consistency graph -----------------------------------------------------------------------------
@@ -481,7 +487,7 @@ std::vector<Corr> angle_filter(const std::vector<Corr>& corr, const std::vector<
         for (int j = 0; j < num; ++j) S[j] = S1[j] * sum;
     }
     auto compat = [&H, num](int a, int b) { return H[(size_t)a * num + b] != 0; };
-    return greedy_select(corr, S, (int)Lp.size(), (int)Rp.size(), 0.001, compat, tie_mode);
+    return greedy_select(corr, S, (int)Lp.size(), (int)Rp.size(), 0.001, compat, tie_mode, kSiteS9);
 }
 
 static float sum_scores(const std::vector<Corr>& c)   // :508-514, :775-781
@@ -525,7 +531,7 @@ float minutiae_score(const MinuTpl& L, const MinuTpl& R, const Codebook& cb, int
     // S3 (:473-488)
     std::vector<int> y((size_t)nL * nR);
     std::iota(y.begin(), y.end(), 0);
-    sort_idx(y, [&norm](int a, int b) { return norm[a] > norm[b]; }, tie_mode);
+    sort_idx(y, [&norm](int a, int b) { return norm[a] > norm[b]; }, tie_mode, kSiteS3);
     int topN = 120;
     if (nR * nL < topN) topN = nR * nL;
     std::vector<Corr> corr;
@@ -569,7 +575,7 @@ float texture_score(const LatTexTpl& L, const RolTexTpl& R, const Codebook& cb, 
     if ((int)tmp.size() > cb.N) {                                         // :736-747
         std::vector<int> y(tmp.size());
         std::iota(y.begin(), y.end(), 0);
-        sort_idx(y, [&tmp](int a, int b) { return std::get<0>(tmp[a]) > std::get<0>(tmp[b]); }, tie_mode);
+        sort_idx(y, [&tmp](int a, int b) { return std::get<0>(tmp[a]) > std::get<0>(tmp[b]); }, tie_mode, kSiteS7);
         corr.resize(cb.N);
         for (int i = 0; i < cb.N; ++i) corr[i] = tmp[y[i]];
     } else corr = tmp;                                                     // :748-749

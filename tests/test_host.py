@@ -447,6 +447,12 @@ def test_structured_generator_has_the_structure_it_claims(cb):
     assert n_smooth > 0.97 * n_nb                                                   # smooth but for the few blocks next to a singular point
     share = {d: SS.dup_share(*(lambda gl: (gl.tex_codes, gl.tex_off))(SS.make_packed_gallery_structured(6, 64, cb, sigma=SS.DUP_SIGMA[d]))) for d in (0, 10, 30)}
     assert share[0] < 0.01 and 0.05 < share[10] < 0.16 and 0.22 < share[30] < 0.40, share
+    few = 0                                                                         # (latent, rolled) minutiae pairs that keep fewer than 120 positive similarities: rare at the named identity weight
+    Lm = SS.make_structured_latent(np.random.default_rng(8)).minu[26]
+    for g in range(300):
+        a_, b_ = int(full.minu_off[g]), int(full.minu_off[g + 1])
+        few += int(((Lm.des @ full.minu_des[a_:b_].T) > 0).sum() < 120)
+    assert few <= 6, few
     same = (full.tex_y[1:] == full.tex_y[:-1]) & (full.tex_x[1:] == full.tex_x[:-1] + 1)
     assert (full.tex_codes[1:] == full.tex_codes[:-1]).sum(1)[same].mean() > 9      # of 16 codes, with the right-hand neighbour
     L = SS.make_structured_latent(np.random.default_rng(3))
