@@ -611,8 +611,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                             const uint32_t key = approx_norm_key(sv[u], rs[u], cs) & (uint32_t)-(int)(tb + u < my_rows);   // (a mask, not a select: the compiler turns the select into a branch region)
                             rk[tb + u] = key;
                             const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
-                            const bool cnt0 = bin <= 0 && (key & 0x7fffffffu) != 0u;                // a positive norm below 2^-15: counted in bin 0 (never a threshold bin; it decides whether a list short of 120 positive keys can be filled up here)
-                            atomicAdd((bin > 0 || cnt0) ? &sm.hist[max(bin, 0)] : &sm.sink[lane], 1u);  // zero similarities and absent rows are not counted
+                            atomicAdd(bin > 0 ? &sm.hist[bin] : &sm.sink[lane], 1u);  // zero similarities, norms < 2^-15 and absent rows are not counted
                         }
                         a += 4 * a_step; i += 4 * R;
                     }
@@ -622,7 +621,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                         if (t < my_rows) {
                             const uint32_t key = approx_norm_key(sm.simi[a], sm.rowsum[i], cs);
                             const int bin = min((int)((key >> 19) & 0xfffu) - kBinBase, kSelBins - 1);
-                            if (bin > 0 || (key & 0x7fffffffu) != 0u) atomicAdd(&sm.hist[max(bin, 0)], 1u);
+                            if (bin > 0) atomicAdd(&sm.hist[bin], 1u);
                         }
                         a += R * ld; i += R;
                     }
@@ -641,7 +640,6 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 const int r1 = __builtin_amdgcn_readlane(suf, 16), r2 = __builtin_amdgcn_readlane(suf, 32), r3 = __builtin_amdgcn_readlane(suf, 48);   // ... and the totals of the rows above
                 suf += lane < 16 ? r1 + r2 + r3 : lane < 32 ? r2 + r3 : lane < 48 ? r3 : 0;
                 const int a3 = suf - s0, a2 = a3 + (int)h.w, a1 = a2 + (int)h.z, a0 = a1 + (int)h.y;     // entries in the bins ABOVE each of the four
-                if (lane == 0) sm.pad_[0] = (int)h.x;                                // positive norms below 2^-15
                 if (a3 < kTopMinu && a3 + (int)h.w >= kTopMinu) sm.thr_bin = 4 * lane + 3;
                 if (a2 < kTopMinu && a2 + (int)h.z >= kTopMinu) sm.thr_bin = 4 * lane + 2;
                 if (a1 < kTopMinu && a1 + (int)h.y >= kTopMinu) sm.thr_bin = 4 * lane + 1;
@@ -654,7 +652,25 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             // Fewer than 120 positive norms, every one of them at least 2^-15 (a latent and a rolled print whose descriptors point away from each other: nearly every similarity is
             // clamped to zero, matcher.cpp:447-451 — 8 % of the pairs of bench.py --workload structured, which the any-shape kernel did at 30 x the time): the positive entries are all
             // candidates and are ranked as always; the rest of the 120 are zero entries, which tie, in ascending element order (tie rule) — filled in below.
-            const bool fill = Braw < 0 && __builtin_amdgcn_readfirstlane(sm.pad_[0]) == 0;
+            bool fill = false;
+            if (Braw < 0) {                                                          // uniform, rare: are there positive norms below 2^-15 (uncounted, bin <= 0)?  Looked for only here — the histogram pass pays nothing for it
+                if (tid == 0) sm.pad_[0] = 0;
+                RT_SYNC();
+                bool tiny = false;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) tiny |= (rk[t] & 0x7fffffffu) != 0u && (int)((rk[t] >> 19) & 0xfffu) - kBinBase <= 0;
+                if (S == 4 && n_rows > 32) {
+                    const float cs2 = sm.colsum[cj];
+                    for (int t = 32; t < my_rows; ++t) {
+                        const int i = cr + R * t;
+                        const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs2);
+                        tiny |= (key & 0x7fffffffu) != 0u && (int)((key >> 19) & 0xfffu) - kBinBase <= 0;
+                    }
+                }
+                if (tiny) sm.pad_[0] = 1;
+                RT_SYNC();
+                fill = __builtin_amdgcn_readfirstlane(sm.pad_[0]) == 0;
+            }
             if (Braw < 2 && !fill) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // a threshold in or next to bin 0, or tiny positive norms among fewer than 120
             const int B = fill ? 0 : Braw;
             // ---- a crowded threshold bin: a second histogram inside it ----
