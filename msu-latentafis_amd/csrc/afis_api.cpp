@@ -45,6 +45,7 @@ int afis_create(afis_ctx** out, const float* codewords, int M, int K, int dsub, 
     CRCHK(hipStreamSynchronize(c->stream));
 #undef CRCHK
     *out = c;
+    register_context(c);
     // The default schedule: the power-limited bound pass on half of the chip's CUs, the minutiae stage beside it on the other half (afis_search_resident; -7.6 % per step at 100k
     // templates, profiles/r04_overlap_ab.json).  AFIS_BOUND_CUS overrides (0 = one stream, the kernels back to back).  A runtime that refuses CU masks leaves it off.
     {
@@ -85,6 +86,7 @@ int afis_create_from_codebook(afis_ctx** out, const void* bytes, size_t len, int
 void afis_destroy(afis_ctx* c)
 {
     if (!c) return;
+    unregister_context(c);
     (void)hipSetDevice(c->device);
     static const bool trace = getenv("AFIS_DESTROY_TRACE") != nullptr;       // development aid: where a destroy spends its time, on stderr
     auto lap = [&](const char* what) { if (trace) { fprintf(stderr, "afis_destroy: %s\n", what); fflush(stderr); } };

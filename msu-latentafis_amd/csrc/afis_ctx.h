@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <numeric>
 #include <string>
@@ -114,6 +115,7 @@ struct afis_ctx {
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     double search_timeout_s = 600.0;     // bound on every host wait of a search (AFIS_SEARCH_TIMEOUT_S; <= 0: plain hipStreamSynchronize, unbounded)
+    int64_t planned_group_bytes = 0;     // per-group buffers the largest launch group uploaded so far will take (group_budget_bytes of OTHER contexts on the device leaves room for it)
     std::vector<afis_queries*> parked_queries;   // query groups a timed-out search may still be reading: freed by drain_abandoned() once the device is back (afis_queries_free parks them here)
     bool search_abandoned = false;       // the last search returned at its deadline: the device may still be working on it (the next search waits for it first)
     bool overlap_failed = false;         // a wait of the overlapped schedule timed out: later searches keep to one stream
@@ -202,6 +204,7 @@ int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t aft
 int ensure_codes_cf(afis_ctx* ctx, int variant);       // the direct kernels' lane-ordered code stream (adc_variant 6 / 7), laid out at first use
 #endif
 int wait_streams(afis_ctx* ctx, std::initializer_list<hipStream_t> streams, const char* what);
+void register_context(afis_ctx* ctx); void unregister_context(afis_ctx* ctx);   // the process-wide list group_budget_bytes consults
 int drain_abandoned(afis_ctx* ctx);                     // waits (bounded) for a search that returned at its deadline
 
 }  // namespace afis

@@ -14,15 +14,40 @@ int64_t group_bytes_per_query(const afis_ctx* ctx, int64_t G)
     const int64_t per_pair = (int64_t)kTexMax * 8 + (ctx->adc_variant == 9 ? (int64_t)kTexMax * kMfRecBytesPerRow : 0) + 3 * (int64_t)kTopMinu * (int64_t)sizeof(MinuCand) + 3 * 4 + 16 + 8;
     return std::max<int64_t>(1, G) * per_pair;
 }
+// ... and what a group of nq latents with rows_total latent texture rows, the longest of them lt_max, really takes (round 6: the buffers are sized by this, not by the worst case —
+// the bench's latents have 671 rows on average, and the records of a 50-latent group at a 100k-template shard are 27 GB instead of 40)
+int64_t group_bytes_actual(const afis_ctx* ctx, int64_t G, int64_t nq, int64_t rows_total, int64_t lt_max)
+{
+    const int64_t lt_pad = std::max<int64_t>(kTileRows, (lt_max + kTileRows - 1) / kTileRows * kTileRows), R_pad = (rows_total + 31) / 32 * 32;
+    const int64_t per_pair = lt_pad * 8 + 3 * (int64_t)kTopMinu * (int64_t)sizeof(MinuCand) + 3 * 4 + 16 + 8;
+    return std::max<int64_t>(1, G) * (nq * per_pair + (ctx->adc_variant == 9 ? R_pad * kMfRecBytesPerRow : 0));
+}
 
-// What a launch group may take: the option, or 60 % of the free device memory (buffers this context already holds for earlier groups are reused, so they count as free).
+// Contexts of this process, per device: what each of them holds in per-group buffers and what it has PLANNED to hold (its largest uploaded launch group) — a context that
+// uploads its queries sees the free memory of the moment, and several contexts on one device each took 60 % of it before any of them had allocated a byte (round-4 advisor item).
+namespace { std::mutex g_ctx_mutex; std::vector<afis_ctx*> g_ctx_live; }
+static size_t held_group_bytes(const afis_ctx* c)
+{
+    return c->rm_val.bytes + c->rm_arg.bytes + c->rm_cv.bytes + c->rm_n.bytes + c->mf_rec.bytes + c->cands.bytes + c->cand_n.bytes + c->parts.bytes + c->minu_fb.bytes;
+}
+void register_context(afis_ctx* c) { std::lock_guard<std::mutex> lk(g_ctx_mutex); g_ctx_live.push_back(c); }
+void unregister_context(afis_ctx* c) { std::lock_guard<std::mutex> lk(g_ctx_mutex); g_ctx_live.erase(std::remove(g_ctx_live.begin(), g_ctx_live.end(), c), g_ctx_live.end()); }
+
+// What a launch group may take: the option, or 60 % of the free device memory (buffers this context already holds for earlier groups are reused, so they count as free;
+// what OTHER contexts of the process on this device have planned but not yet allocated does not).
 int64_t group_budget_bytes(const afis_ctx* ctx)
 {
     if (ctx->rowmax_budget_bytes > 0) return ctx->rowmax_budget_bytes;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 36ll << 30;
-    const size_t held = ctx->rm_val.bytes + ctx->rm_arg.bytes + ctx->rm_cv.bytes + ctx->rm_n.bytes + ctx->mf_rec.bytes + ctx->cands.bytes + ctx->cand_n.bytes + ctx->parts.bytes + ctx->minu_fb.bytes;
-    return std::max<int64_t>(1ll << 30, (int64_t)((double)(free_b + held) * 0.6));
+    int64_t pending_elsewhere = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        for (const afis_ctx* c : g_ctx_live)
+            if (c != ctx && c->device == ctx->device) pending_elsewhere += std::max<int64_t>(0, c->planned_group_bytes - (int64_t)held_group_bytes(c));
+    }
+    const int64_t avail = (int64_t)free_b + (int64_t)held_group_bytes(ctx) - pending_elsewhere;
+    return std::max<int64_t>(1ll << 30, (int64_t)((double)std::max<int64_t>(0, avail) * 0.6));
 }
 
 // Host wait for streams with a deadline: hipStreamQuery on each of them in turn (which also keeps every one of them submitting: with ROCm 7.2 a blocking hipStreamSynchronize
@@ -191,6 +216,7 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     int per = (int)std::max<int64_t>(1, std::min<int64_t>(want, by_mem));
     afis_queries* q = new afis_queries();
     q->n_q = n_q;
+    const int64_t budget = group_budget_bytes(ctx);
     // Launch groups are contiguous runs of at most `per` queries; with the matrix-core bound pass (adc_variant 9) the cuts are placed where its row groups of 768 latent
     // texture rows are fewest (launch_group_cuts, afis_device.h; tests/test_host.py checks the rule on the CPU).  Results do not depend on the cuts.
     std::vector<long long> rows((size_t)n_q + 1, 0);
@@ -201,7 +227,23 @@ int afis_queries_upload(afis_ctx* ctx, const afis_template_view* queries, int n_
     }
     std::vector<int> cuts((size_t)std::max(n_q, 1));                        // group ends (exclusive)
     int n_cuts = 0;
-    launch_group_cuts(rows.data(), n_q, per, ctx->adc_variant == 9, cuts.data(), &n_cuts);
+    // `per` so far is what the budget allows if every latent had 1000 texture rows.  The latents are known here: when that worst case is what limits the group, larger groups are tried
+    // against what they would REALLY take (group_bytes_actual), largest first.
+    auto largest_group_bytes = [&](int n) {
+        int64_t worst = 0; int a0 = 0;
+        for (int c = 0; c < n; ++c) {
+            int64_t lt_max = 0;
+            for (int i = a0; i < cuts[(size_t)c]; ++i) lt_max = std::max<int64_t>(lt_max, rows[(size_t)i + 1] - rows[(size_t)i]);
+            worst = std::max(worst, group_bytes_actual(ctx, G, cuts[(size_t)c] - a0, rows[(size_t)cuts[(size_t)c]] - rows[(size_t)a0], lt_max));
+            a0 = cuts[(size_t)c];
+        }
+        return worst;
+    };
+    for (int try_per = (int)std::max<int64_t>(per, std::min<int64_t>(want, std::max(n_q, 1)));; --try_per) {
+        launch_group_cuts(rows.data(), n_q, try_per, ctx->adc_variant == 9, cuts.data(), &n_cuts);
+        if (try_per <= per || largest_group_bytes(n_cuts) <= budget) { per = try_per; break; }
+    }
+    ctx->planned_group_bytes = std::max(ctx->planned_group_bytes, largest_group_bytes(n_cuts));
     cuts.resize((size_t)n_cuts);
     int g0 = 0;
     for (int end : cuts) {
@@ -302,9 +344,9 @@ int adc_stage_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, hipEvent_t aft
     if (grp.n_lt_rows <= 0 || g.G <= 0) { if (after_lut) HIPCHK(ctx, hipEventRecord(after_lut, s)); if (after_bound) HIPCHK(ctx, hipEventRecord(after_bound, s)); return AFIS_OK; }
     { int rcg = ensure_mf_gallery(ctx, s); if (rcg != AFIS_OK) return rcg; }
     const int n_rows = grp.n_lt_rows, n_rb = (n_rows + 31) / 32, R_pad = n_rb * 32;
-    // The per-row buffers are sized for the group's WORST case (every latent with kTexMax rows), as afis_search_resident has already done before queuing anything: these
-    // calls find them large enough (a hipMalloc behind queued work was seen to take 0.5-0.8 s; see there).  Callers outside a search (the parity taps) allocate here.
-    const size_t R_cap = std::max<size_t>((size_t)R_pad, ((size_t)grp.nq * kTexMax + 31) / 32 * 32);
+    // The per-row buffers have been brought to the size of the search's LARGEST group by afis_search_resident before it queued anything: these calls find them large enough
+    // (a hipMalloc behind queued work was seen to take 0.5-0.8 s; see there).  Callers outside a search (the parity taps) allocate here.
+    const size_t R_cap = (size_t)R_pad;                                 // the group's own rows (afis_search_resident has brought the buffers to the largest group of the search)
     HIPCHK(ctx, ctx->mf_bfrag.ensure(R_cap / 32 * 6 * 64 * 16));
     HIPCHK(ctx, ctx->mf_rowk.ensure(R_cap * 16));
     HIPCHK(ctx, ctx->mf_rec.ensure((size_t)g.G * R_cap * kMfRecBytesPerRow));
@@ -338,6 +380,94 @@ int adc_refine_mfma(afis_ctx* ctx, QueryGroup& grp, bool all_rows, bool compact)
 // Rank lists are made on the device for k <= kDeviceTopK (k passes of a workgroup-wide maximum per query); larger k sorts on the host.
 static const int kDeviceTopK = 64;
 
+// (1 of 3) Every buffer of the launch groups, brought to its size while the device is idle and before anything of the search is queued.
+static int prepare_search_buffers(afis_ctx* ctx, const afis_queries* q, bool want_parts)
+{
+    const int64_t G = ctx->gal.G;
+    const int nq_all = q->n_q;
+    float* const parts = want_parts ? reinterpret_cast<float*>(1) : nullptr;     // (only its being asked for matters here)
+    // Every buffer of the launch groups is brought to its size HERE, while the device is idle and before anything of this search is queued: for the largest group of
+    // the search (round 6: for what that group really takes — its own texture rows — not for the worst case of 1000 rows per latent), so that the calls further down never
+    // re-allocate.  A hipMalloc of 6-13 GB takes 0.3 ms on an idle device; issued behind queued work (the row records used to be allocated inside adc_stage_mfma, after
+    // the group's first kernels) it took 510-790 ms in three runs of ten (match -ldir: one search call in seven; profiles/r04_alloc_trace.txt).
+    if (G > 0) {
+        int nq_max = 0, nL_max = 1; size_t rows_pad_max = 32, pair_rows_max = 0;
+        for (const QueryGroup& grp : q->groups) {
+            nq_max = std::max(nq_max, grp.nq); nL_max = std::max(nL_max, grp.max_nL);
+            rows_pad_max = std::max(rows_pad_max, ((size_t)std::max(grp.n_lt_rows, 0) + 31) / 32 * 32);
+            pair_rows_max = std::max(pair_rows_max, (size_t)grp.nq * (size_t)grp.dev.lt_pad);          // a group's row-maximum arrays: [pair][lt_pad]
+        }
+        const size_t n_pairs = (size_t)nq_max * G;
+        if (n_pairs > 0) {
+            const size_t rm_bytes = std::max<size_t>(pair_rows_max * (size_t)G * 4, 16);
+            if (ctx->adc_variant != 9) HIPCHK(ctx, ctx->rm_val.ensure(rm_bytes));      // variant 9: the values live in the compact list (rm_cv) only
+            HIPCHK(ctx, ctx->rm_arg.ensure(rm_bytes));
+            HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));   // per-part scores on request: every group's block stays on the device until the search is done
+            HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
+            HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
+            HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
+            {   // the generic candidate kernel's scratch (sized as in the loop below, for the longest latent minutiae template of the search)
+                const size_t per_wg = 2 * (((size_t)nL_max * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+                int n_wg = 1024;
+                while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
+                HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
+            }
+            if (ctx->adc_variant == 9) {
+                HIPCHK(ctx, ctx->rm_cv.ensure(rm_bytes)); HIPCHK(ctx, ctx->rm_n.ensure(n_pairs * 4));
+                const size_t R_cap = rows_pad_max;
+                HIPCHK(ctx, ctx->mf_bfrag.ensure(R_cap / 32 * 6 * 64 * 16));
+                HIPCHK(ctx, ctx->mf_rowk.ensure(R_cap * 16));
+                HIPCHK(ctx, ctx->mf_rec.ensure((size_t)G * R_cap * kMfRecBytesPerRow));
+                if (!ctx->mf_gal_built) {                                  // first search: the bound pass's copy of the gallery codes (adc_stage_mfma fills it)
+                    const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
+                    HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
+                    HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
+                    HIPCHK(ctx, ctx->g_tile_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
+                }
+            }
+        }
+    }
+    return AFIS_OK;
+}
+
+// (3 of 3) What the search's events and diagnostics rows say: where the candidate tasks went, the clocks the sampled workgroups saw, the stage times per launch group.
+static int collect_timing(afis_ctx* ctx, const afis_queries* q, afis_timing& tm, bool dev_topk, hipEvent_t* evk)
+{
+    const int64_t G = ctx->gal.G;
+    const size_t n_groups = q->groups.size();
+    {   // where the candidate tasks went, and the clocks the sampled workgroups saw (shader cycles per tick of the constant 100 MHz counter)
+        unsigned long long acc[kDiagWords] = {};
+        for (size_t i = 0; i < n_groups; ++i) for (int w = 0; w < kDiagWords; ++w) acc[w] += ctx->h_diag[i * kDiagWords + w];
+        tm.minu_fallback_tasks = (int64_t)acc[kDiagFallback];
+        tm.minu_tasks_small = (int64_t)acc[kDiagSmall]; tm.minu_tasks_medium = (int64_t)acc[kDiagSmall + 1]; tm.minu_tasks_large = (int64_t)acc[kDiagSmall + 2];
+        tm.minu_tasks = tm.minu_tasks_small + tm.minu_tasks_medium + tm.minu_tasks_large + tm.minu_fallback_tasks;
+        tm.cands_clock_ghz = acc[kDiagCandsWall] ? (float)((double)acc[kDiagCandsClk] / (double)acc[kDiagCandsWall] * 0.1) : 0.0f;
+        tm.bound_clock_ghz = acc[kDiagBoundWall] ? (float)((double)acc[kDiagBoundClk] / (double)acc[kDiagBoundWall] * 0.1) : 0.0f;
+    }
+    if (G > 0) {
+        for (size_t i = 0; i < n_groups; ++i) {
+            hipEvent_t* ev = &ctx->evpool[i * 10];
+            float tot = 0;
+            auto el = [&](int a, int b, float& out) -> int { out = 0; HIPCHK(ctx, hipEventElapsedTime(&out, ev[a], ev[b])); return AFIS_OK; };
+            const bool ov = q->groups[i].overlapped;
+            float t_lut = 0, t_adc = 0, t_tex = 0, t_minu = 0, t_fuse = 0, t_bound = 0, t_ref = 0, t_c = 0, t_g = 0;
+            if (el(0, 5, tot)) return AFIS_EDEVICE;
+            if (ov) {                                                          // overlapped form: the bound pass's time is its own stream's, the minutiae stage ran beside it; the stage times overlap (their sum exceeds total_ms)
+                if (el(0, 1, t_lut) || el(1, 6, t_bound) || el(8, 2, t_ref) || el(2, 3, t_tex) || el(0, 7, t_c) || el(7, 4, t_g) || el(9, 5, t_fuse)) return AFIS_EDEVICE;
+                t_adc = t_bound + t_ref; t_minu = t_c + t_g;
+            } else {
+                if (el(0, 1, t_lut) || el(1, 2, t_adc) || el(2, 3, t_tex) || el(3, 4, t_minu) || el(9, 5, t_fuse) || el(3, 7, t_c) || el(7, 4, t_g)) return AFIS_EDEVICE;
+                if (ctx->adc_variant == 9 && q->groups[i].n_lt_rows > 0) { if (el(1, 6, t_bound) || el(6, 2, t_ref)) return AFIS_EDEVICE; }
+                else t_bound = t_adc;
+            }
+            tm.adc_bound_ms += t_bound; tm.adc_refine_ms += t_ref; tm.cands_ms += t_c; tm.minu_graph_ms += t_g;
+            tm.lut_ms += t_lut; tm.adc_ms += t_adc; tm.tex_tail_ms += t_tex; tm.minu_ms += t_minu; tm.fuse_ms += t_fuse; tm.total_ms += tot;
+        }
+        if (dev_topk) { float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, evk[0], evk[1])); tm.topk_ms = t; tm.total_ms += t; }
+    }
+    return AFIS_OK;
+}
+
 }  // namespace afis
 
 extern "C" {
@@ -363,43 +493,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     if (G > 0 && nq_all > 0) HIPCHK(ctx, ctx->scores.ensure((size_t)nq_all * G * 4));
     HIPCHK(ctx, ctx->diag.ensure(std::max<size_t>(n_groups, 1) * kDiagWords * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->diag.p, 0, std::max<size_t>(n_groups, 1) * kDiagWords * 8, s));    // before the first group's ev[0]: ordered before everything the side streams do
-    // Every buffer of the launch groups is brought to its size HERE, while the device is idle and before anything of this search is queued: for the largest group of
-    // the search and for its worst case (every latent with kTexMax texture rows — what group_bytes_per_query budgets), so that the calls further down never
-    // re-allocate.  A hipMalloc of 6-13 GB takes 0.3 ms on an idle device; issued behind queued work (the row records used to be allocated inside adc_stage_mfma, after
-    // the group's first kernels) it took 510-790 ms in three runs of ten (match -ldir: one search call in seven; profiles/r04_alloc_trace.txt).
-    if (G > 0) {
-        int nq_max = 0, nL_max = 1, lt_pad_max = 0;
-        for (const QueryGroup& grp : q->groups) { nq_max = std::max(nq_max, grp.nq); nL_max = std::max(nL_max, grp.max_nL); lt_pad_max = std::max(lt_pad_max, grp.dev.lt_pad); }
-        const size_t n_pairs = (size_t)nq_max * G;
-        const size_t lt_cap = std::max<size_t>((size_t)lt_pad_max, ((size_t)kTexMax + kTileRows - 1) / kTileRows * kTileRows);
-        if (n_pairs > 0) {
-            if (ctx->adc_variant != 9) HIPCHK(ctx, ctx->rm_val.ensure(n_pairs * lt_cap * 4));      // variant 9: the values live in the compact list (rm_cv) only
-            HIPCHK(ctx, ctx->rm_arg.ensure(n_pairs * lt_cap * 4));
-            HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));   // per-part scores on request: every group's block stays on the device until the search is done
-            HIPCHK(ctx, ctx->cands.ensure(n_pairs * 3 * kTopMinu * sizeof(MinuCand)));
-            HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
-            HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
-            {   // the generic candidate kernel's scratch (sized as in the loop below, for the longest latent minutiae template of the search)
-                const size_t per_wg = 2 * (((size_t)nL_max * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
-                int n_wg = 1024;
-                while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
-                HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
-            }
-            if (ctx->adc_variant == 9) {
-                HIPCHK(ctx, ctx->rm_cv.ensure(n_pairs * lt_cap * 4)); HIPCHK(ctx, ctx->rm_n.ensure(n_pairs * 4));
-                const size_t R_cap = ((size_t)nq_max * kTexMax + 31) / 32 * 32;
-                HIPCHK(ctx, ctx->mf_bfrag.ensure(R_cap / 32 * 6 * 64 * 16));
-                HIPCHK(ctx, ctx->mf_rowk.ensure(R_cap * 16));
-                HIPCHK(ctx, ctx->mf_rec.ensure((size_t)G * R_cap * kMfRecBytesPerRow));
-                if (!ctx->mf_gal_built) {                                  // first search: the bound pass's copy of the gallery codes (adc_stage_mfma fills it)
-                    const size_t n_ent = std::max<size_t>((size_t)ctx->t32_tiles * 32, 1);
-                    HIPCHK(ctx, ctx->g_codes_p.ensure(n_ent * 16));
-                    HIPCHK(ctx, ctx->g_nrm_p.ensure(n_ent * 4));
-                    HIPCHK(ctx, ctx->g_tile_meta.ensure(std::max<size_t>((size_t)ctx->t32_tiles * 8, 16)));
-                }
-            }
-        }
-    }
+    { const int rcp = prepare_search_buffers(ctx, q, parts != nullptr); if (rcp != AFIS_OK) return rcp; }
     int q0 = 0;
     size_t gi = 0;
     SideStreamGuard side_guard(ctx);
@@ -415,7 +509,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
 #ifdef AFIS_EXPERIMENTAL_KERNELS
             if (ctx->adc_variant < 8) HIPCHK(ctx, ctx->lut.ensure(std::max<size_t>((size_t)d.n_tiles * kTileFloats * 4, 16)));   // tile LUT of the direct kernels only
 #endif
-            const size_t lt_cap = std::max<size_t>((size_t)d.lt_pad, ((size_t)kTexMax + kTileRows - 1) / kTileRows * kTileRows);    // worst case, as budgeted: no re-allocation when a later group's longest latent is longer (adc_stage_mfma)
+            const size_t lt_cap = (size_t)d.lt_pad;                          // (already large enough: the top of the search sized them for its largest group)
             if (ctx->adc_variant != 9) HIPCHK(ctx, ctx->rm_val.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
             HIPCHK(ctx, ctx->rm_arg.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16)));
             if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
@@ -569,36 +663,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
         if (!h_sc) { ctx->h_scores.resize((size_t)nq_all * G); h_sc = ctx->h_scores.data(); }
         HIPCHK(ctx, hipMemcpy(h_sc, ctx->scores.p, (size_t)nq_all * G * 4, hipMemcpyDeviceToHost));
     }
-    {   // where the candidate tasks went, and the clocks the sampled workgroups saw (shader cycles per tick of the constant 100 MHz counter)
-        unsigned long long acc[kDiagWords] = {};
-        for (size_t i = 0; i < n_groups; ++i) for (int w = 0; w < kDiagWords; ++w) acc[w] += ctx->h_diag[i * kDiagWords + w];
-        tm.minu_fallback_tasks = (int64_t)acc[kDiagFallback];
-        tm.minu_tasks_small = (int64_t)acc[kDiagSmall]; tm.minu_tasks_medium = (int64_t)acc[kDiagSmall + 1]; tm.minu_tasks_large = (int64_t)acc[kDiagSmall + 2];
-        tm.minu_tasks = tm.minu_tasks_small + tm.minu_tasks_medium + tm.minu_tasks_large + tm.minu_fallback_tasks;
-        tm.cands_clock_ghz = acc[kDiagCandsWall] ? (float)((double)acc[kDiagCandsClk] / (double)acc[kDiagCandsWall] * 0.1) : 0.0f;
-        tm.bound_clock_ghz = acc[kDiagBoundWall] ? (float)((double)acc[kDiagBoundClk] / (double)acc[kDiagBoundWall] * 0.1) : 0.0f;
-    }
-    if (G > 0) {
-        for (size_t i = 0; i < n_groups; ++i) {
-            hipEvent_t* ev = &ctx->evpool[i * 10];
-            float tot = 0;
-            auto el = [&](int a, int b, float& out) -> int { out = 0; HIPCHK(ctx, hipEventElapsedTime(&out, ev[a], ev[b])); return AFIS_OK; };
-            const bool ov = q->groups[i].overlapped;
-            float t_lut = 0, t_adc = 0, t_tex = 0, t_minu = 0, t_fuse = 0, t_bound = 0, t_ref = 0, t_c = 0, t_g = 0;
-            if (el(0, 5, tot)) return AFIS_EDEVICE;
-            if (ov) {                                                          // overlapped form: the bound pass's time is its own stream's, the minutiae stage ran beside it; the stage times overlap (their sum exceeds total_ms)
-                if (el(0, 1, t_lut) || el(1, 6, t_bound) || el(8, 2, t_ref) || el(2, 3, t_tex) || el(0, 7, t_c) || el(7, 4, t_g) || el(9, 5, t_fuse)) return AFIS_EDEVICE;
-                t_adc = t_bound + t_ref; t_minu = t_c + t_g;
-            } else {
-                if (el(0, 1, t_lut) || el(1, 2, t_adc) || el(2, 3, t_tex) || el(3, 4, t_minu) || el(9, 5, t_fuse) || el(3, 7, t_c) || el(7, 4, t_g)) return AFIS_EDEVICE;
-                if (ctx->adc_variant == 9 && q->groups[i].n_lt_rows > 0) { if (el(1, 6, t_bound) || el(6, 2, t_ref)) return AFIS_EDEVICE; }
-                else t_bound = t_adc;
-            }
-            tm.adc_bound_ms += t_bound; tm.adc_refine_ms += t_ref; tm.cands_ms += t_c; tm.minu_graph_ms += t_g;
-            tm.lut_ms += t_lut; tm.adc_ms += t_adc; tm.tex_tail_ms += t_tex; tm.minu_ms += t_minu; tm.fuse_ms += t_fuse; tm.total_ms += tot;
-        }
-        if (dev_topk) { float t = 0; HIPCHK(ctx, hipEventElapsedTime(&t, evk[0], evk[1])); tm.topk_ms = t; tm.total_ms += t; }
-    }
+    { const int rct = collect_timing(ctx, q, tm, dev_topk, evk); if (rct != AFIS_OK) return rct; }
     if (host_topk) {                                                       // k > kDeviceTopK (or an empty gallery)
         std::vector<int32_t> ind((size_t)G);
         for (int i = 0; i < nq_all; ++i) {

@@ -225,17 +225,18 @@ def test_config_fallback_pinned_by_reference_json_library(tmp_path):
 def test_scores_stay_inside_the_tolerance_under_every_accumulation_order(oracle, codebook_bytes):
     """The reference leaves S1's product, S2's sums and the S8 mat-vecs to Eigen (matcher.cpp:443, :455-470, :1279-1289, :1401-1411; version unpinned, not in the tree): the
     oracle and the HIP path fix one order.  SURVEY section 8d's rule — final scores within 1e-3 * max(1, |s|) for >= 99.9 % of the pairs, the same rank 1 — must hold
-    against every order an Eigen build could take (oracle sum_order 1..5; tools/order_sweep.py runs 96 000 pairs per order -> profiles/r06_order_sweep*.json).  Here: 1200
+    against every order an Eigen build could take (oracle sum_order 1..5; tools/order_sweep.py runs 96 000 pairs per order -> profiles/r06_order_sweep*.json).  Here: 1600
     structured pairs (most of them score above zero, unlike the i.i.d. templates), every order against the canonical one."""
     SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
     cb = T.Codebook.from_bytes(codebook_bytes)
     sg = SS.DUP_SIGMA[10]
     lats = SS.make_structured_latents(41, 2, sigma=sg)
-    gal = SS.make_packed_gallery_structured(41, 600, cb, sigma=sg)
-    planted = SS.plant_structured_mates(41, gal, cb, lats, G=600, sigma=sg)
+    gal = SS.make_packed_gallery_structured(41, 800, cb, sigma=sg)
+    planted = SS.plant_structured_mates(41, gal, cb, lats, G=800, sigma=sg)
     ocb = oracle.codebook(codebook_bytes)
     hr = [oracle.rolled(T.write_rolled(gal.template(g)))[0] for g in range(gal.G)]
     n_pos = n_bits = 0
+    n_far = {so: 0 for so in (1, 2, 3, 4, 5)}
     for qi, L in enumerate(lats):
         hl, _ = oracle.latent(ocb, T.write_latent(L))
         _, s0 = oracle.search(ocb, hl, hr, tie_mode=1)
@@ -244,7 +245,8 @@ def test_scores_stay_inside_the_tolerance_under_every_accumulation_order(oracle,
         for so in (1, 2, 3, 4, 5):
             _, s1 = oracle.search(ocb, hl, hr, tie_mode=1 | (so << 4))
             far = np.abs(s1 - s0) > 1e-3 * np.maximum(1.0, np.abs(s0))
-            assert far.mean() <= 1e-3, (qi, so, int(far.sum()), s0[far], s1[far])
+            n_far[so] += int(far.sum())
             assert int(np.argmax(s1)) == int(np.argmax(s0))
             n_bits += int((s1.view(np.uint32) != s0.view(np.uint32)).sum())
+    assert all(v <= 1e-3 * 2 * gal.G for v in n_far.values()), n_far     # >= 99.9 % of the 1600 pairs inside the tolerance, for every order (the 96 000-pair sweeps: 99.997 %)
     assert n_pos > 600 and n_bits > 0          # the orders DO differ in the last bits of many scores: the test is not vacuous
