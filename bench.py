@@ -125,6 +125,64 @@ def cpu_baseline(cb_bytes, lats, gal, lo, pairs_per_thread=800):
             "sample_8_threads": f"1 latent x {n8} gallery templates, 8 threads schedule(static,16)"}
 
 
+class PowerSampler:
+    """Board power of one GPU while a region runs, so that a schedule or a kernel change can be judged in joules as well as in milliseconds (the bound pass is power-limited:
+    DESIGN section 8).  Source: the amdgpu hwmon file of the device (power1_average or power1_input, microwatts; the card whose PCI bus id matches), read by a thread every 50 ms;
+    when the driver exposes none, `rocm-smi --showpower --json` once a second.  Returns None when neither works."""
+
+    def __init__(self, pci_bus_id):
+        import glob
+        self.path = None; self.samples = []; self._stop = False; self._thr = None; self.source = None
+        want = (pci_bus_id or "").lower()
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                bus = os.path.basename(os.path.realpath(dev)).lower()
+            except OSError:
+                continue
+            if want and bus != want: continue
+            for name in ("power1_average", "power1_input"):
+                hits = glob.glob(os.path.join(dev, "hwmon", "hwmon*", name))
+                if hits: self.path = hits[0]; self.source = "hwmon " + name; break
+            if self.path: break
+        if not self.path:
+            import shutil
+            self.smi = shutil.which("rocm-smi")
+            if self.smi: self.source = "rocm-smi --showpower"
+        else:
+            self.smi = None
+
+    def _read(self):
+        if self.path:
+            return int(open(self.path).read().strip()) * 1e-6
+        import subprocess
+        o = subprocess.run([self.smi, "--showpower", "--json"], capture_output=True, text=True, timeout=10).stdout
+        vals = [float(v) for card in json.loads(o).values() for k_, v in card.items() if "ower" in k_ and str(v).replace(".", "", 1).isdigit()]
+        return vals[0] if vals else None
+
+    def start(self):
+        if not (self.path or self.smi): return self
+        import threading
+        self.samples = []; self._stop = False
+        def run():
+            while not self._stop:
+                try:
+                    w = self._read()
+                    if w: self.samples.append(w)
+                except Exception:
+                    pass
+                time.sleep(0.05 if self.path else 1.0)
+        self._thr = threading.Thread(target=run, daemon=True); self._thr.start()
+        return self
+
+    def stop(self, seconds, units):
+        """-> {"watts_mean", "watts_max", "samples", "joules_per_query", "source"} or None"""
+        self._stop = True
+        if self._thr: self._thr.join(timeout=15)
+        if not self.samples: return None
+        w = float(np.mean(self.samples))
+        return {"watts_mean": round(w, 1), "watts_max": round(float(np.max(self.samples)), 1), "samples": len(self.samples), "joules_per_query": round(w * seconds / max(1, units), 3), "source": self.source}
+
+
 def _free_ports(n):
     """n distinct TCP ports that are free on 127.0.0.1 right now (bound together, then released)."""
     import socket
@@ -328,6 +386,7 @@ def main():
         step()
     sync()
     wall["search"] = wall["exchange"] = 0.0
+    power = PowerSampler(m.device_info(gpu).get("pci_bus_id")).start() if rank == 0 else None
     t0 = time.perf_counter()
     tm_acc = None
     for _ in range(a.steps):
@@ -336,6 +395,7 @@ def main():
         tm_acc = tm if tm_acc is None else {k_: tm_acc[k_] + v for k_, v in tm.items()}
     sync()
     elapsed = time.perf_counter() - t0
+    power_timed = power.stop(elapsed, Q * a.steps) if power is not None else None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -383,14 +443,16 @@ def main():
 
     # ---- outside the timed region: the same step with the kernels back to back on one stream, so that the line also carries the bound pass's duration when it
     # has the whole chip (the roofline of the kernel by itself) and the per-stage times without overlap.  Two steps after one warm-up step; rank lists must not change.
-    alone = None
+    alone = None; power_alone = None
     if bound_cus > 0 and world == 1 and not a.no_alone:
         m.set_option("bound_cus", 0)
         m.search_resident(qh, k=a.k)
         acc = None
+        power2 = PowerSampler(m.device_info(gpu).get("pci_bus_id")).start(); t_al = time.perf_counter()
         for _ in range(2):
             r_ = m.search_resident(qh, k=a.k); t_ = m.timing()
             acc = t_ if acc is None else {k_: acc[k_] + v for k_, v in t_.items()}
+        power_alone = power2.stop(time.perf_counter() - t_al, Q * 2)
         assert np.array_equal(r_["topk_idx"], np.asarray(idx)) or use_dist, "the schedule changed a rank list"
         alone = {k_: (v / 2 if (k_.endswith("_ms") or k_.endswith("_ghz")) else v) for k_, v in acc.items()}
         m.set_option("bound_cus", bound_cus_opt)
@@ -533,6 +595,8 @@ def main():
                                      "exchange_and_merge": {"min": round(float(pr_min[1]), 3), "max": round(float(pr_max[1]), 3)},
                                      "note": "host wall time per rank; a rank that finishes its shard early waits in the exchange for the slowest: min(exchange) is the step's own cost"},
             "exchange_ms_per_step": round(float(pr_min[1]), 3), "exchange_ldir": exchange_ldir,
+            "power": {"timed_schedule": power_timed, "kernels_back_to_back": power_alone,
+                      "what": "board power of rank 0's GPU sampled by a host thread during the timed steps, and during the two back-to-back steps after them (bound_cus 0); joules_per_query = mean watts x wall seconds / queries; null = the box exposes no power reading"},
             "ranks": ranks_info,
             "distinct_devices": len({(r_["uuid"] or r_["pci_bus_id"]) for r_ in ranks_info}),
             "shared_gpu": bool(a.share_gpu) or len({(r_["uuid"] or r_["pci_bus_id"]) for r_ in ranks_info}) < world,

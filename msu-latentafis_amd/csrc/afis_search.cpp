@@ -494,6 +494,8 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
     HIPCHK(ctx, ctx->diag.ensure(std::max<size_t>(n_groups, 1) * kDiagWords * 8));
     HIPCHK(ctx, hipMemsetAsync(ctx->diag.p, 0, std::max<size_t>(n_groups, 1) * kDiagWords * 8, s));    // before the first group's ev[0]: ordered before everything the side streams do
     { const int rcp = prepare_search_buffers(ctx, q, parts != nullptr); if (rcp != AFIS_OK) return rcp; }
+    static const bool alloc_trace = getenv("AFIS_ALLOC_TRACE") != nullptr;   // (the trace of DevBuf::ensure, afis_ctx.h: from this line on a search must not allocate — tests/test_gpu_parity.py)
+    if (alloc_trace) { fprintf(stderr, "queue: the search starts queuing\n"); fflush(stderr); }
     int q0 = 0;
     size_t gi = 0;
     SideStreamGuard side_guard(ctx);

@@ -1279,10 +1279,11 @@ def test_minutiae_coordinates_beyond_the_packed_path(codebook_bytes, cb, oracle)
 
 
 def test_a_search_allocates_before_it_queues_and_never_again(codebook_bytes, tmp_path):
-    """The allocation rule: the buffers of a search's launch groups are sized for the largest group's worst case (every latent with 1000
-    texture rows) and allocated before anything is queued — a hipMalloc behind queued work was seen to take 0.5-0.8 s (profiles/r04_alloc_trace.txt).
-    Observable through AFIS_ALLOC_TRACE=1: searching 8 short latents and then 8 of the longest latents against the same gallery (re)allocates nothing of
-    64 MB or more during the second search, in either schedule; fewer latents per search never allocate; more latents per search do (once)."""
+    """The allocation rule: the buffers of a search's launch groups are brought to the size of the search's largest group — what it really takes: its own latent
+    texture rows (round 6; rounds 4-5 sized them for 1000 rows per latent) — BEFORE anything of the search is queued: a hipMalloc behind queued work was seen to take 0.5-0.8 s
+    (profiles/r04_alloc_trace.txt), on the idle device 0.3 ms.  Observable through AFIS_ALLOC_TRACE=1 (every (re)allocation of 64 MB or more, and the point where a search starts
+    queuing): no search allocates after that point, in either schedule; a search of longer latents grows the row buffers (before it queues), the same search again allocates
+    nothing, fewer latents never allocate, more latents per search do."""
     import subprocess, sys, textwrap
     cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1300,6 +1301,8 @@ def test_a_search_allocates_before_it_queues_and_never_again(codebook_bytes, tmp
         def mark(s): sys.stderr.write("mark: " + s + "\\n"); sys.stderr.flush()
         mark("short"); a = m.search(short, k=4)
         mark("long"); b = m.search(long_, k=4)
+        mark("long again"); b2 = m.search(long_, k=4)
+        assert np.array_equal(b["scores"], b2["scores"])
         mark("fewer"); m.search(long_[:3], k=4)
         m.set_option("bound_cus", 0)
         mark("back to back"); c = m.search(long_, k=4)
@@ -1309,12 +1312,15 @@ def test_a_search_allocates_before_it_queues_and_never_again(codebook_bytes, tmp
     """)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, AFIS_ALLOC_TRACE="1"))
     assert r.returncode == 0, r.stderr[-2000:]
-    allocs, where = {}, None
+    allocs, late, where, queued = {}, {}, None, False
     for line in r.stderr.splitlines():
-        if line.startswith("mark: "): where = line[6:]; allocs[where] = []
-        elif line.startswith("alloc: ") and where is not None: allocs[where].append(line)
-    assert len(allocs["short"]) >= 4, allocs                       # the first search of a context allocates (row maxima x 3, records, candidate lists ...)
-    assert allocs["long"] == [] and allocs["fewer"] == [] and allocs["back to back"] == [], allocs
+        if line.startswith("mark: "): where = line[6:]; allocs[where] = []; late[where] = []; queued = False
+        elif line.startswith("queue: "): queued = True
+        elif line.startswith("alloc: ") and where is not None: (late if queued else allocs)[where].append(line)
+    assert all(v == [] for v in late.values()), late               # nothing is (re)allocated once a search has started queuing
+    assert len(allocs["short"]) >= 4, allocs                       # the first search of a context allocates (row maxima x 2, records, candidate lists ...)
+    assert 1 <= len(allocs["long"]) <= 4, allocs                   # longer latents: the row-indexed buffers grow (row maxima x 2, records), the candidate lists do not
+    assert allocs["long again"] == [] and allocs["fewer"] == [] and allocs["back to back"] == [], allocs
     assert len(allocs["more"]) >= 4, allocs                        # 16 latents per search: larger buffers, once
 
 
