@@ -503,7 +503,7 @@ def main():
         hbm_achieved = alg_bytes_launch / (adc_ms_avg * 1e-3) / 1e9 if adc_ms_avg > 0 else 0.0
         variant = 9 if a.variant < 0 else a.variant
         carried = None
-        cp = next((p_ for p_ in (os.path.join(ROOT, "profiles", f) for f in ("r05_adc_counters.json", "r04_adc_counters.json")) if os.path.exists(p_)), "")
+        cp = next((p_ for p_ in (os.path.join(ROOT, "profiles", f) for f in ("r06_adc_counters.json", "r05_adc_counters.json", "r04_adc_counters.json")) if os.path.exists(p_)), "")
         carried_name = "profiles/" + os.path.basename(cp)
         if cp and world == 1 and G == 100000 and Q == 100 and variant == 9:   # measured for the default workload only (PMC passes with the kernels back to back, --bound-cus 0: a kernel's traffic does not depend on what runs beside it)
             try:

@@ -218,15 +218,15 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
         const uint2* rec0 = rec + (size_t)gi * R_pad + l0;               // one record per (template, row): the bound pass merges the two lane halves (adc_mfma.hip)
         const float* des = q.lt_des + (size_t)l0 * kDes;
 
-        // exact similarity of latent row e and rolled point p: table entries recomputed (include.h:327-359), the four chains of matcher.cpp:571-592
-        auto exact_sim = [&](int e, int p) -> float {
+        // exact similarity of the latent row whose descriptor sits in W.val[0 .. 95] (rows evaluated over every point) and rolled point p: table entries recomputed (include.h:327-359), the four chains of matcher.cpp:571-592
+        auto exact_sim_lds = [&](int p) -> float {
             const uint4 cd = g.tex_codes[r0 + p];
             const uint32_t w4[4] = {cd.x, cd.y, cd.z, cd.w};
-            const float4* a4 = reinterpret_cast<const float4*>(des + (size_t)e * kDes);
+            const float4* a4 = reinterpret_cast<const float4*>(W.val);
             float d[4] = {6.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int mg = 0; mg < 4; ++mg) {
-                __builtin_amdgcn_sched_barrier(0);                      // one quarter of the descriptor (24 floats) in registers at a time
+                __builtin_amdgcn_sched_barrier(0);
                 float a[24];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) { const float4 v = a4[mg * 6 + k]; a[4 * k] = v.x; a[4 * k + 1] = v.y; a[4 * k + 2] = v.z; a[4 * k + 3] = v.w; }
@@ -241,7 +241,6 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
             }
             return (d[0] + d[1]) + (d[2] + d[3]);
         };
-
         // ---- A: lower bounds of every row's maximum (ordered keys, 16 registers) ------------------------------------------------------------
         constexpr int kRegs = (kTexMax + 63) / 64;
         const int n_regs = (n_lt + 63) >> 6;
@@ -401,8 +400,13 @@ __global__ __launch_bounds__(kRfWaves * 64) void k_tex_refine(QueryDev q, Galler
                 // std::max_element (matcher.cpp:730): the first point's value stands until a STRICTLY greater one comes.  A NaN similarity never compares
                 // greater, and a NaN at point 0 (a NaN in the latent row: every similarity of the row is NaN) is never beaten; a row of -inf
                 // (an infinite or overflowing descriptor) keeps point 0 as well.
+                // The row's descriptor goes through the wave's (idle: values only live inside flush()) value buffer: every trip of the loop used to fetch its 96 floats again — 24 vector loads of
+                // ONE address per lane and trip (13 trips per row): the texture path, not the arithmetic, was what a full row cost.  From LDS they are 24 broadcast reads.
+                if (lane < 24) reinterpret_cast<float4*>(W.val)[lane] = reinterpret_cast<const float4*>(des + (size_t)row * kDes)[lane];
+                RF_WSYNC();
                 float bv = -INFINITY, v_first = 0.0f; int bp = 0x7fffffff;
-                for (int p = lane; p < n_rt; p += 64) { const float v = exact_sim(row, p); if (p == lane) v_first = v; if (v > bv) { bv = v; bp = p; } }
+                for (int p = lane; p < n_rt; p += 64) { const float v = exact_sim_lds(p); if (p == lane) v_first = v; if (v > bv) { bv = v; bp = p; } }
+                RF_WSYNC();
                 rf_argmax(bv, bp);
                 const float s0 = __shfl(v_first, 0);                    // n_rt >= 1: lane 0 evaluated point 0
                 if (s0 != s0 || bp == 0x7fffffff) { bv = s0; bp = 0; }

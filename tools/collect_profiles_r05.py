@@ -6,7 +6,8 @@ import csv, json, os, re, shutil, sys
 
 tag = sys.argv[1]
 src = f"gpurun_out/{tag}"
-pre = "r05"
+pre = sys.argv[2] if len(sys.argv) > 2 else "r05"                      # python tools/collect_profiles_r05.py <tag> r06: the same bundle layout (tools/profile_round6.sh adds the structured workload)
+ROUND = {"r05": "round 5", "r06": "round 6"}.get(pre, pre)
 last = lambda p: json.loads(open(p).read().strip().splitlines()[-1])
 bench = last(f"{src}/bench.json"); prof = last(f"{src}/bench_profiled.json")
 shutil.copy(f"{src}/bench.json", f"profiles/{pre}_bench_100x100k.json")
@@ -85,7 +86,7 @@ r_raw = r["fetch_KB_raw"] * 1024; r_fetch_lo = r_raw + 0.5 * write_b; r_fetch_hi
 alg_bytes = bench["roofline"]["hbm_view"]["alg_bytes_per_launch"]
 bound_cus = bench["config"].get("bound_cus", 0)
 out = {
-    "round": "round 5", "kernel": "afis::k_adc_mfma<2> (adc_variant 9, default)",
+    "round": ROUND, "kernel": "afis::k_adc_mfma<2> (adc_variant 9, default)",
     "schedule_of_these_counters": "one stream, the kernels of a launch group back to back (bench.py --bound-cus 0): every kernel is characterised ALONE; in the default schedule the bound pass runs on "
                                   f"{bound_cus} of the 256 CUs with the minutiae stage beside it (kernels[...].avg_launch_ms_default_schedule)",
     "workload": f"bench.py default: 100 latents x 100k gallery, launch groups cut by latent texture rows ({launches} launches per step, {q_per_launch:.1f} latents per launch on average)",
@@ -129,7 +130,7 @@ json.dump(proj, open(f"profiles/{pre}_shard_projection.json", "w"), indent=1)
 # ---- the tables the documents quote -------------------------------------------------------------------------------------------------
 st = bench["stage_ms_per_step"]
 L = []
-L.append(f"# Round-5 numbers (generated by tools/collect_profiles_r05.py from gpurun_out/{tag}; do not edit)\n")
+L.append(f"# {ROUND.capitalize()} numbers (generated by tools/collect_profiles_r05.py from gpurun_out/{tag}; do not edit)\n")
 L.append(f"Workload: bench.py default = {bench['config']['queries']} latents x {bench['config']['gallery']} templates, one MI355X; a step = {launches} launch groups of {q_per_launch:.1f} latents on average "
          f"({bench['config']['mean_latent_tex_rows']:.0f} latent texture rows, {bench['config']['mean_rolled_tex_points']:.0f} rolled texture points, {bench['config']['mean_rolled_minutiae']:.0f} rolled minutiae per template).\n")
 L.append("## Step\n")
@@ -191,6 +192,34 @@ L.append("\n## Shards (the per-rank workload of an N-GPU job on ONE GPU; project
 L.append("| N | shard templates | ms per step | projected queries/s | of linear |\n|---|---|---|---|---|")
 for s3 in proj["shards"]:
     L.append(f"| {s3['n_gpus']} | {s3['shard_templates']} | {s3['ms_per_step']:.1f} | {s3['projected_queries_per_s']:.1f} | {s3['projected_efficiency_vs_linear']:.3f} |")
+# ---- round 6: the structured workload (bench.py --workload structured --dup 0 / 10 / 30; tools/profile_round6.sh) ----
+st_runs = {d: last(f"{src}/bench_structured_dup{d}.json") for d in (0, 10, 30) if os.path.exists(f"{src}/bench_structured_dup{d}.json")}
+if st_runs:
+    doc = {"what": "bench.py --workload structured (host/synth_structured.py: texture points on the extractor's 16-px grid inside a foreground blob, smooth ridge flow, descriptors near a shared manifold PQ-encoded "
+                   "afterwards; --dup = the share of a rolled template's texture points whose 16-byte code vector occurs at another point of the template too) at BASELINE.json configs[2]'s sizes, one MI355X, "
+                   "same box and bundle as the headline line beside it.  NOT the headline.",
+           "headline_same_box": {"queries_per_s": bench["value"], "ms_per_step": bench["ms_per_step"], "stage_ms_per_step": bench["stage_ms_per_step"], "stage_ms_per_step_back_to_back": bench.get("stage_ms_per_step_back_to_back")},
+           "runs": {}}
+    L.append("\n## The structured workload (`bench.py --workload structured`; NOT the headline) on the same box\n")
+    L.append("| repeated code vectors | queries/s | ms per step (x the headline's) | back to back: bound / recompute / texture lists / candidates / minutiae lists (ms per step) | rows evaluated per pair | cells per evaluated row | evaluated rows over every point | non-mates scoring > 0 | candidate tasks to the any-shape kernel |\n|---|---|---|---|---|---|---|---|---|")
+    hb = bench.get("stage_ms_per_step_back_to_back") or {}
+    L.append(f"| (headline, i.i.d. templates) | {bench['value']:.2f} | {bench['ms_per_step']:.1f} (1.00) | {hb.get('adc_bound_ms', 0):.0f} / {hb.get('adc_refine_ms', 0):.0f} / {hb.get('tex_tail_ms', 0):.0f} / {hb.get('cands_ms', 0):.0f} / {hb.get('minu_graph_ms', 0):.0f} | {rs['rows_evaluated'] / rs['pairs']:.1f} | {rs['cells_evaluated'] / rs['rows_evaluated']:.3f} | {100 * rs['rows_evaluated_in_full'] / rs['rows_evaluated']:.3f} % | | {mt.get('any_shape_fallback_kernel')} |")
+    for d, j in sorted(st_runs.items()):
+        open(f"profiles/{pre}_bench_structured_dup{d}.json", "w").write(json.dumps(j) + "\n")
+        jb = j.get("stage_ms_per_step_back_to_back") or {}; jr = j.get("refine_stats") or {}; js = j.get("score_stats") or {}
+        doc["runs"][f"dup{d}"] = {"queries_per_s": j["value"], "ms_per_step": j["ms_per_step"], "step_time_relative_to_headline": round(j["ms_per_step"] / bench["ms_per_step"], 3),
+                                   "measured_share_of_repeated_code_vectors": j["config"].get("structured_dup_share_measured"), "stage_ms_per_step": j["stage_ms_per_step"], "stage_ms_per_step_back_to_back": jb,
+                                   "refine_stats": jr, "score_stats": js, "minutiae_candidate_tasks": j["minutiae_candidate_tasks"], "rank1_hits": j["rank1_hits"], "power": j.get("power")}
+        L.append(f"| {100 * (j['config'].get('structured_dup_share_measured') or 0):.1f} % (--dup {d}) | **{j['value']:.2f}** | {j['ms_per_step']:.1f} ({j['ms_per_step'] / bench['ms_per_step']:.3f}) | {jb.get('adc_bound_ms', 0):.0f} / {jb.get('adc_refine_ms', 0):.0f} / {jb.get('tex_tail_ms', 0):.0f} / {jb.get('cands_ms', 0):.0f} / {jb.get('minu_graph_ms', 0):.0f} | "
+                 f"{jr.get('evaluated_rows_per_pair', 0):.1f} | {jr.get('cells_per_evaluated_row', 0):.3f} | {100 * jr.get('share_of_evaluated_rows_in_full', 0):.3f} % | {100 * js.get('non_mates_with_positive_score', 0):.1f} % | {j['minutiae_candidate_tasks']['any_shape_fallback_kernel']} |")
+    json.dump(doc, open(f"profiles/{pre}_bench_structured.json", "w"), indent=1)
+    if os.path.exists(f"{src}/kernel_stats_structured.csv"): shutil.copy(f"{src}/kernel_stats_structured.csv", f"profiles/{pre}_kernel_stats_structured_back_to_back.csv")
+pw = bench.get("power") or {}
+if pw.get("timed_schedule") or pw.get("kernels_back_to_back"):
+    L.append("\n## Board power (bench.py: a host thread samples the GPU's hwmon power file during the timed steps)\n")
+    L.append("| schedule | mean W | max W | J per query |\n|---|---|---|---|")
+    for k_, lab in (("timed_schedule", f"default schedule (bound pass on {bound_cus} CUs)"), ("kernels_back_to_back", "kernels back to back")):
+        if pw.get(k_): L.append(f"| {lab} | {pw[k_]['watts_mean']:.0f} | {pw[k_]['watts_max']:.0f} | {pw[k_]['joules_per_query']:.2f} |")
 if os.path.exists("profiles/r04_cli_scale.json"):       # (round 4's measurement: the host side of `match` did not change in round 5)
     c = json.load(open("profiles/r04_cli_scale.json"))
     L.append(f"\n## `match` end to end, {c['Q']} latents x {c['G']} templates (tools/cli_scale_r04.py, ROUND 4's run; wall seconds, stages from the process's own clock; measured at the end of the round, after the host-side staging / allocation work — the kernels are the bundle's)\n")
