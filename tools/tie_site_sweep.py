@@ -27,7 +27,9 @@ def run(idw, dup, Q, G, seed=77):
     lats = SS.make_structured_latents(seed, Q, sigma=sg); gal = SS.make_packed_gallery_structured(seed, G, cb, sigma=sg); SS.plant_structured_mates(seed, gal, cb, lats, G=G, sigma=sg)
     orc = Oracle(); ocb = orc.codebook(cbb); nt = orc.lib.orc_num_threads()
     hr = [orc.rolled(T.write_rolled(gal.template(g)))[0] for g in range(G)]
-    res = {t: {"pairs_beyond_1e-3": 0, "pairs_with_a_differing_bit": 0, "minutiae_parts_beyond_1e-3": 0, "texture_part_beyond_1e-3": 0, "top24_changes_over_positive": 0} for t in SITES}
+    res = {t: {"pairs_beyond_1e-3": 0, "pairs_with_a_differing_bit": 0, "minutiae_parts_beyond_1e-3": 0, "texture_part_beyond_1e-3": 0, "top24_changes_over_positive": 0,
+               "largest_score_among_the_pairs_beyond_1e-3": 0.0, "largest_absolute_difference": 0.0, "planted_mates_beyond_1e-3": 0} for t in SITES}
+    planted = SS.plant_structured_mates(seed, gal, cb, lats, G=G, sigma=sg)          # (idempotent: the same mates again; returns their slots)
     short = tasks = pos = 0
     for qi, L in enumerate(lats):
         hl, _ = orc.latent(ocb, T.write_latent(L))
@@ -36,7 +38,12 @@ def run(idw, dup, Q, G, seed=77):
         pos += int((s0 > 0).sum())
         for t in SITES:
             s1, p1 = sc[t]; r = res[t]
-            r["pairs_beyond_1e-3"] += int((np.abs(s0 - s1) > 1e-3 * np.maximum(1, np.abs(s0))).sum())
+            far_ = np.abs(s0 - s1) > 1e-3 * np.maximum(1, np.abs(s0))
+            r["pairs_beyond_1e-3"] += int(far_.sum())
+            if far_.any():
+                r["largest_score_among_the_pairs_beyond_1e-3"] = max(r["largest_score_among_the_pairs_beyond_1e-3"], float(np.maximum(s0, s1)[far_].max()))
+                r["largest_absolute_difference"] = max(r["largest_absolute_difference"], float(np.abs(s0 - s1)[far_].max()))
+                r["planted_mates_beyond_1e-3"] += int(sum(bool(far_[g_]) for g_, _f in planted[qi]))
             r["pairs_with_a_differing_bit"] += int((s0.view(np.uint32) != s1.view(np.uint32)).sum())
             r["minutiae_parts_beyond_1e-3"] += int((np.abs(p0[:, :3] - p1[:, :3]) > 1e-3 * np.maximum(1, np.abs(p0[:, :3]))).sum())
             r["texture_part_beyond_1e-3"] += int((np.abs(p0[:, 3] - p1[:, 3]) > 1e-3 * np.maximum(1, np.abs(p0[:, 3]))).sum())
