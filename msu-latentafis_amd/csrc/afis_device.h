@@ -203,7 +203,7 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
 // (task = (q*3+s)*G + g).  Pairs of up to 256 latent x 512 rolled minutiae and 38 912 similarities go through the rolled-template-stationary MFMA kernel in one of its
 // three shape classes (above); what it cannot take (other shapes, degenerate key distributions) it appends to `fallback` (count, task ids), which the
-// generic kernel then works off.  force_generic: the generic kernel does every task.  max_nL / max_nR: the longest latent list of the launch and the
+// generic kernel then works off.  force_generic: a flags word — bit 0: the generic kernel does every task; bit 1: option s3_tie_order (equal norms in std::sort's order where the generic kernel holds the matrix in LDS).  max_nL / max_nR: the longest latent list of the launch and the
 // longest rolled minutiae template of the gallery (which classes can have work at all).
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
                              int force_generic, MinuCand* cands, int32_t* cand_n, int32_t* fallback /* minu_fb_ints() ints */, int max_nL, int max_nR,

@@ -10,6 +10,7 @@
 // Canonical arithmetic (see oracle/afis_oracle.cpp): descriptor dot products are k-ascending fmaf chains, row/column sums are
 // index-ascending, the normalisation is evaluated in double exactly as the reference's expression promotes it.
 #include "afis_device.h"
+#include "stdsort_order.h"
 #include <cstdlib>
 
 namespace afis {
@@ -71,13 +72,16 @@ struct MinuSmem {
     int te[kTopMinu];
     int slots[2 * kWaves];
     int counter;
+    uint16_t order[kFastN];         // option s3_tie_order 1: the element indices std::sort permutes (16 KB)
+    int sort_stack[3 * 64];
 };
 
 // Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
 __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
                                                          MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n,
                                                          const int32_t* __restrict__ fb /* NULL: every task; else fb[0] tasks listed in fb[1 ...] */,
-                                                         unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row */)
+                                                         unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row */,
+                                                         int ref_tie_order /* option s3_tie_order: equal norms in libstdc++'s std::sort order (stdsort_order.h) for tasks whose matrix fits LDS */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
@@ -181,6 +185,25 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
             f = f - sv;
             return ord_f32((float)((double)sv / ((double)f + 0.000001)));                        // :467
         };
+        if (ref_tie_order && fast) {
+            // The reference's own order of equal norms (matcher.cpp:473-476: std::sort of the indices 0 .. n-1 by norm, descending): every key of the task in LDS (the GEMM's
+            // operand tiles are dead), the indices in order, and ONE lane runs libstdc++'s algorithm on them as far as the first 120 positions need it (stdsort_order.h).
+            uint32_t* const keys32 = reinterpret_cast<uint32_t*>(sm.A);                           // A and B are contiguous: 38.4 KB >= 4 n bytes (n <= 8192)
+            static_assert(sizeof(sm.A) + sizeof(sm.B) >= sizeof(uint32_t) * kFastN && offsetof(MinuSmem, B) == sizeof(sm.A), "the keys reuse the GEMM's operand tiles");
+            for (int e = tid; e < n; e += kThreads) { keys32[e] = norm_key(e); sm.order[e] = (uint16_t)e; }
+            __syncthreads();
+            if (tid == 0) stdsort_prefix(sm.order, n, topN, keys32, sm.sort_stack);
+            __syncthreads();
+            if (tid < topN) {
+                const int e = sm.order[tid];
+                const int i1 = e / nR, i2 = e - i1 * nR;
+                MinuCand c; c.sim = simi[e]; c.li = (short)i1; c.ri = (short)i2;
+                cands[(size_t)task * kTopMinu + tid] = c;
+            }
+            if (tid == 0) cand_n[task] = topN;
+            __syncthreads();
+            continue;
+        }
         // K-th largest key T, built bit by bit from wave-level ballot counts; then the keys above T plus the lowest-index
         // keys equal to T.  `keyv(u)` is this thread's u-th key (element e = tid + u*256), 0 beyond n (real keys are >= 2^31).
         uint32_t rk[kKeyRegs];
@@ -394,7 +417,8 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                                                                 MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb,
                                                                 const int32_t* __restrict__ work /* rolled templates with tasks of this class */,
                                                                 int32_t* __restrict__ ctl /* ctl[c]: entries of work[]; ctl[4 + c]: the draw counter */,
-                                                                unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row (afis_device.h) */)
+                                                                unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row (afis_device.h) */,
+                                                                int ref_tie_order /* option s3_tie_order: lists short of 120 positive norms go to the any-shape kernel, which orders their tied zeros as std::sort does */)
 {
     typedef RtCfg<S> Cfg;
     constexpr int kT = Cfg::kT, kW = Cfg::kW, kSimi = Cfg::kSimi, kCls = S == 1 ? 0 : S == 2 ? 1 : 2;
@@ -653,7 +677,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             // clamped to zero, matcher.cpp:447-451 — 8 % of the pairs of bench.py --workload structured, which the any-shape kernel did at 30 x the time): the positive entries are all
             // candidates and are ranked as always; the rest of the 120 are zero entries, which tie, in ascending element order (tie rule) — filled in below.
             bool fill = false;
-            if (Braw < 0) {                                                          // uniform, rare: are there positive norms below 2^-15 (uncounted, bin <= 0)?  Looked for only here — the histogram pass pays nothing for it
+            if (Braw < 0 && !ref_tie_order) {                                        // uniform, rare: are there positive norms below 2^-15 (uncounted, bin <= 0)?  Looked for only here — the histogram pass pays nothing for it
                 if (tid == 0) sm.pad_[0] = 0;
                 RT_SYNC();
                 bool tiny = false;
@@ -824,7 +848,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
 }
 
 template <int S>
-static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int32_t* work, int32_t* ctl, unsigned long long* diag, hipStream_t stream)
+static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int32_t* work, int32_t* ctl, unsigned long long* diag, int ref_tie_order, hipStream_t stream)
 {
     // opt-in to > 64 KB of dynamic LDS: a per-device function attribute, set on every launch (cheap) rather than cached per process
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands_rt<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RtSmem<S>));
@@ -835,7 +859,7 @@ static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCa
 #endif
     const int full = (AFIS_RT_GRID_CAP > 0 && S == 1) ? AFIS_RT_GRID_CAP : 256 * per_cu;
     const int grid = g.G < full ? g.G : full;
-    hipLaunchKernelGGL(k_minu_cands_rt<S>, dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag);
+    hipLaunchKernelGGL(k_minu_cands_rt<S>, dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag, ref_tie_order);
     return hipGetLastError();
 }
 
@@ -846,6 +870,8 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
     if (n_tasks <= 0) return hipSuccess;
     if (n_tasks > 0x7ffffff0LL) return hipErrorInvalidValue;
     hipError_t e;
+    const int ref_tie_order = (force_generic >> 1) & 1;                             // bit 1 of the flags word: option s3_tie_order
+    force_generic &= 1;
     if (!force_generic) {
         int32_t* ctl = fallback + 1 + n_tasks;                                    // minu_fb_ints(): [count | n_tasks task ids | 8 control words | 3 G work-list entries]
         int32_t* work = ctl + 8;
@@ -856,15 +882,15 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
         hipLaunchKernelGGL(k_minu_classify, dim3((g.G + 255) / 256), dim3(256), 0, stream, q, g, work, ctl, cand_n, fallback);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        e = launch_rt_class<1>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
+        e = launch_rt_class<1>(q, g, cands, cand_n, fallback, work, ctl, diag, ref_tie_order, stream);
         if (e != hipSuccess) return e;
         // the larger classes only when the shapes of this launch can reach them (a kernel that finds its work list empty still costs a launch)
         const int mr = max_nR < 256 ? (max_nR > 0 ? max_nR : 1) : 256;
         if (max_nL > rt_class_max_latent(1) || max_nR > rt_class_max_rolled(1)) {
-            e = launch_rt_class<2>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
+            e = launch_rt_class<2>(q, g, cands, cand_n, fallback, work, ctl, diag, ref_tie_order, stream);
             if (e != hipSuccess) return e;
             if (max_nR > rt_class_max_rolled(2) || max_nL > rt_max_rows(2, mr)) {
-                e = launch_rt_class<4>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
+                e = launch_rt_class<4>(q, g, cands, cand_n, fallback, work, ctl, diag, ref_tie_order, stream);
                 if (e != hipSuccess) return e;
             }
         }
@@ -874,7 +900,7 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
     if (e != hipSuccess) return e;
     const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
     hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n,
-                       force_generic ? (const int32_t*)nullptr : fallback, diag);
+                       force_generic ? (const int32_t*)nullptr : fallback, diag, ref_tie_order);
     return hipGetLastError();
 }
 

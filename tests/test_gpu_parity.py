@@ -1447,3 +1447,53 @@ def test_structured_templates_against_oracle(codebook_bytes, cb, oracle):
     SS.IDENTITY_WEIGHT = 0.3
     assert n_fill >= 5, n_fill
     assert n_pairs == 200 and n_pos >= 100, (n_pairs, n_pos)                   # most non-mates score above zero
+
+
+def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
+    """Option s3_tie_order 1: where candidate norms tie, the list of 120 is the one libstdc++'s std::sort leaves (matcher.cpp:473-476 sorts the nL x nR indices with a non-strict
+    comparator) — csrc/stdsort_order.h run by the any-shape candidate kernel — instead of ascending element index.  It matters for lists with fewer than 120 POSITIVE similarities
+    (the zeros that fill the list are all tied): tiny latent templates, and prints whose descriptors point away from each other (structured templates at identity weight 1.0).
+    The oracle's tie mode 4 takes std::sort at S3 and the stable order elsewhere: per-part and fused scores and the S3 lists bit for bit; and the test is not vacuous — the
+    default order (tie mode 1) gives other scores on some of the pairs."""
+    SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
+    rng = np.random.default_rng(905)
+    SS.IDENTITY_WEIGHT = 1.0
+    try:
+        lats = [SS.make_structured_latent(rng, sigma=0.0095, n_tex_lo=200, n_tex_hi=260) for _ in range(3)]
+        lats.append(SS.make_structured_latent(rng, sigma=0.0095, n_tex_lo=200, n_tex_hi=260, n_minu_lo=3, n_minu_hi=6))          # tiny lists: nL x nR / 2 < 120 against small rolled prints
+        gal = [SS.make_structured_mate(rng, cb, L, frac=0.6, sigma=0.0095, n_minu=int(rng.integers(40, 120)), n_tex=320) for L in lats[:3]]
+        while len(gal) < 60: gal.append(SS.make_structured_rolled(rng, cb, sigma=0.0095, n_minu=int(rng.integers(20, 128)), n_tex=300))
+    finally:
+        SS.IDENTITY_WEIGHT = 0.3
+    m = M.Matcher(codebook_bytes, taps=True)
+    m.gallery_add(gal); m.gallery_commit(0)
+    base = m.search(lats, k=0, want_parts=True)
+    m.set_option("s3_tie_order", 1)
+    assert m.get_option("s3_tie_order") == 1
+    res = m.search(lats, k=0, want_parts=True); tm = m.timing()
+    assert tm["minu_fallback_tasks"] > 0
+    ocb = oracle.codebook(codebook_bytes)
+    hl, hr = cases.to_orc(oracle, ocb, lats, gal)
+    n_moved = n_short = 0
+    for qi in range(len(lats)):
+        rc, sc4, p4 = oracle.search(ocb, hl[qi], hr, tie_mode=4, want_parts=True)
+        rc, sc1, p1 = oracle.search(ocb, hl[qi], hr, tie_mode=1, want_parts=True)
+        got = np.concatenate([res["parts"][qi], res["scores"][qi][:, None]], axis=1)
+        diff = got.view(np.uint32) != p4.view(np.uint32)
+        assert not diff.any(), (qi, np.argwhere(diff)[:4], got[diff][:4], p4[diff][:4])
+        gb = np.concatenate([base["parts"][qi], base["scores"][qi][:, None]], axis=1)
+        assert np.array_equal(gb.view(np.uint32), p1.view(np.uint32))                      # the default stays the ascending-index order
+        n_moved += int((p4.view(np.uint32) != p1.view(np.uint32)).any(axis=1).sum())
+        for s_ in (26, 2, 11):
+            for R in gal: n_short += int(((lats[qi].minu[s_].des @ R.minu[0].des.T) > 0).sum() < min(120, lats[qi].minu[s_].n * R.minu[0].n))
+    assert n_short >= 20 and n_moved >= 3, (n_short, n_moved)
+    for qi, gi in ((0, 5), (3, 7), (3, 20), (1, 33)):                                       # the S3 lists themselves
+        for which in (1, 2, 3):
+            want = oracle.trace(ocb, hl[qi], hr[gi], which=which, stage=0, tie_mode=4)
+            gotl = m.debug_stage_list(lats[qi], gi, which, 0)
+            assert (want is None) == (gotl is None)
+            if want is None: continue
+            assert np.array_equal(gotl[1], want[1]) and np.array_equal(gotl[2], want[2]), (qi, gi, which)
+    with pytest.raises(M.AfisError):
+        m.set_option("s3_tie_order", 2)
+    m.close()

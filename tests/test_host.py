@@ -465,3 +465,14 @@ def test_structured_generator_has_the_structure_it_claims(cb):
     assert len(np.unique(rc)) == len(rc)                                            # a mate keeps unique coordinates
     rc2, back = T.read_rolled(T.write_rolled(R))
     assert rc2 == 0 and np.array_equal(back.tex[0].codes, R.tex[0].codes)
+
+
+def test_stdsort_order_equals_libstdcxx(tmp_path):
+    """csrc/stdsort_order.h — the restatement of libstdc++'s std::sort that option s3_tie_order 1 runs on the device to order equal candidate norms as the reference binary does
+    (matcher.cpp:473-476) — against std::sort itself on the host: 40 000 arrays (distinct keys, few distinct values, mostly-zero keys as in a list short of 120 positive
+    similarities, all equal, organ pipes; every n up to 300 and task-shaped ones up to 8192), the first K positions only (the pruned form the kernel uses) and whole arrays,
+    and forced depth limits so that the heap-sort branch runs."""
+    exe = tmp_path / "stdsort_check"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tools", "stdsort_check.cpp")], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout + out.stderr
