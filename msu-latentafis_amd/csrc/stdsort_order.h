@@ -98,6 +98,38 @@ SSO_FN int sso_partition_pivot(const SsoCtx& c, int f, int l)
         ++first;
     }
 }
+// The same partition in CLOSED FORM — what lets a wave do it in parallel (minu.hip::sso_partition_wave is this function with ballots for the loops).  The unguarded
+// Hoare partition moves two pointers towards each other and swaps where both have stopped; until they cross, neither pointer ever reads a position the other has
+// written.  So the stops are those of the ORIGINAL array: left stops L_1 < L_2 < ... = the positions of (first + 1, last) whose key is <= the pivot's, right stops
+// R_1 > R_2 > ... = those whose key is >= the pivot's; swap i exchanges L_i and R_i while L_i < R_i (say m swaps); and the partition point is
+// min(L_{m+1}, R_m) (R_m now holds a left-stop element; R_0 = nothing).  lpos / rpos: scratch of (last - first) entries each.
+SSO_FN int sso_partition_pivot_closed(const SsoCtx& c, int f, int l, uint16_t* lpos, uint16_t* rpos)
+{
+    uint16_t* A = c.A;
+    const int mid = f + (l - f) / 2;
+    const int a = f + 1, b = mid, cc = l - 1;
+    if (sso_before(c, A[a], A[b])) {
+        if (sso_before(c, A[b], A[cc])) sso_swap(A, f, b);
+        else if (sso_before(c, A[a], A[cc])) sso_swap(A, f, cc);
+        else sso_swap(A, f, a);
+    } else if (sso_before(c, A[a], A[cc])) sso_swap(A, f, a);
+    else if (sso_before(c, A[b], A[cc])) sso_swap(A, f, cc);
+    else sso_swap(A, f, b);
+    const uint32_t pk = c.key[A[f]];
+    int nl = 0, nr = 0;
+    for (int p = f + 1; p < l; ++p) {
+        const uint32_t k = c.key[A[p]];
+        if (k <= pk) lpos[nl++] = (uint16_t)p;                              // !before(A[p], pivot): the left pointer stops here
+        if (k >= pk) rpos[nr++] = (uint16_t)p;                              // !before(pivot, A[p]): the right pointer stops here (ascending; the i-th from the right is rpos[nr - i])
+    }
+    int m = 0;
+    while (m < nl && m < nr && lpos[m] < rpos[nr - 1 - m]) ++m;
+    for (int i = 0; i < m; ++i) sso_swap(A, lpos[i], rpos[nr - 1 - i]);
+    int cut = m < nl ? (int)lpos[m] : 0x7fffffff;
+    if (m > 0 && (int)rpos[nr - m] < cut) cut = rpos[nr - m];
+    return cut;
+}
+
 SSO_FN int sso_floor_log2(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } return k; }
 
 // A[0 .. n) = a permutation (normally 0 .. n-1 in order); afterwards A[0 .. min(K, n)) is what std::sort(A, A + n, comp) leaves there.

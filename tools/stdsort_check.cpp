@@ -28,6 +28,20 @@ static void one(const std::vector<uint32_t>& key, int K, int depth)
         if (a[i] != b[i]) { if (bad < 5) fprintf(stderr, "mismatch: n %d K %d depth %d at %d: %u vs %u\n", n, K, depth, i, a[i], b[i]); ++bad; return; }
 }
 
+// the closed form of the partition (what the device's wave executes in parallel) against the pointer walk, on the same array
+static void partition_forms(const std::vector<uint32_t>& key)
+{
+    const int n = (int)key.size();
+    if (n < 17) return;
+    std::vector<uint16_t> a(n), b(n), lp(n), rp(n);
+    std::iota(a.begin(), a.end(), 0);
+    std::mt19937 r2(n * 7 + 1); std::shuffle(a.begin(), a.end(), r2); b = a;
+    const afis::SsoCtx ca{a.data(), key.data()}, cb{b.data(), key.data()};
+    const int c1 = afis::sso_partition_pivot(ca, 0, n), c2 = afis::sso_partition_pivot_closed(cb, 0, n, lp.data(), rp.data());
+    ++checked;
+    if (c1 != c2 || a != b) { if (bad < 5) fprintf(stderr, "partition forms differ: n %d cut %d vs %d\n", n, c1, c2); ++bad; }
+}
+
 int main()
 {
     std::mt19937 rng(12345);
@@ -45,7 +59,7 @@ int main()
                 default: key[i] = (uint32_t)std::min(i, n - 1 - i) / 2; break;
                 }
             }
-            one(key, n, -1); one(key, 120, -1); one(key, 17, -1);
+            one(key, n, -1); one(key, 120, -1); one(key, 17, -1); partition_forms(key);
             for (int d : {0, 1, 2, 3}) { one(key, n, d); one(key, 120, d); }
         }
     for (int rep = 0; rep < 400; ++rep) {                                // the shapes of real tasks: 20..64 x 20..128 entries, a few dozen positive, the rest zero
@@ -54,7 +68,7 @@ int main()
         const int pos = rng() % 130;
         for (int i = 0; i < pos; ++i) key[rng() % n] = 1 + rng() % 100000;
         if (rep % 5 == 0) for (int i = 0; i < n; ++i) if (rng() % 3 == 0) key[i] = 1 + rng() % 50;    // many positive ties as well
-        one(key, 120, -1);
+        one(key, 120, -1); partition_forms(key);
         if (rep % 40 == 0) { one(key, n, -1); one(key, 120, 3); one(key, 120, 5); }
     }
     printf("stdsort_order: %ld comparisons with libstdc++, %ld mismatches\n", checked, bad);
