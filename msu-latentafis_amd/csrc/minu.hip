@@ -73,8 +73,100 @@ struct MinuSmem {
     int slots[2 * kWaves];
     int counter;
     uint16_t order[kFastN];         // option s3_tie_order 1: the element indices std::sort permutes (16 KB)
+    uint16_t lpos[kFastN], rpos[kFastN];   // ... the two pointers' stops of a partition (stdsort_order.h: the closed form)
+    uint16_t leaf_f[256], leaf_l[256];     // ... the ranges of <= 16 elements the introsort loop leaves for the final insertion sort
     int sort_stack[3 * 64];
 };
+
+// stdsort_prefix (stdsort_order.h) by ONE WAVE: the same ranges, the same pivots, the same swaps — a range's partition in its closed form (sso_partition_pivot_closed) with
+// ballots and prefix counts for the loops, the final insertion sort one lane per leaf range (no element crosses a leaf's boundary: everything to its left is >= everything in it,
+// and insertion moves an element left only past strictly smaller keys).  The depth-limit branch (heap sort) and the median of three stay with lane 0.
+#define SSO_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+__device__ __forceinline__ int sso_lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
+__device__ int sso_partition_wave(const SsoCtx& c, int f, int l, uint16_t* lpos, uint16_t* rpos)
+{
+    uint16_t* A = c.A;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {                                                                // __move_median_to_first(first, first + 1, mid, last - 1)
+        const int a = f + 1, b = f + (l - f) / 2, cc = l - 1;
+        if (sso_before(c, A[a], A[b])) {
+            if (sso_before(c, A[b], A[cc])) sso_swap(A, f, b);
+            else if (sso_before(c, A[a], A[cc])) sso_swap(A, f, cc);
+            else sso_swap(A, f, a);
+        } else if (sso_before(c, A[a], A[cc])) sso_swap(A, f, a);
+        else if (sso_before(c, A[b], A[cc])) sso_swap(A, f, cc);
+        else sso_swap(A, f, b);
+    }
+    SSO_WSYNC();
+    const uint32_t pk = c.key[A[f]];
+    int nl = 0, nr = 0;                                                             // uniform
+    for (int p0 = f + 1; p0 < l; p0 += 64) {
+        const int p = p0 + lane;
+        const bool in = p < l;
+        const uint32_t k = in ? c.key[A[p]] : 0u;
+        const bool sl = in && k <= pk, sr = in && k >= pk;
+        const u64 ml = __ballot(sl), mr = __ballot(sr);
+        if (sl) lpos[nl + sso_lane_prefix(ml)] = (uint16_t)p;
+        if (sr) rpos[nr + sso_lane_prefix(mr)] = (uint16_t)p;
+        nl += (int)__popcll(ml); nr += (int)__popcll(mr);
+    }
+    SSO_WSYNC();
+    int m = 0;
+    const int lim = nl < nr ? nl : nr;
+    for (int i0 = 0; i0 < lim; i0 += 64) {                                          // the swaps happen while L_i < R_i: a prefix of the i (L ascends, R descends)
+        const int i = i0 + lane;
+        const bool ok = i < lim && lpos[i] < rpos[nr - 1 - i];
+        const int cnt = (int)__popcll(__ballot(ok));
+        m += cnt;
+        if (cnt < 64) break;
+    }
+    for (int i = lane; i < m; i += 64) {
+        const int pl = lpos[i], pr = rpos[nr - 1 - i];
+        const uint16_t x = A[pl], y = A[pr];
+        A[pl] = y; A[pr] = x;
+    }
+    int cut = m < nl ? (int)lpos[m] : 0x7fffffff;
+    if (m > 0) { const int r = rpos[nr - m]; cut = r < cut ? r : cut; }
+    SSO_WSYNC();
+    return cut;
+}
+__device__ void stdsort_prefix_wave(uint16_t* A, int n, int K, const uint32_t* key, int* stack, uint16_t* lpos, uint16_t* rpos, uint16_t* leaf_f, uint16_t* leaf_l)
+{
+    const SsoCtx c{A, key};
+    const int lane = threadIdx.x & 63;
+    if (n < 2) return;
+    if (K > n) K = n;
+    int sp = 1, n_leaf = 0;
+    if (lane == 0) { stack[0] = 0; stack[1] = n; stack[2] = 2 * sso_floor_log2(n); }
+    SSO_WSYNC();
+    while (sp > 0) {
+        --sp;
+        int f = stack[3 * sp], l = stack[3 * sp + 1], d = stack[3 * sp + 2];        // uniform: every lane reads the same words
+        SSO_WSYNC();                                                                // (read before lane 0 may push over them)
+        if (f >= K) continue;
+        while (l - f > 16) {
+            if (d == 0) { if (lane == 0) sso_heap_sort(c, f, l); SSO_WSYNC(); break; }
+            --d;
+            const int cut = sso_partition_wave(c, f, l, lpos, rpos);
+            if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
+            ++sp;
+            SSO_WSYNC();
+            l = cut;
+        }
+        if (l > f && n_leaf < 256) { if (lane == 0) { leaf_f[n_leaf] = (uint16_t)f; leaf_l[n_leaf] = (uint16_t)l; } ++n_leaf; }
+    }
+    SSO_WSYNC();
+    for (int b = lane; b < n_leaf; b += 64) {                                       // the final insertion sort, one lane per leaf range
+        const int lf = leaf_f[b], ll = leaf_l[b];
+        for (int i = lf + 1; i < ll; ++i) {
+            const uint16_t val = A[i];
+            int j = i;
+            while (j > lf && sso_before(c, val, A[j - 1])) { A[j] = A[j - 1]; --j; }
+            A[j] = val;
+        }
+    }
+    SSO_WSYNC();
+}
 
 // Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
 __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
@@ -192,7 +284,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
             static_assert(sizeof(sm.A) + sizeof(sm.B) >= sizeof(uint32_t) * kFastN && offsetof(MinuSmem, B) == sizeof(sm.A), "the keys reuse the GEMM's operand tiles");
             for (int e = tid; e < n; e += kThreads) { keys32[e] = norm_key(e); sm.order[e] = (uint16_t)e; }
             __syncthreads();
-            if (tid == 0) stdsort_prefix(sm.order, n, topN, keys32, sm.sort_stack);
+            if (tid < 64) stdsort_prefix_wave(sm.order, n, topN, keys32, sm.sort_stack, sm.lpos, sm.rpos, sm.leaf_f, sm.leaf_l);
             __syncthreads();
             if (tid < topN) {
                 const int e = sm.order[tid];
