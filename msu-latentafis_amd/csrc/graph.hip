@@ -1004,13 +1004,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
             for (int u = 0; u < TexSmem::U; ++u) {
                 const int t = lane + 64 * u;
                 m32[u] = t < num ? key32[t] : T;
-                dmax = max(dmax, (int)(m32[u] - T));                              // keys are >= T (the 200th largest) and share its sign: the difference is small and non-negative
-            }
-            dmax = g_wave_max(dmax);
-            const int shift = max(0, 26 - __clz(dmax | 1));                       // bin = (key - T) >> shift in [0, 63]
+                dmax = max(dmax, (int)((m32[u] - T) >> 1));                       // keys are >= T (the 200th largest): the difference is non-negative — but NOT small when the 200 row maxima have both signs
+            }                                                                     // (ordered keys of +3 and -3 are 2^31 + 2^23 apart): HALF of it is what fits an int.  Rounds 3-5 took the difference itself: negative
+            dmax = g_wave_max(dmax);                                              // for such lists, a zero shift, bins far beyond 63, counters scattered over the list's LDS and ranking loops of 2^31 trips (72 s per
+            const int shift = max(0, 27 - __clz(dmax | 1));                       // search of a 224-row latent against structured prints; results still right: the tie fallback re-ranks).  bin = (key - T) >> shift in [0, 63]
             int bin[TexSmem::U];
 #pragma unroll
-            for (int u = 0; u < TexSmem::U; ++u) bin[u] = (int)((m32[u] - T) >> shift);
+            for (int u = 0; u < TexSmem::U; ++u) bin[u] = min((int)((m32[u] - T) >> shift), 63);
             s_cnt[lane] = 0u;
             WSYNC();
 #pragma unroll

@@ -1497,3 +1497,36 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
     with pytest.raises(M.AfisError):
         m.set_option("s3_tie_order", 2)
     m.close()
+
+
+def test_texture_top200_with_row_maxima_of_both_signs(codebook_bytes, cb, oracle):
+    """S7 on a latent of 201 .. 256 texture rows whose row maxima have BOTH signs and magnitudes of a few units (prints whose descriptors point away from each other: structured
+    templates at identity weight 1.0; the top 200 of 224 rows then hold negative maxima too).  The ordered keys of +3 and -3 are more than 2^31 apart: rounds 3-5 took that difference
+    as an int when they binned the 200 keys for ranking — a negative number, bins far out of range, ranking loops of 2^31 trips: 72 s for one search (the results stayed right, the tie
+    fallback re-ranked).  Scores against the oracle, and the texture stage's time."""
+    SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
+    rng = np.random.default_rng(905)
+    SS.IDENTITY_WEIGHT = 1.0
+    try:
+        lats = [SS.make_structured_latent(rng, sigma=0.0095, n_tex_lo=200, n_tex_hi=260) for _ in range(2)]
+        gal = [SS.make_structured_rolled(rng, cb, sigma=0.0095, n_minu=int(rng.integers(20, 128)), n_tex=300) for _ in range(40)]
+    finally:
+        SS.IDENTITY_WEIGHT = 0.3
+    assert all(200 < L.tex[0].n <= 256 for L in lats)
+    m = M.Matcher(codebook_bytes, taps=True)
+    m.gallery_add(gal); m.gallery_commit(0)
+    ocb = oracle.codebook(codebook_bytes)
+    hl, hr = cases.to_orc(oracle, ocb, lats, gal)
+    both = 0
+    for qi, L in enumerate(lats):
+        res = m.search([L], k=0, want_parts=True); tm = m.timing()
+        assert tm["tex_tail_ms"] < 500.0, tm                                   # (72 000 ms before the fix)
+        rc, sc, parts = oracle.search(ocb, hl[qi], hr, tie_mode=1, want_parts=True)
+        got = np.concatenate([res["parts"][0], res["scores"][0][:, None]], axis=1)
+        assert np.array_equal(got.view(np.uint32), parts.view(np.uint32))
+        for gi in range(0, 40, 7):
+            val, _ = m.debug_texture_rowmax(L, gi)
+            top = np.sort(val)[-200:]
+            both += int(top.min() < -1.0 and top.max() > 1.0)
+    assert both >= 3, both                                                     # the lists DO hold row maxima of both signs
+    m.close()
