@@ -1500,10 +1500,12 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
 
 
 def test_texture_top200_with_row_maxima_of_both_signs(codebook_bytes, cb, oracle):
-    """S7 on a latent of 201 .. 256 texture rows whose row maxima have BOTH signs and magnitudes of a few units (prints whose descriptors point away from each other: structured
-    templates at identity weight 1.0; the top 200 of 224 rows then hold negative maxima too).  The ordered keys of +3 and -3 are more than 2^31 apart: rounds 3-5 took that difference
-    as an int when they binned the 200 keys for ranking — a negative number, bins far out of range, ranking loops of 2^31 trips: 72 s for one search (the results stayed right, the tie
-    fallback re-ranked).  Scores against the oracle, and the texture stage's time."""
+    """S7 on a latent of 201 .. 256 texture rows whose 200 best row maxima have BOTH signs and reach 2.0 (prints whose descriptors point away from each other: structured templates
+    at identity weight 1.0).  When exactly 200 rows pass the recomputation's bound test and some of their maxima are negative but above -2, the list kernel's bit-by-bit search for the
+    200th key stops at the coarse prefix 0x40000000 (count == 200 at bit 30), and a maximum >= 2.0 has an ordered key >= 0xC0000000: 2^31 or more above it.  Rounds 3-5 took that
+    difference as an int when they binned the 200 keys for ranking — a negative number, a zero shift, bins far out of range, counters scattered over the list's LDS, ranking loops of 2^31
+    trips: 72 s for one search (the results stayed right: the tie fallback re-ranked).  Scores against the oracle, the texture stage's time, and a host emulation of the search that
+    shows such lists are in the set."""
     SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
     rng = np.random.default_rng(905)
     SS.IDENTITY_WEIGHT = 1.0
@@ -1517,16 +1519,30 @@ def test_texture_top200_with_row_maxima_of_both_signs(codebook_bytes, cb, oracle
     m.gallery_add(gal); m.gallery_commit(0)
     ocb = oracle.codebook(codebook_bytes)
     hl, hr = cases.to_orc(oracle, ocb, lats, gal)
-    both = 0
+
+    def ordered_key(v):
+        u = np.asarray(v, np.float32).view(np.uint32).astype(np.uint64)
+        return np.where(u & 0x80000000, (~u) & 0xffffffff, u | 0x80000000)
+
+    def search_T(keys):                                                        # graph.hip::k_graph_texture: the 200th largest key, bit by bit, stopping early at an exact count
+        t = 0
+        for bit in range(31, -1, -1):
+            c = int((keys >= (t | (1 << bit))).sum())
+            if c >= 200:
+                t |= 1 << bit
+                if c == 200: break
+        return t
+
+    wide = 0
     for qi, L in enumerate(lats):
         res = m.search([L], k=0, want_parts=True); tm = m.timing()
         assert tm["tex_tail_ms"] < 500.0, tm                                   # (72 000 ms before the fix)
         rc, sc, parts = oracle.search(ocb, hl[qi], hr, tie_mode=1, want_parts=True)
         got = np.concatenate([res["parts"][0], res["scores"][0][:, None]], axis=1)
         assert np.array_equal(got.view(np.uint32), parts.view(np.uint32))
-        for gi in range(0, 40, 7):
-            val, _ = m.debug_texture_rowmax(L, gi)
-            top = np.sort(val)[-200:]
-            both += int(top.min() < -1.0 and top.max() > 1.0)
-    assert both >= 3, both                                                     # the lists DO hold row maxima of both signs
+        for gi in range(len(gal)):
+            val, _ = oracle.texture_rowmax(ocb, hl[qi], hr[gi])
+            keys = np.sort(ordered_key(val))[-200:]                            # (exactly the 200 best rows active: the common case for a 224-row latent)
+            wide += int(int(keys.max()) - search_T(keys) >= 2 ** 31)
+    assert wide >= 3, wide                                                     # lists whose largest key lies 2^31 or more above the search's threshold exist in this set
     m.close()
