@@ -16,8 +16,12 @@ G = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
 cbb = open(os.path.join(ROOT, "tests", "golden", "codebook_EmbeddingSize_96_stride_16_subdim_6.dat"), "rb").read(); cb = T.Codebook.from_bytes(cbb)
 wl = S.WORKLOADS[os.environ.get("AFIS_SWEEP_WORKLOAD", "headline")]                 # AFIS_SWEEP_WORKLOAD=wide: the off-envelope shapes of bench.py --workload wide
 m = M.Matcher(cbb)
+TIE = 1
+if os.environ.get("AFIS_SWEEP_S3_ORDER") == "1":                                     # option s3_tie_order 1 against the oracle's tie mode 4 (std::sort at S3, the stable order elsewhere)
+    m.set_option("s3_tie_order", 1); TIE = 4
 if os.environ.get("AFIS_SWEEP_WORKLOAD") == "structured":                            # AFIS_SWEEP_WORKLOAD=structured [AFIS_SWEEP_DUP=0|10|30]: templates with the structure of extracted prints (host/synth_structured.py)
     SS = importlib.import_module("msu-latentafis_amd.host.synth_structured"); sg = SS.DUP_SIGMA[int(os.environ.get("AFIS_SWEEP_DUP", "10"))]
+    if os.environ.get("AFIS_SWEEP_IDENTITY"): SS.IDENTITY_WEIGHT = float(os.environ["AFIS_SWEEP_IDENTITY"])       # 1.0: a twelfth of the minutiae lists is short of 120 positive similarities
     lats = SS.make_structured_latents(seed, Q, sigma=sg); gal = SS.make_packed_gallery_structured(seed, G, cb, sigma=sg, encode=m.pq_encode); SS.plant_structured_mates(seed, gal, cb, lats, G=G, sigma=sg)
     print("structured: share of texture points whose code vector occurs twice in their template:", round(SS.dup_share(gal.tex_codes, gal.tex_off), 4))
 else:
@@ -31,7 +35,7 @@ TIE0 = len(sys.argv) > 4
 t0 = time.time(); bad = 0; nz = 0; pos0 = bit0 = far0 = top0 = 0
 for qi, L in enumerate(lats):
     hl, _ = orc.latent(ocb, T.write_latent(L))
-    rc, sc, parts = orc.search(ocb, hl, hr, tie_mode=1, threads=orc.lib.orc_num_threads(), want_parts=True)
+    rc, sc, parts = orc.search(ocb, hl, hr, tie_mode=TIE, threads=orc.lib.orc_num_threads(), want_parts=True)
     got = np.concatenate([r["parts"][qi], r["scores"][qi][:, None]], axis=1)
     diff = got.view(np.uint32) != parts.view(np.uint32)
     bad += int(diff.any(axis=1).sum()); nz += int((parts[:, :4] > 0).sum())
@@ -49,7 +53,7 @@ for qi, L in enumerate(lats):
 tmr = m.timing()
 npos_pairs = int((r["scores"] > 0).sum())
 print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, {npos_pairs} pairs with a positive score, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
-print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_a_positive_score": npos_pairs, "dup": os.environ.get("AFIS_SWEEP_DUP"), "pairs_with_any_differing_bit": bad,
+print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "oracle_tie_mode": TIE, "s3_tie_order": int(TIE == 4), "identity_weight": os.environ.get("AFIS_SWEEP_IDENTITY"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_a_positive_score": npos_pairs, "dup": os.environ.get("AFIS_SWEEP_DUP"), "pairs_with_any_differing_bit": bad,
       "candidate_task_routing": {k: int(v) for k, v in tmr.items() if k.startswith("minu_") and k.endswith("tasks")}}))
 if TIE0:
     print(f"  vs tie_mode=0 (reference sort order): {pos0} positive pairs, {bit0} with a differing bit, {far0} beyond 1e-3, queries whose positive top-24 order changes: {top0}")
