@@ -991,7 +991,9 @@ hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scra
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MinuSmem));
     if (e != hipSuccess) return e;
     const int grid = (int)(n_tasks < n_wg ? n_tasks : n_wg);
-    hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), sizeof(MinuSmem), stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n,
+    // (the arrays of the std::sort restatement — 50 KB at the end of MinuSmem — are asked for only when the option is on: two workgroups per CU otherwise, as before)
+    const size_t smem = ref_tie_order ? sizeof(MinuSmem) : offsetof(MinuSmem, order);
+    hipLaunchKernelGGL(k_minu_cands, dim3(grid), dim3(kThreads), smem, stream, q, g, scratch, scratch_floats_per_wg, cands, cand_n,
                        force_generic ? (const int32_t*)nullptr : fallback, diag, ref_tie_order);
     return hipGetLastError();
 }
