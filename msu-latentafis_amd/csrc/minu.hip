@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
                                                          MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n,
                                                          const int32_t* __restrict__ fb /* NULL: every task; else fb[0] tasks listed in fb[1 ...] */,
                                                          unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row */,
-                                                         int ref_tie_order /* option s3_tie_order: equal norms in libstdc++'s std::sort order (stdsort_order.h) for tasks whose matrix fits LDS */)
+                                                         int ref_tie_order /* option s3_tie_order: equal norms in libstdc++'s std::sort order (stdsort_order.h) for tasks of up to 8192 similarities */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
             f = f - sv;
             return ord_f32((float)((double)sv / ((double)f + 0.000001)));                        // :467
         };
-        if (ref_tie_order && fast) {
+        if (ref_tie_order && n <= kFastN) {                                        // (any shape of up to 8192 similarities: the keys and the index array are what must fit LDS; the matrix may sit in global scratch)
             // The reference's own order of equal norms (matcher.cpp:473-476: std::sort of the indices 0 .. n-1 by norm, descending): every key of the task in LDS (the GEMM's
             // operand tiles are dead), the indices in order, and ONE lane runs libstdc++'s algorithm on them as far as the first 120 positions need it (stdsort_order.h).
             uint32_t* const keys32 = reinterpret_cast<uint32_t*>(sm.A);                           // A and B are contiguous: 38.4 KB >= 4 n bytes (n <= 8192)
