@@ -226,8 +226,8 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * workgroups (2.9 x); 6 = the same with 512; 0 = plain LDS gather, 1 = chain/row-quad rotated lanes, 2/3 = 0/1 with 1024-thread workgroups — are reference kernels built into libafis_hip_test.so only.
  * "mf_blocks" (form of variant 9's bound pass, bit-identical: 2 = two row blocks per wave, the only value of the product library; libafis_hip_test.so also takes 3), "bound_cus" (below), "query_batch" (latents per launch group),
  * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "s3_tie_order" (0 [default]: candidate norms that tie — in practice the zero norms that fill a list with fewer
- * than 120 positive similarities — are taken in ascending element order; 1: in the order libstdc++'s std::sort leaves them, i.e. what the reference binary's matcher.cpp:473-476 delivers, for pairs of at most 8192 similarities (latent x rolled minutiae):
- * such lists then go through the any-shape candidate kernel, one lane of which runs the sort — about 0.5 ms per affected list), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
+ * than 120 positive similarities — are taken in ascending element order; 1: in the order libstdc++'s std::sort leaves them, i.e. what the reference binary's matcher.cpp:473-476 delivers:
+ * such lists — and the rare list in which two positive norms tie — then go through the any-shape candidate kernel, one wave of which runs the sort; about +2 % of a search on structured templates), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
  * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded; "search_timeout_ms" sets the same bound in
  * milliseconds; afis_get_option reads "search_timeout_s" rounded UP to whole seconds and "search_timeout_ms" exactly.  After such a timeout the device may still be working on the call: the caller's output
  * buffers must stay valid until afis_destroy, or until a later call on the context succeeds; afis_queries_free then only parks the handle (its device buffers are released by the next call that finds the device idle),

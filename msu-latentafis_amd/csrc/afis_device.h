@@ -191,6 +191,13 @@ inline void launch_group_cuts(const long long* rows_prefix, int n, int per, bool
 }
 // ints of the candidate stage's control buffer: [fallback count | n_tasks fallback task ids | 8 control words | 3 G work-list entries]
 inline size_t minu_fb_ints(size_t n_tasks, size_t G) { return 1 + n_tasks + 8 + 3 * G; }
+// floats of global scratch one workgroup of k_minu_cands needs: simi[n] | keys[n] | rowsum[2048] | colsum[2048], n = the largest latent x rolled minutiae count of the launch
+// (rounded to 64); with option s3_tie_order three more arrays of n words (the index array std::sort permutes and the two pointers' stops: minu.hip)
+inline size_t minu_scratch_floats(int max_nL, int max_nR, int s3_tie_order)
+{
+    const size_t n = ((size_t)(max_nL > 1 ? max_nL : 1) * (size_t)(max_nR > 1 ? max_nR : 1) + 63) / 64 * 64;
+    return (s3_tie_order ? 5 : 2) * n + 4096;
+}
 // One row of 16 unsigned 64-bit diagnostics per launch group, zeroed at the start of a search and read back with its results (afis_timing):
 enum { kDiagFallback = 0,       // candidate tasks handed to the any-shape kernel
        kDiagSmall = 1,          // tasks done by k_minu_cands_rt<1>, <2>, <4> (kDiagSmall + class)

@@ -407,7 +407,7 @@ static int prepare_search_buffers(afis_ctx* ctx, const afis_queries* q, bool wan
             HIPCHK(ctx, ctx->cand_n.ensure(n_pairs * 3 * 4));
             HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(n_pairs * 3, (size_t)G) * 4));
             {   // the generic candidate kernel's scratch (sized as in the loop below, for the longest latent minutiae template of the search)
-                const size_t per_wg = 2 * (((size_t)nL_max * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+                const size_t per_wg = minu_scratch_floats(nL_max, ctx->max_nR, ctx->s3_tie_order);
                 int n_wg = 1024;
                 while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
                 HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
@@ -517,7 +517,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             if (ctx->adc_variant == 9) { HIPCHK(ctx, ctx->rm_cv.ensure(std::max<size_t>(n_pairs * lt_cap * 4, 16))); HIPCHK(ctx, ctx->rm_n.ensure(std::max<size_t>(n_pairs * 4, 16))); }
             HIPCHK(ctx, ctx->parts.ensure(parts ? (size_t)nq_all * G * 16 : n_pairs * 16));
             // minutiae scratch per workgroup: simi[n] | keys[n] | rowsum[2048] | colsum[2048]  (only pairs the fast kernel cannot take use it)
-            size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+            size_t per_wg = minu_scratch_floats(grp.max_nL, ctx->max_nR, ctx->s3_tie_order);
             int n_wg = 1024;
             while (n_wg > 64 && per_wg * 4 * n_wg > (8ull << 30)) n_wg /= 2;
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
@@ -707,7 +707,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
     DevBuf d_xy, d_n;
     auto body = [&]() -> int {
         if (status[0] != AFIS_QUERY_OK) return AFIS_OK;                    // matcher.cpp:383-386: nothing is matched, nothing written
-        const size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+        const size_t per_wg = minu_scratch_floats(grp.max_nL, ctx->max_nR, ctx->s3_tie_order);
         const int n_wg = 64;
         HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * n_wg));
         HIPCHK(ctx, ctx->cands.ensure((size_t)n * 3 * kTopMinu * sizeof(MinuCand)));

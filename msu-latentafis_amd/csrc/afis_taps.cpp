@@ -155,7 +155,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
                                              d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
         } else {
             slot = which - 1; cap = kTopMinu;
-            const size_t per_wg = 2 * (((size_t)std::max(1, grp.max_nL) * std::max(1, ctx->max_nR) + 63) / 64 * 64) + 4096;
+            const size_t per_wg = minu_scratch_floats(grp.max_nL, ctx->max_nR, ctx->s3_tie_order);
             HIPCHK(ctx, ctx->scratch.ensure(per_wg * 4 * 64));
             HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12)); HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(3, 1) * 4));
             HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, ctx->minu_generic | (ctx->s3_tie_order << 1), ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, nullptr, s));

@@ -83,9 +83,9 @@ struct MinuSmem {
 // and insertion moves an element left only past strictly smaller keys).  The depth-limit branch (heap sort) and the median of three stay with lane 0.
 #define SSO_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 __device__ __forceinline__ int sso_lane_prefix(u64 mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
-__device__ int sso_partition_wave(const SsoCtx& c, int f, int l, uint16_t* lpos, uint16_t* rpos)
+template <typename I> __device__ int sso_partition_wave(const SsoCtx<I>& c, int f, int l, I* lpos, I* rpos)
 {
-    uint16_t* A = c.A;
+    I* A = c.A;
     const int lane = threadIdx.x & 63;
     if (lane == 0) {                                                                // __move_median_to_first(first, first + 1, mid, last - 1)
         const int a = f + 1, b = f + (l - f) / 2, cc = l - 1;
@@ -106,8 +106,8 @@ __device__ int sso_partition_wave(const SsoCtx& c, int f, int l, uint16_t* lpos,
         const uint32_t k = in ? c.key[A[p]] : 0u;
         const bool sl = in && k <= pk, sr = in && k >= pk;
         const u64 ml = __ballot(sl), mr = __ballot(sr);
-        if (sl) lpos[nl + sso_lane_prefix(ml)] = (uint16_t)p;
-        if (sr) rpos[nr + sso_lane_prefix(mr)] = (uint16_t)p;
+        if (sl) lpos[nl + sso_lane_prefix(ml)] = (I)p;
+        if (sr) rpos[nr + sso_lane_prefix(mr)] = (I)p;
         nl += (int)__popcll(ml); nr += (int)__popcll(mr);
     }
     SSO_WSYNC();
@@ -121,18 +121,18 @@ __device__ int sso_partition_wave(const SsoCtx& c, int f, int l, uint16_t* lpos,
         if (cnt < 64) break;
     }
     for (int i = lane; i < m; i += 64) {
-        const int pl = lpos[i], pr = rpos[nr - 1 - i];
-        const uint16_t x = A[pl], y = A[pr];
+        const int pl = (int)lpos[i], pr = (int)rpos[nr - 1 - i];
+        const I x = A[pl], y = A[pr];
         A[pl] = y; A[pr] = x;
     }
     int cut = m < nl ? (int)lpos[m] : 0x7fffffff;
-    if (m > 0) { const int r = rpos[nr - m]; cut = r < cut ? r : cut; }
+    if (m > 0) { const int r = (int)rpos[nr - m]; cut = r < cut ? r : cut; }
     SSO_WSYNC();
     return cut;
 }
-__device__ void stdsort_prefix_wave(uint16_t* A, int n, int K, const uint32_t* key, int* stack, uint16_t* lpos, uint16_t* rpos, uint16_t* leaf_f, uint16_t* leaf_l)
+template <typename I> __device__ void stdsort_prefix_wave(I* A, int n, int K, const uint32_t* key, int* stack, I* lpos, I* rpos, uint16_t* leaf_f, uint16_t* leaf_l)
 {
-    const SsoCtx c{A, key};
+    const SsoCtx<I> c{A, key};
     const int lane = threadIdx.x & 63;
     if (n < 2) return;
     if (K > n) K = n;
@@ -144,8 +144,9 @@ __device__ void stdsort_prefix_wave(uint16_t* A, int n, int K, const uint32_t* k
         int f = stack[3 * sp], l = stack[3 * sp + 1], d = stack[3 * sp + 2];        // uniform: every lane reads the same words
         SSO_WSYNC();                                                                // (read before lane 0 may push over them)
         if (f >= K) continue;
+        bool by_heap = false;
         while (l - f > 16) {
-            if (d == 0) { if (lane == 0) sso_heap_sort(c, f, l); SSO_WSYNC(); break; }
+            if (d == 0) { if (lane == 0) sso_heap_sort(c, f, l); SSO_WSYNC(); by_heap = true; break; }
             --d;
             const int cut = sso_partition_wave(c, f, l, lpos, rpos);
             if (lane == 0) { stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; }
@@ -153,13 +154,14 @@ __device__ void stdsort_prefix_wave(uint16_t* A, int n, int K, const uint32_t* k
             SSO_WSYNC();
             l = cut;
         }
-        if (l > f && n_leaf < 256) { if (lane == 0) { leaf_f[n_leaf] = (uint16_t)f; leaf_l[n_leaf] = (uint16_t)l; } ++n_leaf; }
+        if (l > f && !by_heap && n_leaf < 256) {      // (a heap-sorted range is in order: the insertion sort would move nothing; every other leaf ends below 120 + 16)
+            if (lane == 0) { leaf_f[n_leaf] = (uint16_t)f; leaf_l[n_leaf] = (uint16_t)l; } ++n_leaf; }
     }
     SSO_WSYNC();
     for (int b = lane; b < n_leaf; b += 64) {                                       // the final insertion sort, one lane per leaf range
         const int lf = leaf_f[b], ll = leaf_l[b];
         for (int i = lf + 1; i < ll; ++i) {
-            const uint16_t val = A[i];
+            const I val = A[i];
             int j = i;
             while (j > lf && sso_before(c, val, A[j - 1])) { A[j] = A[j - 1]; --j; }
             A[j] = val;
@@ -168,12 +170,12 @@ __device__ void stdsort_prefix_wave(uint16_t* A, int n, int K, const uint32_t* k
     SSO_WSYNC();
 }
 
-// Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048]
+// Global scratch of one workgroup (pairs too large for the LDS fast path): simi[n] | keys[n] | rowsum[2048] | colsum[2048] (| order[n] | lpos[n] | rpos[n] with option s3_tie_order)
 __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev g, float* __restrict__ scratch, size_t scratch_per_wg,
                                                          MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n,
                                                          const int32_t* __restrict__ fb /* NULL: every task; else fb[0] tasks listed in fb[1 ...] */,
                                                          unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row */,
-                                                         int ref_tie_order /* option s3_tie_order: equal norms in libstdc++'s std::sort order (stdsort_order.h) for tasks of up to 8192 similarities */)
+                                                         int ref_tie_order /* option s3_tie_order: equal norms in libstdc++'s std::sort order (stdsort_order.h) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     MinuSmem& sm = *reinterpret_cast<MinuSmem*>(smem_raw);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
         const int n = nL * nR;
         PHASE_INIT();
         const bool fast = nL <= kFastL && nR <= kFastR;
-        const size_t half = (scratch_per_wg - 4096) >> 1;
+        const size_t half = (scratch_per_wg - 4096) / (ref_tie_order ? 5 : 2);     // afis_device.h::minu_scratch_floats(): option s3_tie_order adds three index arrays of n words
         float* simi = fast ? sm.simi : gscr;
         uint32_t* gkeys = reinterpret_cast<uint32_t*>(gscr + half);
         float* rowsum = fast ? sm.rowsum : gscr + 2 * half;
@@ -277,17 +279,24 @@ __global__ __launch_bounds__(kThreads) void k_minu_cands(QueryDev q, GalleryDev 
             f = f - sv;
             return ord_f32((float)((double)sv / ((double)f + 0.000001)));                        // :467
         };
-        if (ref_tie_order && n <= kFastN) {                                        // (any shape of up to 8192 similarities: the keys and the index array are what must fit LDS; the matrix may sit in global scratch)
-            // The reference's own order of equal norms (matcher.cpp:473-476: std::sort of the indices 0 .. n-1 by norm, descending): every key of the task in LDS (the GEMM's
-            // operand tiles are dead), the indices in order, and ONE lane runs libstdc++'s algorithm on them as far as the first 120 positions need it (stdsort_order.h).
-            uint32_t* const keys32 = reinterpret_cast<uint32_t*>(sm.A);                           // A and B are contiguous: 38.4 KB >= 4 n bytes (n <= 8192)
+        if (ref_tie_order) {
+            // The reference's own order of equal norms (matcher.cpp:473-476: std::sort of the indices 0 .. n-1 by norm, descending): every key of the task and the indices in
+            // order, and ONE wave runs libstdc++'s algorithm on them as far as the first 120 positions need it (stdsort_order.h).  Up to 8192 similarities the arrays sit in LDS
+            // (the keys in the GEMM's dead operand tiles; the matrix itself may be in global scratch), beyond that in the workgroup's global scratch with 32-bit indices.
+            const bool in_lds = n <= kFastN;
+            uint32_t* const keys32 = in_lds ? reinterpret_cast<uint32_t*>(sm.A) : gkeys;          // A and B are contiguous: 38.4 KB >= 4 n bytes (n <= 8192)
             static_assert(sizeof(sm.A) + sizeof(sm.B) >= sizeof(uint32_t) * kFastN && offsetof(MinuSmem, B) == sizeof(sm.A), "the keys reuse the GEMM's operand tiles");
-            for (int e = tid; e < n; e += kThreads) { keys32[e] = norm_key(e); sm.order[e] = (uint16_t)e; }
+            uint32_t* const gord = reinterpret_cast<uint32_t*>(gscr + 2 * half + 4096);
+            if (in_lds) for (int e = tid; e < n; e += kThreads) { keys32[e] = norm_key(e); sm.order[e] = (uint16_t)e; }
+            else        for (int e = tid; e < n; e += kThreads) { keys32[e] = norm_key(e); gord[e] = (uint32_t)e; }
             __syncthreads();
-            if (tid < 64) stdsort_prefix_wave(sm.order, n, topN, keys32, sm.sort_stack, sm.lpos, sm.rpos, sm.leaf_f, sm.leaf_l);
+            if (tid < 64) {
+                if (in_lds) stdsort_prefix_wave<uint16_t>(sm.order, n, topN, keys32, sm.sort_stack, sm.lpos, sm.rpos, sm.leaf_f, sm.leaf_l);
+                else        stdsort_prefix_wave<uint32_t>(gord, n, topN, keys32, sm.sort_stack, gord + half, gord + 2 * half, sm.leaf_f, sm.leaf_l);
+            }
             __syncthreads();
             if (tid < topN) {
-                const int e = sm.order[tid];
+                const int e = in_lds ? (int)sm.order[tid] : (int)gord[tid];
                 const int i1 = e / nR, i2 = e - i1 * nR;
                 MinuCand c; c.sim = simi[e]; c.li = (short)i1; c.ri = (short)i2;
                 cands[(size_t)task * kTopMinu + tid] = c;
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                                                                 const int32_t* __restrict__ work /* rolled templates with tasks of this class */,
                                                                 int32_t* __restrict__ ctl /* ctl[c]: entries of work[]; ctl[4 + c]: the draw counter */,
                                                                 unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row (afis_device.h) */,
-                                                                int ref_tie_order /* option s3_tie_order: lists short of 120 positive norms go to the any-shape kernel, which orders their tied zeros as std::sort does */)
+                                                                int ref_tie_order /* option s3_tie_order: lists short of 120 positive norms, and lists in which positive norms tie, go to the any-shape kernel, which orders equal norms as std::sort does */)
 {
     typedef RtCfg<S> Cfg;
     constexpr int kT = Cfg::kT, kW = Cfg::kW, kSimi = Cfg::kSimi, kCls = S == 1 ? 0 : S == 2 ? 1 : 2;
@@ -536,6 +545,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
     const int n_tickets = n_work * n_split;
     // Rolled templates are DRAWN from a counter, not dealt by stride: the kernel may start on the part of the chip the (CU-masked) bound pass leaves free and spread
     // over the rest when that finishes (afis_search.cpp, option bound_cus): workgroups that start late must not find a fixed share of the work waiting for them.
+    if (tid == 0) sm.pad_[1] = 0;                                                    // option s3_tie_order: "this list holds equal norms" (set in the ranking, consumed after the task's last barrier)
     for (;;) {
         if (tid == 0) sm.ticket = atomicAdd(&ctl[4 + kCls], 1);
         __syncthreads();
@@ -911,6 +921,16 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                     MinuCand cd; cd.sim = sm.simi[ci * ld + cj2]; cd.li = (short)ci; cd.ri = (short)cj2;
                     cands[(size_t)task * kTopMinu + r] = cd;
                 }
+                if (ref_tie_order && r <= kTopMinu) {                                // (uniform flag, the option only) equal POSITIVE norms in or at the end of the list — one list in 10^5 — are ordered by
+                    // libstdc++'s sort as well: the same walk counting the strictly larger NORMS; a difference = a candidate of the same norm and a lower element index in front of this one
+                    const u64 mine_top = mine | 0xffffull;
+                    int gcount = lo;
+                    for (int k = lo; k < hi; k += 8) {
+                        const ulonglong2 k0 = c2[(k >> 1)], k1 = c2[(k >> 1) + 1], k2 = c2[(k >> 1) + 2], k3 = c2[(k >> 1) + 3];
+                        gcount += (int)(k0.x > mine_top) + (int)(k0.y > mine_top) + (int)(k1.x > mine_top) + (int)(k1.y > mine_top) + (int)(k2.x > mine_top) + (int)(k2.y > mine_top) + (int)(k3.x > mine_top) + (int)(k3.y > mine_top);
+                    }
+                    if (gcount != r) sm.pad_[1] = 1;
+                }
             }
             if (fill && wave == 0) {                                                 // ranks n_c .. 119: the first zero similarities in element order (n >= 512 entries, fewer than 120 of them positive: there are enough)
                 int rank = n_c;
@@ -928,6 +948,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             ++n_done;
 #if AFIS_MC_ABLATE != 3                                                  // (3: timing experiment only — no barrier at the end of a task: what dropping it could give at most)
             RT_SYNC();
+            if (ref_tie_order && tid == 0 && sm.pad_[1] != 0) { sm.pad_[1] = 0; to_fallback(task); }   // the any-shape kernel redoes this list in the reference's sort order (it runs after this kernel, on the same stream)
 #endif
             PHASE(20);
         }

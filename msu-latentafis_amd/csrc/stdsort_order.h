@@ -4,7 +4,8 @@
 // norm[a] > norm[b]) and keeps the first 120.  Where norms tie, which index comes first is whatever libstdc++'s introsort does with the whole array — and ties
 // are not rare where it matters: a (latent, rolled) pair with fewer than 120 POSITIVE similarities fills its list with zero-norm entries, all tied (every tiny
 // latent template; 0.4 % of the lists of the structured workload: tools/tie_site_sweep.py).  The library's default orders tied entries by ascending element index;
-// with the option on, the any-shape candidate kernel (minu.hip::k_minu_cands) runs THIS restatement instead and delivers the list the reference binary delivers.
+// with the option on, the any-shape candidate kernel (minu.hip::k_minu_cands) runs THIS restatement instead and delivers the list the reference binary delivers
+// (index type I = uint16_t with the arrays in LDS up to 8192 similarities, uint32_t with the arrays in the workgroup's global scratch beyond).
 //
 // What is restated (the published algorithm of libstdc++'s <bits/stl_algo.h>, unchanged since GCC 4; written from its description, not copied):
 //   sort            = introsort loop with depth limit 2 floor(log2 n), then a final insertion sort
@@ -17,7 +18,7 @@
 // are skipped — the work is about 2 n element steps instead of n log n.
 //
 // tests/test_host.py::test_stdsort_order_equals_libstdcxx compiles this header on the host and compares it with std::sort itself (random and tie-heavy arrays,
-// every n up to 300 and a sample up to 8192, forced depth limits for the heap-sort branch).
+// every n up to 300, a sample up to 8192 with 16-bit indices and up to 400 000 with 32-bit ones, forced depth limits for the heap-sort branch).
 #pragma once
 #include <stdint.h>
 
@@ -30,14 +31,14 @@
 namespace afis {
 
 // comp(a, b) == key[a] > key[b]: "a sorts before b" (descending keys), as the reference's lambda
-struct SsoCtx { uint16_t* A; const uint32_t* key; };
-SSO_FN bool sso_before(const SsoCtx& c, uint16_t a, uint16_t b) { return c.key[a] > c.key[b]; }
-SSO_FN void sso_swap(uint16_t* A, int i, int j) { const uint16_t t = A[i]; A[i] = A[j]; A[j] = t; }
+template <typename I> struct SsoCtx { I* A; const uint32_t* key; };   // I: uint16_t (arrays in LDS, n <= 65535) or uint32_t (arrays in global scratch)
+template <typename I> SSO_FN bool sso_before(const SsoCtx<I>& c, I a, I b) { return c.key[a] > c.key[b]; }
+template <typename I> SSO_FN void sso_swap(I* A, int i, int j) { const I t = A[i]; A[i] = A[j]; A[j] = t; }
 
 // __adjust_heap + __push_heap on the range starting at `f` (positions relative to f), "less" = sso_before
-SSO_FN void sso_adjust_heap(const SsoCtx& c, int f, int hole, int len, uint16_t value)
+template <typename I> SSO_FN void sso_adjust_heap(const SsoCtx<I>& c, int f, int hole, int len, I value)
 {
-    uint16_t* A = c.A + f;
+    I* A = c.A + f;
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -60,7 +61,7 @@ SSO_FN void sso_adjust_heap(const SsoCtx& c, int f, int hole, int len, uint16_t 
     A[hole] = value;
 }
 // __partial_sort(first, last, last) = make_heap + sort_heap: the depth-limit branch
-SSO_FN void sso_heap_sort(const SsoCtx& c, int f, int l)
+template <typename I> SSO_FN void sso_heap_sort(const SsoCtx<I>& c, int f, int l)
 {
     const int len = l - f;
     if (len < 2) return;
@@ -70,14 +71,14 @@ SSO_FN void sso_heap_sort(const SsoCtx& c, int f, int l)
     }
     for (int last = l; last - f > 1;) {
         --last;
-        const uint16_t value = c.A[last];
+        const I value = c.A[last];
         c.A[last] = c.A[f];
         sso_adjust_heap(c, f, 0, last - f, value);
     }
 }
-SSO_FN int sso_partition_pivot(const SsoCtx& c, int f, int l)
+template <typename I> SSO_FN int sso_partition_pivot(const SsoCtx<I>& c, int f, int l)
 {
-    uint16_t* A = c.A;
+    I* A = c.A;
     const int mid = f + (l - f) / 2;
     const int a = f + 1, b = mid, cc = l - 1;                              // __move_median_to_first(first, first + 1, mid, last - 1)
     if (sso_before(c, A[a], A[b])) {
@@ -88,7 +89,7 @@ SSO_FN int sso_partition_pivot(const SsoCtx& c, int f, int l)
     else if (sso_before(c, A[b], A[cc])) sso_swap(A, f, cc);
     else sso_swap(A, f, b);
     int first = f + 1, last = l;                                          // __unguarded_partition(first + 1, last, pivot = *first)
-    const uint16_t pivot = A[f];
+    const I pivot = A[f];
     for (;;) {
         while (sso_before(c, A[first], pivot)) ++first;
         --last;
@@ -103,9 +104,9 @@ SSO_FN int sso_partition_pivot(const SsoCtx& c, int f, int l)
 // written.  So the stops are those of the ORIGINAL array: left stops L_1 < L_2 < ... = the positions of (first + 1, last) whose key is <= the pivot's, right stops
 // R_1 > R_2 > ... = those whose key is >= the pivot's; swap i exchanges L_i and R_i while L_i < R_i (say m swaps); and the partition point is
 // min(L_{m+1}, R_m) (R_m now holds a left-stop element; R_0 = nothing).  lpos / rpos: scratch of (last - first) entries each.
-SSO_FN int sso_partition_pivot_closed(const SsoCtx& c, int f, int l, uint16_t* lpos, uint16_t* rpos)
+template <typename I> SSO_FN int sso_partition_pivot_closed(const SsoCtx<I>& c, int f, int l, I* lpos, I* rpos)
 {
-    uint16_t* A = c.A;
+    I* A = c.A;
     const int mid = f + (l - f) / 2;
     const int a = f + 1, b = mid, cc = l - 1;
     if (sso_before(c, A[a], A[b])) {
@@ -119,8 +120,8 @@ SSO_FN int sso_partition_pivot_closed(const SsoCtx& c, int f, int l, uint16_t* l
     int nl = 0, nr = 0;
     for (int p = f + 1; p < l; ++p) {
         const uint32_t k = c.key[A[p]];
-        if (k <= pk) lpos[nl++] = (uint16_t)p;                              // !before(A[p], pivot): the left pointer stops here
-        if (k >= pk) rpos[nr++] = (uint16_t)p;                              // !before(pivot, A[p]): the right pointer stops here (ascending; the i-th from the right is rpos[nr - i])
+        if (k <= pk) lpos[nl++] = (I)p;                              // !before(A[p], pivot): the left pointer stops here
+        if (k >= pk) rpos[nr++] = (I)p;                              // !before(pivot, A[p]): the right pointer stops here (ascending; the i-th from the right is rpos[nr - i])
     }
     int m = 0;
     while (m < nl && m < nr && lpos[m] < rpos[nr - 1 - m]) ++m;
@@ -135,9 +136,9 @@ SSO_FN int sso_floor_log2(int n) { int k = 0; while (n > 1) { n >>= 1; ++k; } re
 // A[0 .. n) = a permutation (normally 0 .. n-1 in order); afterwards A[0 .. min(K, n)) is what std::sort(A, A + n, comp) leaves there.
 // stack: 3 * 64 ints of scratch (first, last, depth of the pending right parts; the depth limit bounds its use by 2 log2 n <= 26 entries).
 // depth0 < 0: the real limit; tests pass small values to reach the heap-sort branch.
-SSO_FN void stdsort_prefix(uint16_t* A, int n, int K, const uint32_t* key, int* stack, int depth0 = -1)
+template <typename I> SSO_FN void stdsort_prefix(I* A, int n, int K, const uint32_t* key, int* stack, int depth0 = -1)
 {
-    const SsoCtx c{A, key};
+    const SsoCtx<I> c{A, key};
     if (n < 2) return;
     if (K > n) K = n;
     int sp = 0;
@@ -160,7 +161,7 @@ SSO_FN void stdsort_prefix(uint16_t* A, int n, int K, const uint32_t* key, int* 
     }
     // __final_insertion_sort over the processed prefix (what lies beyond it cannot move into it)
     for (int i = 1; i < kend; ++i) {
-        const uint16_t val = A[i];
+        const I val = A[i];
         int j = i;
         while (j > 0 && sso_before(c, val, A[j - 1])) { A[j] = A[j - 1]; --j; }
         A[j] = val;

@@ -1451,8 +1451,9 @@ def test_structured_templates_against_oracle(codebook_bytes, cb, oracle):
 
 def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
     """Option s3_tie_order 1: where candidate norms tie, the list of 120 is the one libstdc++'s std::sort leaves (matcher.cpp:473-476 sorts the nL x nR indices with a non-strict
-    comparator) — csrc/stdsort_order.h run by the any-shape candidate kernel — instead of ascending element index.  It matters for lists with fewer than 120 POSITIVE similarities
+    comparator) — csrc/stdsort_order.h run by the any-shape candidate kernel (arrays in LDS up to 8192 similarities, in global scratch beyond) — instead of ascending element index.  It matters for lists with fewer than 120 POSITIVE similarities
     (the zeros that fill the list are all tied): tiny latent templates, and prints whose descriptors point away from each other (structured templates at identity weight 1.0).
+    Equal POSITIVE norms inside a full list (two rolled minutiae with the same descriptor) are ordered the same way: the fast kernel detects them while ranking and hands the list over.
     The oracle's tie mode 4 takes std::sort at S3 and the stable order elsewhere: per-part and fused scores and the S3 lists bit for bit; and the test is not vacuous — the
     default order (tie mode 1) gives other scores on some of the pairs."""
     SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
@@ -1463,8 +1464,33 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
         lats.append(SS.make_structured_latent(rng, sigma=0.0095, n_tex_lo=200, n_tex_hi=260, n_minu_lo=3, n_minu_hi=6))          # tiny lists: nL x nR / 2 < 120 against small rolled prints
         gal = [SS.make_structured_mate(rng, cb, L, frac=0.6, sigma=0.0095, n_minu=int(rng.integers(40, 120)), n_tex=320) for L in lats[:3]]
         while len(gal) < 60: gal.append(SS.make_structured_rolled(rng, cb, sigma=0.0095, n_minu=int(rng.integers(20, 128)), n_tex=300))
+        # pairs BEYOND 8192 similarities with short lists (the arrays of the restatement sit in global scratch there, 32-bit indices): rolled prints of 400 minutiae whose
+        # descriptors point away from latent 0's — every similarity clamps to zero — except two or three rows copied from it (2 nL or 3 nL positive similarities, fewer than 120)
+        n_big = 0
+        for k_copy in (2, 3, 0):
+            R = SS.make_structured_rolled(rng, cb, sigma=0.0095, n_minu=400, n_tex=300)
+            src = np.concatenate([lats[0].minu[s_].des for s_ in (26, 2, 11)])
+            u = src.mean(axis=0); u /= np.linalg.norm(u)
+            des = -u[None, :] * 1.2 + 0.02 * rng.standard_normal(R.minu[0].des.shape)
+            des[rng.choice(400, k_copy, replace=False)] = src[rng.choice(len(src), k_copy, replace=False)]
+            R.minu[0].des[:] = des.astype(np.float32)
+            gal.append(R)
+        # equal POSITIVE norms inside full lists (met once in 180 000 lists of the sweeps): rolled prints of 100 minutiae, 60 of them near latent 0's descriptors, two pairs of them identical
+        # (same similarities, same column sums: the norms of (i, 4) and (i, 11) are the same float for every latent row i)
+        for _ in range(3):
+            R = SS.make_structured_rolled(rng, cb, sigma=0.0095, n_minu=100, n_tex=300)
+            d = R.minu[0].des
+            d[:60] = (src[rng.choice(len(src), 60)] + 0.3 * rng.standard_normal((60, d.shape[1]))).astype(np.float32)
+            d[11] = d[4]; d[37] = d[20]
+            gal.append(R)
     finally:
         SS.IDENTITY_WEIGHT = 0.3
+    for s_ in (26, 2, 11):
+        for R in gal[63:]: assert int(((lats[0].minu[s_].des @ R.minu[0].des.T) > 0).sum()) >= 1000       # full lists: not the zero-fill mechanism
+        for R in gal[60:63]:
+            npos = int(((lats[0].minu[s_].des @ R.minu[0].des.T) > 0).sum())
+            n_big += int(lats[0].minu[s_].n * 400 > 8192 and npos < 120)
+    assert n_big >= 6, n_big
     m = M.Matcher(codebook_bytes, taps=True)
     m.gallery_add(gal); m.gallery_commit(0)
     base = m.search(lats, k=0, want_parts=True)
@@ -1474,7 +1500,7 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
     assert tm["minu_fallback_tasks"] > 0
     ocb = oracle.codebook(codebook_bytes)
     hl, hr = cases.to_orc(oracle, ocb, lats, gal)
-    n_moved = n_short = 0
+    n_moved = n_short = n_big_moved = 0
     for qi in range(len(lats)):
         rc, sc4, p4 = oracle.search(ocb, hl[qi], hr, tie_mode=4, want_parts=True)
         rc, sc1, p1 = oracle.search(ocb, hl[qi], hr, tie_mode=1, want_parts=True)
@@ -1487,13 +1513,17 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
         for s_ in (26, 2, 11):
             for R in gal: n_short += int(((lats[qi].minu[s_].des @ R.minu[0].des.T) > 0).sum() < min(120, lats[qi].minu[s_].n * R.minu[0].n))
     assert n_short >= 20 and n_moved >= 3, (n_short, n_moved)
-    for qi, gi in ((0, 5), (3, 7), (3, 20), (1, 33)):                                       # the S3 lists themselves
+    for qi, gi in ((0, 5), (3, 7), (3, 20), (1, 33), (0, 60), (0, 61), (0, 62), (0, 63), (0, 64), (0, 65)):   # the S3 lists themselves
         for which in (1, 2, 3):
             want = oracle.trace(ocb, hl[qi], hr[gi], which=which, stage=0, tie_mode=4)
             gotl = m.debug_stage_list(lats[qi], gi, which, 0)
             assert (want is None) == (gotl is None)
             if want is None: continue
             assert np.array_equal(gotl[1], want[1]) and np.array_equal(gotl[2], want[2]), (qi, gi, which)
+            if gi >= 60:                                                                    # ... and on the large pairs and the lists with equal positive norms it is not the ascending-index list
+                w1 = oracle.trace(ocb, hl[qi], hr[gi], which=which, stage=0, tie_mode=1)
+                n_big_moved += int(not (np.array_equal(w1[1], want[1]) and np.array_equal(w1[2], want[2])))
+    assert n_big_moved >= 10, n_big_moved
     with pytest.raises(M.AfisError):
         m.set_option("s3_tie_order", 2)
     m.close()

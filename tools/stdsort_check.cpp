@@ -10,12 +10,12 @@
 
 static long checked = 0, bad = 0;
 
-static void one(const std::vector<uint32_t>& key, int K, int depth)
+template <typename I> static void one_t(const std::vector<uint32_t>& key, int K, int depth)
 {
     const int n = (int)key.size();
-    std::vector<uint16_t> a(n), b(n);
+    std::vector<I> a(n), b(n);
     std::iota(a.begin(), a.end(), 0); b = a;
-    auto comp = [&key](uint16_t x, uint16_t y) { return key[x] > key[y]; };
+    auto comp = [&key](I x, I y) { return key[x] > key[y]; };
     if (depth < 0) std::sort(a.begin(), a.end(), comp);
     else if (n > 1) {                                                    // the same algorithm with a forced depth limit (libstdc++'s own internals)
         std::__introsort_loop(a.begin(), a.end(), (long)depth, __gnu_cxx::__ops::__iter_comp_iter(comp));
@@ -28,6 +28,8 @@ static void one(const std::vector<uint32_t>& key, int K, int depth)
         if (a[i] != b[i]) { if (bad < 5) fprintf(stderr, "mismatch: n %d K %d depth %d at %d: %u vs %u\n", n, K, depth, i, a[i], b[i]); ++bad; return; }
 }
 
+static void one(const std::vector<uint32_t>& key, int K, int depth) { one_t<uint16_t>(key, K, depth); }
+
 // the closed form of the partition (what the device's wave executes in parallel) against the pointer walk, on the same array
 static void partition_forms(const std::vector<uint32_t>& key)
 {
@@ -36,7 +38,7 @@ static void partition_forms(const std::vector<uint32_t>& key)
     std::vector<uint16_t> a(n), b(n), lp(n), rp(n);
     std::iota(a.begin(), a.end(), 0);
     std::mt19937 r2(n * 7 + 1); std::shuffle(a.begin(), a.end(), r2); b = a;
-    const afis::SsoCtx ca{a.data(), key.data()}, cb{b.data(), key.data()};
+    const afis::SsoCtx<uint16_t> ca{a.data(), key.data()}, cb{b.data(), key.data()};
     const int c1 = afis::sso_partition_pivot(ca, 0, n), c2 = afis::sso_partition_pivot_closed(cb, 0, n, lp.data(), rp.data());
     ++checked;
     if (c1 != c2 || a != b) { if (bad < 5) fprintf(stderr, "partition forms differ: n %d cut %d vs %d\n", n, c1, c2); ++bad; }
@@ -70,6 +72,15 @@ int main()
         if (rep % 5 == 0) for (int i = 0; i < n; ++i) if (rng() % 3 == 0) key[i] = 1 + rng() % 50;    // many positive ties as well
         one(key, 120, -1); partition_forms(key);
         if (rep % 40 == 0) { one(key, n, -1); one(key, 120, 3); one(key, 120, 5); }
+    }
+    for (int rep = 0; rep < 24; ++rep) {                                 // pairs beyond 8192 similarities: 32-bit indices (the device keeps these arrays in global scratch)
+        const int n = 8193 + rng() % (rep < 20 ? 60000 : 400000);
+        std::vector<uint32_t> key(n, 0);
+        const int pos = rng() % 130;
+        for (int i = 0; i < pos; ++i) key[rng() % n] = 1 + rng() % 100000;
+        if (rep % 4 == 0) for (int i = 0; i < n; ++i) if (rng() % 3 == 0) key[i] = 1 + rng() % 50;
+        one_t<uint32_t>(key, 120, -1);
+        if (rep % 8 == 0) { one_t<uint32_t>(key, 120, 4); one_t<uint32_t>(key, n, -1); }
     }
     printf("stdsort_order: %ld comparisons with libstdc++, %ld mismatches\n", checked, bad);
     return bad ? 1 : 0;
