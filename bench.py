@@ -255,7 +255,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--tile-share", type=int, default=0)
     ap.add_argument("--bound-cus", type=int, default=-1, help="CUs the bound pass is confined to, the minutiae stage running beside it on the others (-1 = the library's default, 128; 0 = one stream, kernels back to back)")
-    ap.add_argument("--s3-tie-order", type=int, default=0, choices=[0, 1], help="option s3_tie_order: 1 = candidate norms that tie in libstdc++'s std::sort order, as the reference binary (lists short of 120 positive similarities go through the any-shape kernel); NOT the headline setting")
+    ap.add_argument("--s3-tie-order", type=int, default=0, choices=[0, 1, 2], help="option s3_tie_order: 1 = candidate norms that tie in libstdc++'s std::sort order, as the reference binary (lists short of 120 positive similarities go through the any-shape kernel); NOT the headline setting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--score-stats", action="store_true", help="after the timed region: the share of non-mate pairs with a positive score (always reported for --workload structured)")
     ap.add_argument("--no-alone", action="store_true", help="skip the extra back-to-back steps after the timed region (roofline.alone_on_the_chip): for profiler runs, whose per-kernel averages they would mix into")
@@ -334,7 +334,7 @@ def main():
     if a.chunk > 0: m.set_option("chunk", a.chunk)
     if a.tile_share > 0: m.set_option("tile_share", a.tile_share)
     if a.bound_cus >= 0: m.set_option("bound_cus", a.bound_cus)
-    if a.s3_tie_order: m.set_option("s3_tie_order", 1)
+    if a.s3_tie_order: m.set_option("ref_tie_order", a.s3_tie_order)      # 1 = s3_tie_order 1; 2 = the greedy selections of S8 / S9 in std::sort's order as well
     bound_cus = m.get_option("bound_cus") if (a.variant < 0 or a.variant == 9) else 0
     if a.share_gpu and world > 1:                          # test mode: the ranks share one device, and each would otherwise budget its launch groups from all of its free memory
         m.set_option("rowmax_budget_mb", max(1024, int(0.5 * torch.cuda.mem_get_info(gpu)[1] / world) >> 20))

@@ -144,6 +144,7 @@ int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
     else if (n == "tile_share") *value = ctx->tile_share;
     else if (n == "minu_generic") *value = ctx->minu_generic;
     else if (n == "s3_tie_order") *value = ctx->s3_tie_order;
+    else if (n == "ref_tie_order") *value = ctx->s3_tie_order + ctx->s89_tie_order;
     else if (n == "minu_fast_max_latent") *value = rt_class_max_latent(4);            // read-only: what the fast candidate kernel's largest shape class takes (afis_device.h: rt_max_rows)
     else if (n == "minu_fast_max_rolled") *value = rt_class_max_rolled(4);
     else if (n == "minu_fast_max_cells") *value = rt_class_simi_floats(4);
@@ -172,7 +173,8 @@ int afis_set_option(afis_ctx* ctx, const char* name, int64_t value)
     else if (n == "query_batch") { if (value < 0 || value > 256) return fail(ctx, AFIS_EINVAL, "query_batch must be 0 (auto) or 1..256"); ctx->query_batch = (int)value; }
     else if (n == "chunk") { if (value < 0 || value > 65536) return fail(ctx, AFIS_EINVAL, "chunk must be 0 (auto) or 1..65536"); ctx->chunk = (int)value; }
     else if (n == "minu_generic") { ctx->minu_generic = value ? 1 : 0; }
-    else if (n == "s3_tie_order") { if (value != 0 && value != 1) return fail(ctx, AFIS_EINVAL, "s3_tie_order must be 0 (equal candidate norms by ascending element index) or 1 (in the order libstdc++'s std::sort leaves them)"); ctx->s3_tie_order = (int)value; }
+    else if (n == "s3_tie_order") { if (value != 0 && value != 1) return fail(ctx, AFIS_EINVAL, "s3_tie_order must be 0 (equal candidate norms by ascending element index) or 1 (in the order libstdc++'s std::sort leaves them)"); ctx->s3_tie_order = (int)value; ctx->s89_tie_order = 0; }
+    else if (n == "ref_tie_order") { if (value < 0 || value > 2) return fail(ctx, AFIS_EINVAL, "ref_tie_order must be 0 (equal sort keys by ascending index), 1 (candidate norms in the order libstdc++'s std::sort leaves them: = s3_tie_order 1) or 2 (the scores of the greedy selections of S8 and S9 as well)"); ctx->s3_tie_order = value >= 1; ctx->s89_tie_order = value >= 2; }
     else if (n == "mf_stats") { ctx->mf_collect_stats = value ? 1 : 0; }
     else if (n == "search_timeout_s") { ctx->search_timeout_s = (double)value; }        // <= 0: unbounded hipStreamSynchronize
     else if (n == "search_timeout_ms") { ctx->search_timeout_s = (double)value * 1e-3; }

@@ -115,6 +115,7 @@ struct afis_ctx {
     int chunk = 0;                       // gallery templates per ADC workgroup; 0 = by gallery size
     int minu_generic = 0;
     int s3_tie_order = 0;                // 1: equal candidate norms in the order libstdc++'s std::sort leaves them (matcher.cpp:476); 0: ascending element index
+    int s89_tie_order = 0;               // 1 (option ref_tie_order 2): the greedy selections of S8 and S9 walk equal scores in std::sort's order too (graph.hip::sort_scores)
     double search_timeout_s = 600.0;     // bound on every host wait of a search (AFIS_SEARCH_TIMEOUT_S; <= 0: plain hipStreamSynchronize, unbounded)
     int64_t planned_group_bytes = 0;     // per-group buffers the largest launch group uploaded so far will take (group_budget_bytes of OTHER contexts on the device leaves room for it)
     std::vector<afis_queries*> parked_queries;   // query groups a timed-out search may still be reading: freed by drain_abandoned() once the device is back (afis_queries_free parks them here)

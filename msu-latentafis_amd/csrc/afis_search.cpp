@@ -550,7 +550,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             auto minutiae_stage = [&]() -> int {
                 HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic | (ctx->s3_tie_order << 1), ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, s));
                 HIPCHK(ctx, hipEventRecord(ev[7], s));
-                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2, s));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2 | (ctx->s89_tie_order << 8), s));
                 return AFIS_OK;
             };
             if (overlap) {
@@ -568,17 +568,17 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
                 HIPCHK(ctx, launch_minu_cands(d, g, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic | (ctx->s3_tie_order << 1), ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, diag_row, sh));
                 HIPCHK(ctx, hipMemsetAsync(g.task_ctr + 1, 0, 4, sh));                     // the list counter both instances of the list kernel draw from: reset BEFORE either may start
                 HIPCHK(ctx, hipEventRecord(ev[7], sh));
-                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2, sh, true));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2 | (ctx->s89_tie_order << 8), sh, true));
                 HIPCHK(ctx, hipEventRecord(ev[4], sh));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[6], 0));
                 HIPCHK(ctx, hipEventRecord(ev[8], s));                                     // the bound pass is done
                 rc9 = adc_refine_mfma(ctx, grp, false, true);
                 if (rc9 != AFIS_OK) return rc9;
                 HIPCHK(ctx, hipEventRecord(ev[2], s));
-                if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), grp_parts, nullptr, nullptr, 2, s));
+                if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), ctx->rm_cv.as<float>(), ctx->rm_n.as<int32_t>(), grp_parts, nullptr, nullptr, 2 | (ctx->s89_tie_order << 8), s));
                 HIPCHK(ctx, hipEventRecord(ev[3], s));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[7], 0));                              // every candidate list exists: help with whatever lists are left
-                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2, s, true));
+                HIPCHK(ctx, launch_graph_minutiae(d, g, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), grp_parts, nullptr, nullptr, nullptr, nullptr, 2 | (ctx->s89_tie_order << 8), s, true));
                 HIPCHK(ctx, hipStreamWaitEvent(s, ev[4], 0));
                 // No host wait here: the groups of a search follow one another on the three streams through events alone, and the search's final wait polls ALL THREE streams
                 // (wait_streams).  Round 4 blocked on the two side streams after every group because hipStreamSynchronize of the context's stream alone never returned with
@@ -606,7 +606,7 @@ int afis_search_resident(afis_ctx* ctx, afis_queries* q, float* scores, float* p
             }
             HIPCHK(ctx, hipEventRecord(ev[2], s));
             if (!skip_tex_tail) HIPCHK(ctx, launch_graph_texture(d, g, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), compact9 ? ctx->rm_cv.as<float>() : nullptr,
-                                             compact9 ? ctx->rm_n.as<int32_t>() : nullptr, grp_parts, nullptr, nullptr, 2, s));
+                                             compact9 ? ctx->rm_n.as<int32_t>() : nullptr, grp_parts, nullptr, nullptr, 2 | (ctx->s89_tie_order << 8), s));
             HIPCHK(ctx, hipEventRecord(ev[3], s));
             { int rcm = minutiae_stage(); if (rcm != AFIS_OK) return rcm; }
             HIPCHK(ctx, hipEventRecord(ev[4], s));
@@ -726,7 +726,7 @@ int afis_correspondences(afis_ctx* ctx, const afis_template_view* query, const i
             int32_t* cand_n = ctx->cand_n.as<int32_t>() + (size_t)i * 3;
             if (launch_minu_cands(grp.dev, one, ctx->scratch.as<float>(), per_wg, n_wg, ctx->minu_generic | (ctx->s3_tie_order << 1), cands, cand_n, ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, nullptr, s) != hipSuccess ||
                 launch_graph_minutiae(grp.dev, one, cands, cand_n, ctx->parts.as<float>() + (size_t)i * 4,
-                                      d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, nullptr, nullptr, 2, s) != hipSuccess)
+                                      d_xy.as<short4>() + (size_t)i * 3 * kTopMinu, d_n.as<int32_t>() + (size_t)i * 3, nullptr, nullptr, 2 | (ctx->s89_tie_order << 8), s) != hipSuccess)
                 err = fail(ctx, AFIS_EDEVICE, "afis_correspondences: kernel launch failed");
         }
         if (err == AFIS_OK) {

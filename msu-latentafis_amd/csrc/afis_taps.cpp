@@ -152,7 +152,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             HIPCHK(ctx, launch_lut_build(d, ctx->codewords.as<float>(), ctx->lut.as<float>(), av, s));
             HIPCHK(ctx, launch_adc_rowmax(d, one, ctx->lut.as<float>(), 32, av, ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), s));
             HIPCHK(ctx, launch_graph_texture(d, one, ctx->table.as<float>(), ctx->rm_val.as<float>(), ctx->rm_arg.as<int32_t>(), nullptr, nullptr, ctx->parts.as<float>(),
-                                             d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
+                                             d_out.as<MinuCand>(), d_n.as<int32_t>(), stage | (ctx->s89_tie_order << 8), s));
         } else {
             slot = which - 1; cap = kTopMinu;
             const size_t per_wg = minu_scratch_floats(grp.max_nL, ctx->max_nR, ctx->s3_tie_order);
@@ -160,7 +160,7 @@ int afis_debug_stage_list(afis_ctx* ctx, const afis_template_view* query, int64_
             HIPCHK(ctx, ctx->cands.ensure(3 * (size_t)kTopMinu * sizeof(MinuCand))); HIPCHK(ctx, ctx->cand_n.ensure(12)); HIPCHK(ctx, ctx->minu_fb.ensure(minu_fb_ints(3, 1) * 4));
             HIPCHK(ctx, launch_minu_cands(d, one, ctx->scratch.as<float>(), per_wg, 64, ctx->minu_generic | (ctx->s3_tie_order << 1), ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->minu_fb.as<int32_t>(), grp.max_nL, ctx->max_nR, nullptr, s));
             HIPCHK(ctx, launch_graph_minutiae(d, one, ctx->cands.as<MinuCand>(), ctx->cand_n.as<int32_t>(), ctx->parts.as<float>(), nullptr, nullptr,
-                                              d_out.as<MinuCand>(), d_n.as<int32_t>(), stage, s));
+                                              d_out.as<MinuCand>(), d_n.as<int32_t>(), stage | (ctx->s89_tie_order << 8), s));
         }
         std::vector<MinuCand> h((size_t)3 * kTopTex); int32_t hn[3] = {-1, -1, -1};
         HIPCHK(ctx, hipMemcpyAsync(h.data(), d_out.p, h.size() * sizeof(MinuCand), hipMemcpyDeviceToHost, s));

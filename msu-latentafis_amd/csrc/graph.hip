@@ -26,6 +26,7 @@
 #include <type_traits>
 #include "atan2f_libm.h"
 #include "graph_arith.h"
+#include "stdsort_order.h"
 
 namespace afis {
 
@@ -166,8 +167,11 @@ __device__ __forceinline__ int next_task(int32_t* ctr)
 // The ordered 32-bit keys are dealt into 64 bins of equal width between the smallest and the largest (counting sort through LDS counters, highest bin
 // first); a key counts the larger keys of ITS bin only and adds the bins above it.  Equal scores make ranks collide, which the sum of the ranks shows (a
 // permutation of 0 .. num-1 sums to num (num-1) / 2): the (key, ~index) composites are ranked against every other one only then.
+// ref_tie (option ref_tie_order 2): where scores that can still be SELECTED (>= thr: the greedy walk stops at the first one below) tie, the order is the one libstdc++'s std::sort
+// leaves (matcher.cpp:1301 / :1423 / :1590 sort the indices with a non-strict comparator) instead of ascending index: lane 0 runs the restatement of stdsort_order.h on the whole
+// array (rare lists only: equal scores below thr — isolated candidates, all zero — do not count, and up to 16 entries std::sort is an insertion sort, which IS the ascending order).
 template <class SM>
-__device__ __forceinline__ void sort_scores(SM& sm, int num)
+__device__ __forceinline__ void sort_scores(SM& sm, int num, double thr = 0.0, int ref_tie = 0)
 {
     const int lane = threadIdx.x;
     constexpr int U = SM::U;
@@ -182,6 +186,21 @@ __device__ __forceinline__ void sort_scores(SM& sm, int num)
         WSYNC();
         int rr = 0;
         for (int k = 0; k < num; ++k) rr += sm.x.s.keys[k] > mine;
+        if (ref_tie && num > 16) {                                            // (uniform)
+            int gg = 0;                                                       // the strictly larger SCORES: fewer than rr = an equal score with a lower index in front of this one
+            for (int k = 0; k < num; ++k) gg += (uint32_t)(sm.x.s.keys[k] >> 32) > (uint32_t)(mine >> 32);
+            const bool tied = lane < num && gg != rr && !((double)sm.b[lane] < thr);
+            if (__ballot(tied) != 0ull) {
+                uint32_t* const k32 = reinterpret_cast<uint32_t*>(sm.x.s.keys) + 96;          // behind the 48 composites: 48 keys, then the sort's stack
+                static_assert(sizeof(sm.x.s.keys) >= (96 + 48 + 48) * 4, "no room for the keys and the stack of the std::sort restatement");
+                WSYNC();
+                if (lane < num) { k32[lane] = (uint32_t)(mine >> 32); sm.y.os.order[lane] = (short)lane; }
+                WSYNC();
+                if (lane == 0) stdsort_prefix<uint16_t>(reinterpret_cast<uint16_t*>(sm.y.os.order), num, num, k32, reinterpret_cast<int*>(k32 + 48));
+                WSYNC();
+                return;
+            }
+        }
         WSYNC();
         if (lane < num) sm.y.os.order[rr] = (short)lane;
         WSYNC();
@@ -231,12 +250,27 @@ __device__ __forceinline__ void sort_scores(SM& sm, int num)
     }
     if (g_wave_sum(rsum) != num * (num - 1) / 2) {                            // equal scores: rank the (key, ~index) composites
         u64 mine[U];
+        int gg[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? ((u64)m32[u] << 32) | (uint32_t)(~(uint32_t)t) : 0ull; r[u] = 0; }
+        for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; mine[u] = t < num ? ((u64)m32[u] << 32) | (uint32_t)(~(uint32_t)t) : 0ull; r[u] = 0; gg[u] = 0; }
         for (int k = 0; k < num; ++k) {
             const u64 kk = ((u64)s_key[k] << 32) | (uint32_t)(~(uint32_t)k);
 #pragma unroll
-            for (int u = 0; u < U; ++u) r[u] += kk > mine[u];
+            for (int u = 0; u < U; ++u) { r[u] += kk > mine[u]; gg[u] += s_key[k] > m32[u]; }
+        }
+        if (ref_tie) {                                                        // (uniform) a tie among scores that can be selected: the reference's order = std::sort's
+            bool tied = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; tied |= t < num && gg[u] != r[u] && !((double)sm.b[t] < thr); }
+            if (__ballot(tied) != 0ull) {
+                WSYNC();                                                      // s_gkey (= cc, which order[] aliases) has been read by every lane
+#pragma unroll
+                for (int u = 0; u < U; ++u) { const int t = lane + 64 * u; if (t < num) sm.y.os.order[t] = (short)t; }
+                WSYNC();
+                if (lane == 0) stdsort_prefix<uint16_t>(reinterpret_cast<uint16_t*>(sm.y.os.order), num, num, s_key, reinterpret_cast<int*>(s_cnt));   // s_cnt: 128 words, dead; the stack takes 3 (2 log2 num + 1) <= 48
+                WSYNC();
+                return;
+            }
         }
     }
     WSYNC();
@@ -434,7 +468,7 @@ __device__ __forceinline__ float h_value(float dist)
 // S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
 // MODE 0: generic arithmetic; 1: packed 16-bit coordinates (texture: with the |d| < 50 test); 2: texture, every coordinate in [0, 49]
 template <class SM, bool LOOKUP, int ITERS, int MODE>
-__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ ext)
+__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ ext, int ref_tie)
 {
     constexpr bool fast = MODE > 0;
     constexpr bool range_test = MODE == 1;
@@ -728,7 +762,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
         WSYNC();
     }
     GPH(PH + 1);
-    sort_scores(sm, num);
+    sort_scores(sm, num, 0.0001, ref_tie);
     GPH(PH + 2);
     const int nsel = greedy(sm, num, 0.0001, [&sm, table, dist_fast](int a, int o) {
         if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
@@ -784,7 +818,7 @@ __device__ __forceinline__ bool angle_compatible(const Pt& p1, float lo1, float 
 // latent and rolled template (global memory), indexed by the correspondences' point indices; only the survivors of the distance
 // stage need them.
 template <class SM>
-__device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori)
+__device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori, int ref_tie)
 {
     constexpr int W = SM::W;
     [[maybe_unused]] constexpr int PH = SM::NMAX > 128 ? 8 : 0;
@@ -859,7 +893,7 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
         WSYNC();
     }
     GPH(PH + 5);
-    sort_scores(sm, num);
+    sort_scores(sm, num, 0.001, ref_tie);
     const int nsel = greedy(sm, num, 0.001, [&sm](int a, int o) { return (sm.hb[a][o >> 5] >> (o & 31)) & 1u; });
     compact(sm, nsel);
     GPH(PH + 6);
@@ -873,10 +907,12 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
 {
     n_survivors = num;                                                     // stop_after 0: the candidate list itself (S3 / S7)
     if (stop_after == 0) return 0.0f;
+    const int ref_tie = mode >> 4;                                         // bit 4 of mode: option ref_tie_order 2 (sort_scores)
+    mode &= 15;
     // instantiations rather than flags inside the loops: the register budget is that of the path taken
-    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2>(sm, num, table, ext);
-    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table, ext);
-    else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table, ext);
+    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2>(sm, num, table, ext, ref_tie);
+    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table, ext, ref_tie);
+    else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table, ext, ref_tie);
     n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
     if (mode >= 1) {                                                       // the survivors' points back to 16-bit integers: what S9 and the correspondence export read
         for (int t = threadIdx.x; t < num; t += 64) {
@@ -890,7 +926,7 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
     if (stop_after == 1) return 0.0f;
     n_survivors = 0;
     if (num < 2) return 0.0f;
-    num = angle_filter(sm, num, lori, rori);
+    num = angle_filter(sm, num, lori, rori, ref_tie);
     n_survivors = num;                                                     // li/ri/xy[0..num) (+ similarities) = corr3 in the reference's order
     // :508-514 / :775-781: the sum of the survivors' similarities in list order.  They are gathered into b[] first (one parallel
     // round trip when they come from global memory) and added up sequentially from LDS.
@@ -902,7 +938,7 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
 }
 
 // parity tap (tests only): the list a task holds after stage `stage` (0 = candidates, 1 = after S8, 2 = after S9)
-struct GraphTap { MinuCand* out; int32_t* n; int stage; };
+struct GraphTap { MinuCand* out; int32_t* n; int stage; int ref_tie; };   // ref_tie: option ref_tie_order 2 (bit 8 of the launchers' tap_stage word)
 template <class SM>
 __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, const float* __restrict__ ext, long long task, int n, int cap)
 {
@@ -1083,7 +1119,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
         GPH_K(15);                                                       // S7 + list build
         int n_surv;
         const float* const row_max = (rm_n ? rm_cv : rm_val) + o;           // the array the entries' slots index
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, row_max, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
+        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, row_max, n_surv, tap.out ? tap.stage : 2, mode | (tap.ref_tie << 4));   // :759, :767
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, row_max, task, n_surv, kTopTex);
         WSYNC();
@@ -1100,7 +1136,7 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
     const int grid = (int)(n_tasks < 16384 ? n_tasks : 16384);
     hipError_t e0 = hipMemsetAsync(g.task_ctr + 0, 0, 4, stream);
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, rm_cv, rm_n, parts, GraphTap{tap_out, tap_n, tap_stage});
+    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, rm_cv, rm_n, parts, GraphTap{tap_out, tap_n, tap_stage & 255, (tap_stage >> 8) & 1});
     return hipGetLastError();
 }
 
@@ -1162,7 +1198,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_MINU_WA
         WSYNC();
         GPH_K(7);                                                        // list load
         int n_surv;
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, nullptr, n_surv, tap.out ? tap.stage : 2, mode);   // :492, :495
+        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, nullptr, n_surv, tap.out ? tap.stage : 2, mode | (tap.ref_tie << 4));   // :492, :495
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, nullptr, task, n_surv, kTopMinu);
         if (corr_out) {
@@ -1187,7 +1223,7 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
     hipError_t e0 = join ? hipSuccess : hipMemsetAsync(g.task_ctr + 1, 0, 4, stream);
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, GraphTap{tap_out, tap_n, tap_stage});
+    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, GraphTap{tap_out, tap_n, tap_stage & 255, (tap_stage >> 8) & 1});
     return hipGetLastError();
 }
 

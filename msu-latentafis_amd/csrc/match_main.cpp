@@ -227,7 +227,7 @@ int main(int argc, char** argv)
 {
     ArgParser args(argc, argv);
     if (args.cmdOptionExists("-h") || args.cmdOptionExists("--help")) {
-        std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>] [-pack <gallery container to write>]\n       -g may name a packed gallery container instead of a directory\n";
+        std::cout << "usage: match -l <latent.dat> | -ldir <latent dir>  -g <gallery dir>  -s <score dir>/  -c <codebook.dat>  [-d <device>] [-corr <prefix>] [-pack <gallery container to write>] [-tie <0|1|2>]\n       -tie: the order of equal sort keys — 0 ascending index (default), 1 candidate norms as libstdc++'s std::sort leaves them, 2 the scores of the greedy selections as well (the reference binary's scores)\n       -g may name a packed gallery container instead of a directory\n";
         return 0;
     }
     const auto config = read_flat_json((fs::current_path().parent_path() / "afis.config").string());
@@ -257,6 +257,13 @@ int main(int argc, char** argv)
     if (int rc = afis_create_from_codebook(&ctx, cb.data(), cb.size(), device); rc != AFIS_OK) {
         std::cerr << "match: afis_create failed (" << rc << "): " << afis_last_error(nullptr) << std::endl;
         return 2;
+    }
+    if (args.cmdOptionExists("-tie")) {                                          // option ref_tie_order (include/afis_matcher.h): 2 = equal keys in the order the reference binary's std::sort leaves them
+        if (int rc = afis_set_option(ctx, "ref_tie_order", atoi(args.getCmdOption("-tie").c_str())); rc != AFIS_OK) {
+            std::cerr << "match: -tie: " << afis_last_error(ctx) << std::endl;
+            afis_destroy(ctx);
+            return 2;
+        }
     }
 
     if (job.multi) {

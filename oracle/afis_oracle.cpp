@@ -83,14 +83,14 @@ typedef std::tuple<float, int, int> Corr;  // (similarity, latent idx, rolled id
 
 // ---- sorting helper -------------------------------------------------------------------------
 // site: which of the reference's sorts this is — 1 = S3 (:476), 2 = S7 (:741), 4 = S8's selection (:1301, :1423), 8 = S9's (:1590).  Tie modes 2..5 take the
-// reference's std::sort at SOME sites and the stable order at the others (2: S9; 3: S8 + S9; 4: S3; 5: S7; 6: S3 + S7; 7: S3 + S8; 8: S3 + S9): they exist to measure which site's tie order moves scores
+// reference's std::sort at SOME sites and the stable order at the others (2: S9; 3: S8 + S9; 4: S3; 5: S7; 6: S3 + S7; 7: S3 + S8; 8: S3 + S9; 9: S3 + S8 + S9 = what the HIP path delivers with option ref_tie_order 2): they exist to measure which site's tie order moves scores
 // (tools/tie_site_sweep.py).  Mode 4 is also what the HIP path implements with option s3_tie_order 1 (csrc/stdsort_order.h): the GPU tests compare that option with it bit for bit.
 enum { kSiteS3 = 1, kSiteS7 = 2, kSiteS8 = 4, kSiteS9 = 8 };
 template <class Cmp>
 void sort_idx(std::vector<int>& y, Cmp cmp, int tie_mode, int site)
 {
     const int t = tie_mode & 15;
-    const int unstable_sites = t == 0 ? 15 : t == 2 ? kSiteS9 : t == 3 ? (kSiteS8 | kSiteS9) : t == 4 ? kSiteS3 : t == 5 ? kSiteS7 : t == 6 ? (kSiteS3 | kSiteS7) : t == 7 ? (kSiteS3 | kSiteS8) : t == 8 ? (kSiteS3 | kSiteS9) : 0;
+    const int unstable_sites = t == 0 ? 15 : t == 2 ? kSiteS9 : t == 3 ? (kSiteS8 | kSiteS9) : t == 4 ? kSiteS3 : t == 5 ? kSiteS7 : t == 6 ? (kSiteS3 | kSiteS7) : t == 7 ? (kSiteS3 | kSiteS8) : t == 8 ? (kSiteS3 | kSiteS9) : t == 9 ? (kSiteS3 | kSiteS8 | kSiteS9) : 0;
     if (unstable_sites & site) std::sort(y.begin(), y.end(), cmp);
     else std::stable_sort(y.begin(), y.end(), cmp);
 }

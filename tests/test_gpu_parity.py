@@ -1526,6 +1526,34 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
     assert n_big_moved >= 10, n_big_moved
     with pytest.raises(M.AfisError):
         m.set_option("s3_tie_order", 2)
+    # ref_tie_order 2: the greedy selections of S8 and S9 (matcher.cpp:1301 / :1423 / :1590) walk equal SCORES in std::sort's order too (graph.hip::sort_scores) — the oracle's tie
+    # mode 9.  That is where the MATES are: a mated pair keeps dozens of correspondences whose S9 scores (boolean H, uniform start vector) tie exactly.
+    m.set_option("ref_tie_order", 2)
+    assert m.get_option("ref_tie_order") == 2 and m.get_option("s3_tie_order") == 1
+    res = m.search(lats, k=0, want_parts=True)
+    n_moved89 = 0
+    for qi in range(len(lats)):
+        rc, sc9, p9 = oracle.search(ocb, hl[qi], hr, tie_mode=9, want_parts=True)
+        rc, sc4, p4 = oracle.search(ocb, hl[qi], hr, tie_mode=4, want_parts=True)
+        got = np.concatenate([res["parts"][qi], res["scores"][qi][:, None]], axis=1)
+        diff = got.view(np.uint32) != p9.view(np.uint32)
+        assert not diff.any(), (qi, np.argwhere(diff)[:4], got[diff][:4], p9[diff][:4])
+        moved = (p9.view(np.uint32) != p4.view(np.uint32)).any(axis=1)
+        n_moved89 += int(moved.sum())
+        if qi < 3: assert moved[qi], qi                                                     # the planted mate of latent qi is gallery template qi
+    assert n_moved89 >= 3, n_moved89
+    for qi, gi in ((0, 0), (1, 1), (2, 2)):                                                # the survivors of S8 and of S9 on the mates
+        for which in (0, 1, 2, 3):
+            for stage in (1, 2):
+                want = oracle.trace(ocb, hl[qi], hr[gi], which=which, stage=stage, tie_mode=9)
+                gotl = m.debug_stage_list(lats[qi], gi, which, stage)
+                assert (want is None) == (gotl is None)
+                if want is None: continue
+                assert np.array_equal(gotl[1], want[1]) and np.array_equal(gotl[2], want[2]), (qi, gi, which, stage)
+    m.set_option("s3_tie_order", 1)
+    assert m.get_option("ref_tie_order") == 1
+    with pytest.raises(M.AfisError):
+        m.set_option("ref_tie_order", 3)
     m.close()
 
 

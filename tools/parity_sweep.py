@@ -19,6 +19,8 @@ m = M.Matcher(cbb)
 TIE = 1
 if os.environ.get("AFIS_SWEEP_S3_ORDER") == "1":                                     # option s3_tie_order 1 against the oracle's tie mode 4 (std::sort at S3, the stable order elsewhere)
     m.set_option("s3_tie_order", 1); TIE = 4
+if os.environ.get("AFIS_SWEEP_S3_ORDER") == "2":                                     # option ref_tie_order 2 against tie mode 9 (std::sort at S3, S8 and S9)
+    m.set_option("ref_tie_order", 2); TIE = 9
 if os.environ.get("AFIS_SWEEP_WORKLOAD") == "structured":                            # AFIS_SWEEP_WORKLOAD=structured [AFIS_SWEEP_DUP=0|10|30]: templates with the structure of extracted prints (host/synth_structured.py)
     SS = importlib.import_module("msu-latentafis_amd.host.synth_structured"); sg = SS.DUP_SIGMA[int(os.environ.get("AFIS_SWEEP_DUP", "10"))]
     if os.environ.get("AFIS_SWEEP_IDENTITY"): SS.IDENTITY_WEIGHT = float(os.environ["AFIS_SWEEP_IDENTITY"])       # 1.0: a twelfth of the minutiae lists is short of 120 positive similarities
@@ -53,7 +55,7 @@ for qi, L in enumerate(lats):
 tmr = m.timing()
 npos_pairs = int((r["scores"] > 0).sum())
 print(f"seed {seed}: {Q} x {G} pairs, {nz} non-zero part scores, {npos_pairs} pairs with a positive score, pairs with any differing bit: {bad}  (oracle {time.time() - t0:.1f} s)")
-print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "oracle_tie_mode": TIE, "s3_tie_order": int(TIE == 4), "identity_weight": os.environ.get("AFIS_SWEEP_IDENTITY"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_a_positive_score": npos_pairs, "dup": os.environ.get("AFIS_SWEEP_DUP"), "pairs_with_any_differing_bit": bad,
+print("SWEEP_JSON " + __import__("json").dumps({"workload": os.environ.get("AFIS_SWEEP_WORKLOAD", "headline"), "oracle_tie_mode": TIE, "ref_tie_order": {1: 0, 4: 1, 9: 2}[TIE], "identity_weight": os.environ.get("AFIS_SWEEP_IDENTITY"), "seed": seed, "Q": Q, "G": G, "pairs": Q * G, "non_zero_part_scores": nz, "pairs_with_a_positive_score": npos_pairs, "dup": os.environ.get("AFIS_SWEEP_DUP"), "pairs_with_any_differing_bit": bad,
       "candidate_task_routing": {k: int(v) for k, v in tmr.items() if k.startswith("minu_") and k.endswith("tasks")}}))
 if TIE0:
     print(f"  vs tie_mode=0 (reference sort order): {pos0} positive pairs, {bit0} with a differing bit, {far0} beyond 1e-3, queries whose positive top-24 order changes: {top0}")
