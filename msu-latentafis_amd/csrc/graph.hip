@@ -170,8 +170,8 @@ __device__ __forceinline__ int next_task(int32_t* ctr)
 // ref_tie (option ref_tie_order 2): where scores that can still be SELECTED (>= thr: the greedy walk stops at the first one below) tie, the order is the one libstdc++'s std::sort
 // leaves (matcher.cpp:1301 / :1423 / :1590 sort the indices with a non-strict comparator) instead of ascending index: lane 0 runs the restatement of stdsort_order.h on the whole
 // array (rare lists only: equal scores below thr — isolated candidates, all zero — do not count, and up to 16 entries std::sort is an insertion sort, which IS the ascending order).
-template <class SM>
-__device__ __forceinline__ void sort_scores(SM& sm, int num, double thr = 0.0, int ref_tie = 0)
+template <class SM, int ref_tie>
+__device__ __forceinline__ void sort_scores(SM& sm, int num, double thr)
 {
     const int lane = threadIdx.x;
     constexpr int U = SM::U;
@@ -467,8 +467,8 @@ __device__ __forceinline__ float h_value(float dist)
 
 // S8a (LOOKUP = false, 5 iterations) / S8b (LOOKUP = true, 3 iterations).  Returns the number of survivors (compacted in place).
 // MODE 0: generic arithmetic; 1: packed 16-bit coordinates (texture: with the |d| < 50 test); 2: texture, every coordinate in [0, 49]
-template <class SM, bool LOOKUP, int ITERS, int MODE>
-__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ ext, int ref_tie)
+template <class SM, bool LOOKUP, int ITERS, int MODE, int REF_TIE>
+__device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ ext)
 {
     constexpr bool fast = MODE > 0;
     constexpr bool range_test = MODE == 1;
@@ -762,7 +762,7 @@ __device__ int dist_filter(SM& sm, int num, const float* __restrict__ table, con
         WSYNC();
     }
     GPH(PH + 1);
-    sort_scores(sm, num, 0.0001, ref_tie);
+    sort_scores<SM, REF_TIE>(sm, num, 0.0001);
     GPH(PH + 2);
     const int nsel = greedy(sm, num, 0.0001, [&sm, table, dist_fast](int a, int o) {
         if (!((sm.hb[a][o >> 5] >> (o & 31)) & 1u)) return false;      // H == 0 < 1e-5
@@ -817,8 +817,8 @@ __device__ __forceinline__ bool angle_compatible(const Pt& p1, float lo1, float 
 // S9, matcher.cpp:1471-1636.  Returns the number of survivors (compacted in place).  lori / rori: orientation arrays of the
 // latent and rolled template (global memory), indexed by the correspondences' point indices; only the survivors of the distance
 // stage need them.
-template <class SM>
-__device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori, int ref_tie)
+template <class SM, int REF_TIE>
+__device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, const float* __restrict__ rori)
 {
     constexpr int W = SM::W;
     [[maybe_unused]] constexpr int PH = SM::NMAX > 128 ? 8 : 0;
@@ -893,7 +893,7 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
         WSYNC();
     }
     GPH(PH + 5);
-    sort_scores(sm, num, 0.001, ref_tie);
+    sort_scores<SM, REF_TIE>(sm, num, 0.001);
     const int nsel = greedy(sm, num, 0.001, [&sm](int a, int o) { return (sm.hb[a][o >> 5] >> (o & 31)) & 1u; });
     compact(sm, nsel);
     GPH(PH + 6);
@@ -901,18 +901,16 @@ __device__ int angle_filter(SM& sm, int num, const float* __restrict__ lori, con
 }
 
 // both graph stages + the final sum; a list of fewer than 2 correspondences cannot survive S9 (a single node ends with S = 0)
-template <class SM, bool LOOKUP, int ITERS>
+template <class SM, bool LOOKUP, int ITERS, int REF_TIE>
 __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __restrict__ table, const float* __restrict__ lori,
                                              const float* __restrict__ rori, const float* __restrict__ ext, int& n_survivors, int stop_after = 2, int mode = 0)
 {
     n_survivors = num;                                                     // stop_after 0: the candidate list itself (S3 / S7)
     if (stop_after == 0) return 0.0f;
-    const int ref_tie = mode >> 4;                                         // bit 4 of mode: option ref_tie_order 2 (sort_scores)
-    mode &= 15;
     // instantiations rather than flags inside the loops: the register budget is that of the path taken
-    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2>(sm, num, table, ext, ref_tie);
-    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1>(sm, num, table, ext, ref_tie);
-    else num = dist_filter<SM, LOOKUP, ITERS, 0>(sm, num, table, ext, ref_tie);
+    if (mode == 2 && LOOKUP) num = dist_filter<SM, LOOKUP, ITERS, 2, REF_TIE>(sm, num, table, ext);
+    else if (mode >= 1) num = dist_filter<SM, LOOKUP, ITERS, 1, REF_TIE>(sm, num, table, ext);
+    else num = dist_filter<SM, LOOKUP, ITERS, 0, REF_TIE>(sm, num, table, ext);
     n_survivors = num;                                                     // stop_after 1: corr2, the survivors of S8
     if (mode >= 1) {                                                       // the survivors' points back to 16-bit integers: what S9 and the correspondence export read
         for (int t = threadIdx.x; t < num; t += 64) {
@@ -926,7 +924,7 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
     if (stop_after == 1) return 0.0f;
     n_survivors = 0;
     if (num < 2) return 0.0f;
-    num = angle_filter(sm, num, lori, rori, ref_tie);
+    num = angle_filter<SM, REF_TIE>(sm, num, lori, rori);
     n_survivors = num;                                                     // li/ri/xy[0..num) (+ similarities) = corr3 in the reference's order
     // :508-514 / :775-781: the sum of the survivors' similarities in list order.  They are gathered into b[] first (one parallel
     // round trip when they come from global memory) and added up sequentially from LDS.
@@ -938,7 +936,7 @@ __device__ __forceinline__ float graph_score(SM& sm, int num, const float* __res
 }
 
 // parity tap (tests only): the list a task holds after stage `stage` (0 = candidates, 1 = after S8, 2 = after S9)
-struct GraphTap { MinuCand* out; int32_t* n; int stage; int ref_tie; };   // ref_tie: option ref_tie_order 2 (bit 8 of the launchers' tap_stage word)
+struct GraphTap { MinuCand* out; int32_t* n; int stage; };
 template <class SM>
 __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, const float* __restrict__ ext, long long task, int n, int cap)
 {
@@ -960,6 +958,7 @@ __device__ __forceinline__ void tap_write(const GraphTap& tap, const SM& sm, con
 typedef WaveSmem<kTopTex, AFIS_TEX_CACHE, false> TexSmem;
 constexpr int kTexRegs = (kTexMax + 63) / 64;     // 16 row maxima per lane: the wave holds all <= 1000 keys in registers
 
+template <int REF_TIE>   // 1: option ref_tie_order 2 (sort_scores); its own instantiation, so that the default kernel is the code it was
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAVES, AFIS_TEX_WAVES))) void k_graph_texture(QueryDev q, GalleryDev g, const float* __restrict__ table_dist,
                                                       const float* __restrict__ rm_val, const int32_t* __restrict__ rm_arg,
                                                       const float* __restrict__ rm_cv, const int32_t* __restrict__ rm_n,
@@ -1119,7 +1118,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_TEX_WAV
         GPH_K(15);                                                       // S7 + list build
         int n_surv;
         const float* const row_max = (rm_n ? rm_cv : rm_val) + o;           // the array the entries' slots index
-        const float score = graph_score<TexSmem, true, 3>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, row_max, n_surv, tap.out ? tap.stage : 2, mode | (tap.ref_tie << 4));   // :759, :767
+        const float score = graph_score<TexSmem, true, 3, REF_TIE>(sm, num, table_dist, q.lt_ori + l0, g.tex_ori + r0, row_max, n_surv, tap.out ? tap.stage : 2, mode);   // :759, :767
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, row_max, task, n_surv, kTopTex);
         WSYNC();
@@ -1136,7 +1135,9 @@ hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const fl
     const int grid = (int)(n_tasks < 16384 ? n_tasks : 16384);
     hipError_t e0 = hipMemsetAsync(g.task_ctr + 0, 0, 4, stream);
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(k_graph_texture, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, rm_cv, rm_n, parts, GraphTap{tap_out, tap_n, tap_stage & 255, (tap_stage >> 8) & 1});
+    const GraphTap tap{tap_out, tap_n, tap_stage & 255};
+    if ((tap_stage >> 8) & 1) hipLaunchKernelGGL(k_graph_texture<1>, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, rm_cv, rm_n, parts, tap);
+    else hipLaunchKernelGGL(k_graph_texture<0>, dim3(grid), dim3(64), 0, stream, q, g, table_dist, rm_val, rm_arg, rm_cv, rm_n, parts, tap);
     return hipGetLastError();
 }
 
@@ -1155,6 +1156,7 @@ typedef WaveSmem<kTopMinu, AFIS_MINU_CACHE, true> MinuGraphSmem;
 #ifndef AFIS_MINU_WAVES
 #define AFIS_MINU_WAVES 6
 #endif
+template <int REF_TIE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_MINU_WAVES, AFIS_MINU_WAVES))) void k_graph_minutiae(QueryDev q, GalleryDev g, const MinuCand* __restrict__ cands,
                                                        const int32_t* __restrict__ cand_n, float* __restrict__ parts,
                                                        short4* __restrict__ corr_out, int32_t* __restrict__ corr_n, GraphTap tap)
@@ -1198,7 +1200,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AFIS_MINU_WA
         WSYNC();
         GPH_K(7);                                                        // list load
         int n_surv;
-        const float score = graph_score<MinuGraphSmem, false, 5>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, nullptr, n_surv, tap.out ? tap.stage : 2, mode | (tap.ref_tie << 4));   // :492, :495
+        const float score = graph_score<MinuGraphSmem, false, 5, REF_TIE>(sm, num, nullptr, q.lm_ori + l0, g.minu_ori + r0, nullptr, n_surv, tap.out ? tap.stage : 2, mode);   // :492, :495
         if (lane == 0) *out = score;
         if (tap.out) tap_write(tap, sm, nullptr, task, n_surv, kTopMinu);
         if (corr_out) {
@@ -1223,7 +1225,9 @@ hipError_t launch_graph_minutiae(const QueryDev& q, const GalleryDev& g, const M
     const int grid = (int)(n_tasks < 32768 ? n_tasks : 32768);
     hipError_t e0 = join ? hipSuccess : hipMemsetAsync(g.task_ctr + 1, 0, 4, stream);
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(k_graph_minutiae, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, GraphTap{tap_out, tap_n, tap_stage & 255, (tap_stage >> 8) & 1});
+    const GraphTap tap{tap_out, tap_n, tap_stage & 255};
+    if ((tap_stage >> 8) & 1) hipLaunchKernelGGL(k_graph_minutiae<1>, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, tap);
+    else hipLaunchKernelGGL(k_graph_minutiae<0>, dim3(grid), dim3(64), 0, stream, q, g, cands, cand_n, parts, corr_out, corr_n, tap);
     return hipGetLastError();
 }
 

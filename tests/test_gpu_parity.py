@@ -1449,7 +1449,7 @@ def test_structured_templates_against_oracle(codebook_bytes, cb, oracle):
     assert n_pairs == 200 and n_pos >= 100, (n_pairs, n_pos)                   # most non-mates score above zero
 
 
-def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
+def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle, tmp_path):
     """Option s3_tie_order 1: where candidate norms tie, the list of 120 is the one libstdc++'s std::sort leaves (matcher.cpp:473-476 sorts the nL x nR indices with a non-strict
     comparator) — csrc/stdsort_order.h run by the any-shape candidate kernel (arrays in LDS up to 8192 similarities, in global scratch beyond) — instead of ascending element index.  It matters for lists with fewer than 120 POSITIVE similarities
     (the zeros that fill the list are all tied): tiny latent templates, and prints whose descriptors point away from each other (structured templates at identity weight 1.0).
@@ -1555,6 +1555,24 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle):
     with pytest.raises(M.AfisError):
         m.set_option("ref_tie_order", 3)
     m.close()
+    # the CLI: `match -ldir ... -tie 2` writes the scores of tie mode 9, without the flag those of tie mode 1 (the mate of latent 1 differs in the first decimal)
+    import subprocess
+    exe = os.path.join(os.path.dirname(M.LIB_PATH), "match")
+    for d in ("gal", "lat", "o1", "o2", "work"): (tmp_path / d).mkdir()
+    for j in range(6): (tmp_path / "gal" / f"R{j:03d}.dat").write_bytes(T.write_rolled(gal[j]))
+    (tmp_path / "lat" / "L1.dat").write_bytes(T.write_latent(lats[1]))
+    cbp = tmp_path / "cb.dat"; cbp.write_bytes(codebook_bytes)
+    rc, s9, _ = oracle.search(ocb, hl[1], hr[:6], tie_mode=9, want_parts=True)
+    rc, s1, _ = oracle.search(ocb, hl[1], hr[:6], tie_mode=1, want_parts=True)
+    assert ["%.3f" % v for v in s9] != ["%.3f" % v for v in s1]
+    for flags, out_dir, want in ((["-tie", "2"], "o2", s9), ([], "o1", s1)):
+        o = subprocess.run([exe, "-ldir", str(tmp_path / "lat"), "-g", str(tmp_path / "gal"), "-c", str(cbp), "-s", str(tmp_path / out_dir) + "/"] + flags, capture_output=True, text=True, cwd=tmp_path / "work")
+        assert o.returncode == 0, o.stderr
+        lines = (tmp_path / out_dir / "L1.csv").read_text().splitlines()
+        got = {int(os.path.basename(l.rsplit(",", 1)[0].strip('"'))[1:4]): l.rsplit(",", 1)[1] for l in lines if l.startswith('"')}      # (directory order is the file system's)
+        assert got == {j: "%.3f" % v for j, v in enumerate(want)}, (flags, got, want)
+    o = subprocess.run([exe, "-ldir", str(tmp_path / "lat"), "-g", str(tmp_path / "gal"), "-c", str(cbp), "-s", str(tmp_path / "o1") + "/", "-tie", "7"], capture_output=True, text=True, cwd=tmp_path / "work")
+    assert o.returncode == 2 and "ref_tie_order" in o.stderr
 
 
 def test_texture_top200_with_row_maxima_of_both_signs(codebook_bytes, cb, oracle):
