@@ -228,8 +228,8 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * "chunk" (gallery templates per workgroup), "minu_generic" (force the generic minutiae candidate kernel), "s3_tie_order" (0 [default]: candidate norms that tie — in practice the zero norms that fill a list with fewer
  * than 120 positive similarities — are taken in ascending element order; 1: in the order libstdc++'s std::sort leaves them, i.e. what the reference binary's matcher.cpp:473-476 delivers:
  * such lists — and the rare list in which two positive norms tie — then go through the any-shape candidate kernel, one wave of which runs the sort; about +2 % of a search on structured templates), "ref_tie_order" (0 [default], 1 = "s3_tie_order" 1, 2 = in addition the greedy selections of S8 and S9 — matcher.cpp:1301 / :1423 / :1590 — walk
- * equal SCORES in std::sort's order: that is where mated pairs differ, whose dozens of surviving correspondences tie exactly at S9; with 2 the scores are the reference binary's on all but two of
- * 240 000 structured pairs [the texture top-200 sort of S7 stays in index order]; no measurable cost beyond level 1; the match CLI: -tie <n>), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
+ * equal SCORES in std::sort's order: that is where mated pairs differ, whose dozens of surviving correspondences tie exactly at S9; with 2 the scores are the reference binary's on all but three of
+ * 350 000 synthetic pairs [the texture top-200 sort of S7 stays in index order]; no measurable cost beyond level 1; the match CLI: -tie <n>), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
  * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded; "search_timeout_ms" sets the same bound in
  * milliseconds; afis_get_option reads "search_timeout_s" rounded UP to whole seconds and "search_timeout_ms" exactly.  After such a timeout the device may still be working on the call: the caller's output
  * buffers must stay valid until afis_destroy, or until a later call on the context succeeds; afis_queries_free then only parks the handle (its device buffers are released by the next call that finds the device idle),
