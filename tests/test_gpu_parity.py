@@ -1550,6 +1550,12 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle, 
                 assert (want is None) == (gotl is None)
                 if want is None: continue
                 assert np.array_equal(gotl[1], want[1]) and np.array_equal(gotl[2], want[2]), (qi, gi, which, stage)
+    # the all-templates mode (matcher.cpp:339-374) runs the same kernels: latent 1 against its mate, every template, tie mode 9
+    qs_, rs_, sc_all = m.One2One_matching_all_templates(lats[1])
+    width = len(lats[1].minu) + len(lats[1].tex)
+    rc, want_all = oracle.all_templates(ocb, hl[1], hr[1], width, tie_mode=9)
+    rc, base_all = oracle.all_templates(ocb, hl[1], hr[1], width, tie_mode=4)
+    assert np.array_equal(sc_all[1].view(np.uint32), want_all.view(np.uint32)) and not np.array_equal(want_all.view(np.uint32), base_all.view(np.uint32))
     m.set_option("s3_tie_order", 1)
     assert m.get_option("ref_tie_order") == 1
     with pytest.raises(M.AfisError):
