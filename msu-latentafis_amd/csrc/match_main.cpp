@@ -14,7 +14,7 @@
 //   * the same stdout lines (gallery size, template counts, rank table, total duration).
 // Differences, all deliberate: the gallery is parsed once and kept in HBM instead of being re-read for every pair
 // (matcher.cpp:173/:278); rank ties are broken by ascending gallery index (the reference's std::sort leaves them unspecified,
-// matcher.cpp:306-309); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
+// matcher.cpp:306-309; with -tie 1|2 on one rank the list is std::sort's own, as the reference binary's); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
 // /LatentAFIS/scores/corr<latent>_<rolled>_<i>.csv (matcher.cpp:325-327, :405, :497-505), go to <score dir>/corr<latent>_<rolled>_<i>.csv
 // (or to the prefix given with -corr).
 // Multi-GPU: started once per GPU with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment
@@ -258,8 +258,9 @@ int main(int argc, char** argv)
         std::cerr << "match: afis_create failed (" << rc << "): " << afis_last_error(nullptr) << std::endl;
         return 2;
     }
+    const int tie_level = args.cmdOptionExists("-tie") ? atoi(args.getCmdOption("-tie").c_str()) : 0;
     if (args.cmdOptionExists("-tie")) {                                          // option ref_tie_order (include/afis_matcher.h): 2 = equal keys in the order the reference binary's std::sort leaves them
-        if (int rc = afis_set_option(ctx, "ref_tie_order", atoi(args.getCmdOption("-tie").c_str())); rc != AFIS_OK) {
+        if (int rc = afis_set_option(ctx, "ref_tie_order", tie_level); rc != AFIS_OK) {
             std::cerr << "match: -tie: " << afis_last_error(ctx) << std::endl;
             afis_destroy(ctx);
             return 2;
@@ -315,7 +316,18 @@ int main(int argc, char** argv)
         constexpr int kk = 24;                                                   // fixed-size per-rank block of the exchange
         std::vector<int64_t> idx(kk); std::vector<float> sc(kk); int32_t status = 0;
         t_s = StageClock::now();
-        if ((ret = job.agree(api(afis_search(ctx, &L.view, 1, nullptr, nullptr, &status, kk, idx.data(), sc.data()), "afis_search"))) != 0) return finish(ret);   // padded with -1 beyond the shard
+        // -tie >= 1, one rank: the rank list as the reference binary makes it — libstdc++'s std::sort of the gallery indices on the non-strict score comparator (matcher.cpp:306-309), called
+        // here on the score column itself: equal scores (the zero scores of a small gallery's tail) come out in ITS order, not by ascending index.  (Several ranks: the per-shard lists are
+        // merged by ascending index, as without the flag.)
+        const bool ref_rank_order = tie_level >= 1 && !job.multi;
+        std::vector<float> column(ref_rank_order ? rolled.size() : 0);
+        if ((ret = job.agree(api(afis_search(ctx, &L.view, 1, ref_rank_order ? column.data() : nullptr, nullptr, &status, kk, idx.data(), sc.data()), "afis_search"))) != 0) return finish(ret);   // padded with -1 beyond the shard
+        if (ref_rank_order && status != AFIS_QUERY_LATENT_EMPTY) {
+            std::vector<int> ind(rolled.size());
+            for (size_t i = 0; i < ind.size(); ++i) ind[i] = (int)i;
+            std::sort(ind.begin(), ind.end(), [&column](const int& a, const int& b) { return column[a] > column[b]; });
+            for (int j = 0; j < k; ++j) { idx[j] = ind[j]; sc[j] = column[ind[j]]; }
+        }
         g_clock.search += StageClock::now() - t_s;
         if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; return finish(1); }
         if (job.multi) {                                                         // the exchange step: per-shard top-24 -> merged top-24

@@ -799,6 +799,17 @@ void orc_atan2f_grid(int R, float* out)
         for (int dx = -R; dx <= R; ++dx) out[(size_t)(dy + R) * W + (dx + R)] = atan2f((float)dy, (float)dx);
 }
 
+// S11's rank list, matcher.cpp:306-309: the gallery indices sorted by score, descending, non-strict comparator.  std_sort != 0: with std::sort as the reference (equal scores in
+// whatever order libstdc++'s introsort leaves them — what `match -l ... -tie 1|2` writes); 0: equal scores by ascending index (afis_search's top-k, the CLI's default).
+void orc_rank_list(const float* scores, int n, int std_sort, int* out)
+{
+    std::vector<int> ind(n);
+    std::iota(ind.begin(), ind.end(), 0);
+    auto cmp = [scores](const int& a, const int& b) { return scores[a] > scores[b]; };
+    if (std_sort) std::sort(ind.begin(), ind.end(), cmp); else std::stable_sort(ind.begin(), ind.end(), cmp);
+    std::copy(ind.begin(), ind.end(), out);
+}
+
 // S11: one latent against a list of rolled handles (the body of the OpenMP loop, matcher.cpp:168-190).
 // scores[j] = final or -1 (rolled empty).  Returns 1 if the latent is empty (whole query skipped).
 // threads <= 0: the reference's own setting, 8 threads schedule(static,16).

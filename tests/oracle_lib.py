@@ -125,6 +125,13 @@ class Oracle:
         self.lib.orc_atan2f_grid(R, out.ctypes.data_as(C.POINTER(C.c_float)))
         return out
 
+    def rank_list(self, scores, std_sort: bool):
+        """matcher.cpp:306-309: gallery indices by descending score; std_sort: libstdc++'s std::sort as the reference (equal scores in introsort's order), else ascending index."""
+        s = np.ascontiguousarray(scores, np.float32); out = np.empty(len(s), np.int32)
+        self.lib.orc_rank_list.restype = None
+        self.lib.orc_rank_list(s.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(len(s)), C.c_int(int(std_sort)), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out
+
     def search(self, cb, lat, rolled_handles, tie_mode=1, threads=0, want_parts=False):
         n = len(rolled_handles)
         arr = (C.c_void_p * n)(*rolled_handles)

@@ -1579,6 +1579,30 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle, 
         assert got == {j: "%.3f" % v for j, v in enumerate(want)}, (flags, got, want)
     o = subprocess.run([exe, "-ldir", str(tmp_path / "lat"), "-g", str(tmp_path / "gal"), "-c", str(cbp), "-s", str(tmp_path / "o1") + "/", "-tie", "7"], capture_output=True, text=True, cwd=tmp_path / "work")
     assert o.returncode == 2 and "ref_tie_order" in o.stderr
+    # the rank list of -l (matcher.cpp:306-309: std::sort of the gallery indices by score): a gallery of 29 prints of which 24 score zero against latent 3 — with -tie the tied zeros of the
+    # top 24 come out in std::sort's order over the directory listing (the oracle's orc_rank_list calls std::sort on the same array), without it by ascending position
+    rc, s9 = oracle.search(ocb, hl[3], hr, tie_mode=9)
+    zero = [j for j in range(len(gal)) if s9[j] == 0][:24]; pos = [j for j in range(len(gal)) if s9[j] > 0][:5]
+    assert len(zero) == 24 and len(pos) == 5
+    for d in ("gal3", "lat3", "o3", "o4", "o5"): (tmp_path / d).mkdir()
+    for j in zero + pos: (tmp_path / "gal3" / f"R{j:03d}.dat").write_bytes(T.write_rolled(gal[j]))
+    (tmp_path / "lat3" / "L3.dat").write_bytes(T.write_latent(lats[3]))
+    base = [exe, "-g", str(tmp_path / "gal3"), "-c", str(cbp)]
+    o = subprocess.run(base + ["-ldir", str(tmp_path / "lat3"), "-s", str(tmp_path / "o3") + "/", "-tie", "2"], capture_output=True, text=True, cwd=tmp_path / "work")
+    assert o.returncode == 0, o.stderr
+    listing = [int(os.path.basename(l.rsplit(",", 1)[0].strip('"'))[1:4]) for l in (tmp_path / "o3" / "L3.csv").read_text().splitlines() if l.startswith('"')]   # the directory order the CLI saw
+    assert sorted(listing) == sorted(zero + pos)
+    col = np.array([s9[j] for j in listing], np.float32)
+    rc, s1 = oracle.search(ocb, hl[3], hr, tie_mode=1)                                      # (without the flag the SCORES are tie mode 1's: a tiny latent's differ)
+    col1 = np.array([s1[j] for j in listing], np.float32)
+    want_ref = [listing[i] for i in oracle.rank_list(col, True)[:24]]; want_idx = [listing[i] for i in oracle.rank_list(col1, False)[:24]]
+    assert want_ref != [listing[i] for i in oracle.rank_list(col, False)[:24]]
+    for flags, out_dir, want in ((["-tie", "2"], "o4", want_ref), ([], "o5", want_idx)):
+        o = subprocess.run(base + ["-l", str(tmp_path / "lat3" / "L3.dat"), "-s", str(tmp_path / out_dir) + "/"] + flags, capture_output=True, text=True, cwd=tmp_path / "work")
+        assert o.returncode == 0, o.stderr
+        rows = (tmp_path / out_dir / "L3.csv").read_text().splitlines()[1:]
+        got = [int(os.path.basename(r.split('"')[1])[1:4]) for r in rows]
+        assert got == want, (flags, got, want)
 
 
 def test_texture_top200_with_row_maxima_of_both_signs(codebook_bytes, cb, oracle):
