@@ -141,7 +141,8 @@ int64_t afis_gallery_size(const afis_ctx* ctx);
  *   parts       [n_q][G][4] or NULL : s0, s1, s2 (latent minutiae templates 26, 2, 11) and the texture score
  *   status      [n_q] or NULL    : AFIS_QUERY_*
  *   k, topk_idx [n_q][k], topk_score [n_q][k] : rank list, score descending, ties by ascending index
- *                                  (the reference's tie order is unspecified, matcher.cpp:306-309); padded with
+ *                                  (the reference's tie order is unspecified, matcher.cpp:306-309 — a caller that wants the
+ *                                  binary's order of EQUAL scores runs std::sort on the score column, as match -l -tie does); padded with
  *                                  idx -1 when k > G.  k = 0 skips it. */
 int afis_search(afis_ctx* ctx, const afis_template_view* queries, int n_q,
                 float* scores, float* parts, int32_t* status,
@@ -229,7 +230,7 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size);
  * than 120 positive similarities — are taken in ascending element order; 1: in the order libstdc++'s std::sort leaves them, i.e. what the reference binary's matcher.cpp:473-476 delivers:
  * such lists — and the rare list in which two positive norms tie — then go through the any-shape candidate kernel, one wave of which runs the sort; about +2 % of a search on structured templates), "ref_tie_order" (0 [default], 1 = "s3_tie_order" 1, 2 = in addition the greedy selections of S8 and S9 — matcher.cpp:1301 / :1423 / :1590 — walk
  * equal SCORES in std::sort's order: that is where mated pairs differ, whose dozens of surviving correspondences tie exactly at S9; with 2 the scores are the reference binary's on all but three of
- * 350 000 synthetic pairs [the texture top-200 sort of S7 stays in index order]; no measurable cost beyond level 1; the match CLI: -tie <n>), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
+ * 710 000 synthetic pairs [the texture top-200 sort of S7 stays in index order]; no measurable cost beyond level 1; the match CLI: -tie <n>), "search_timeout_s" (every host wait of a search is bounded: after this many seconds
  * without the device finishing, afis_search returns AFIS_EDEVICE instead of blocking; default 600, AFIS_SEARCH_TIMEOUT_S; <= 0 = unbounded; "search_timeout_ms" sets the same bound in
  * milliseconds; afis_get_option reads "search_timeout_s" rounded UP to whole seconds and "search_timeout_ms" exactly.  After such a timeout the device may still be working on the call: the caller's output
  * buffers must stay valid until afis_destroy, or until a later call on the context succeeds; afis_queries_free then only parks the handle (its device buffers are released by the next call that finds the device idle),
