@@ -204,7 +204,9 @@ enum { kDiagFallback = 0,       // candidate tasks handed to the any-shape kerne
        kDiagCandsClk = 4, kDiagCandsWall = 5,      // sampled workgroups of the candidate kernel: shader cycles and 100 MHz ticks they lived
        kDiagBoundClk = 6, kDiagBoundWall = 7,      // the same for the bound pass
        kDiagWords = 16 };
-// S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]; rm_n != NULL: the compact form above (rm_val unused), otherwise the dense one (rm_cv unused)
+// S7+S8b+S9: texture lists, one wave per (query, gallery template) -> parts[(q*G+g)*4+3]; rm_n != NULL: the compact form above (rm_val unused), otherwise the dense one (rm_cv unused).
+// tap_stage (this launcher and launch_graph_minutiae): bits 0-7 = the stage a parity tap stops after (2 = the whole scorer); bit 8 = option ref_tie_order 2 (the <1> instantiation of the
+// kernel: equal selectable scores of S8 / S9 in std::sort's order, graph.hip::sort_scores)
 hipError_t launch_graph_texture(const QueryDev& q, const GalleryDev& g, const float* table_dist,
                                 const float* rm_val, const int32_t* rm_arg, const float* rm_cv, const int32_t* rm_n, float* parts, MinuCand* tap_out, int32_t* tap_n, int tap_stage, hipStream_t stream);
 // S1-S3 for the three selected latent minutiae templates: correspondence lists in rank order, cands[task][120], cand_n[task]
