@@ -512,14 +512,13 @@ __global__ __launch_bounds__(256) void k_minu_classify(QueryDev q, GalleryDev g,
 #else
 #define RT_SYNC() __syncthreads()
 #endif
-template <int S>
+template <int S, int ref_tie_order /* option s3_tie_order: lists short of 120 positive norms, and lists in which positive norms tie, go to the any-shape kernel, which orders equal norms as std::sort does; an instantiation of its own: the default kernel carries none of it */>
 __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, GalleryDev g, const float4* __restrict__ lat_frag,
                                                                 const float4* __restrict__ rol_frag,  // descriptors as operand fragments
                                                                 MinuCand* __restrict__ cands, int32_t* __restrict__ cand_n, int32_t* __restrict__ fb,
                                                                 const int32_t* __restrict__ work /* rolled templates with tasks of this class */,
                                                                 int32_t* __restrict__ ctl /* ctl[c]: entries of work[]; ctl[4 + c]: the draw counter */,
-                                                                unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row (afis_device.h) */,
-                                                                int ref_tie_order /* option s3_tie_order: lists short of 120 positive norms, and lists in which positive norms tie, go to the any-shape kernel, which orders equal norms as std::sort does */)
+                                                                unsigned long long* __restrict__ diag /* NULL, or the launch group's diagnostics row (afis_device.h) */)
 {
     typedef RtCfg<S> Cfg;
     constexpr int kT = Cfg::kT, kW = Cfg::kW, kSimi = Cfg::kSimi, kCls = S == 1 ? 0 : S == 2 ? 1 : 2;
@@ -779,15 +778,13 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             // clamped to zero, matcher.cpp:447-451 — 8 % of the pairs of bench.py --workload structured, which the any-shape kernel did at 30 x the time): the positive entries are all
             // candidates and are ranked as always; the rest of the 120 are zero entries, which tie, in ascending element order (tie rule) — filled in below.
             bool fill = false;
-            if (Braw < 0 && !ref_tie_order) {                                        // uniform, rare: are there positive norms below 2^-15 (uncounted, bin <= 0)?  Looked for only here — the histogram pass pays nothing for it
+            if (__builtin_expect(Braw < 0 && !ref_tie_order, 0)) {                                        // uniform, rare: are there positive norms below 2^-15 (uncounted, bin <= 0)?  Looked for only here — the histogram pass pays nothing for it
                 if (tid == 0) sm.pad_[0] = 0;
                 RT_SYNC();
                 bool tiny = false;
-#pragma unroll
-                for (int t = 0; t < 32; ++t) tiny |= (rk[t] & 0x7fffffffu) != 0u && (int)((rk[t] >> 19) & 0xfffu) - kBinBase <= 0;
-                if (S == 4 && n_rows > 32) {
-                    const float cs2 = sm.colsum[cj];
-                    for (int t = 32; t < my_rows; ++t) {
+                {   // (the keys are recomputed from the matrix, not read from the 32 registers that hold them: a rare path that walks the register array costs the common one 1 % — measured)
+                    const float cs2 = my_rows > 0 ? sm.colsum[cj] : 0.0f;
+                    for (int t = 0; t < my_rows; ++t) {
                         const int i = cr + R * t;
                         const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs2);
                         tiny |= (key & 0x7fffffffu) != 0u && (int)((key >> 19) & 0xfffu) - kBinBase <= 0;
@@ -797,7 +794,7 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                 RT_SYNC();
                 fill = __builtin_amdgcn_readfirstlane(sm.pad_[0]) == 0;
             }
-            if (Braw < 2 && !fill) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // a threshold in or next to bin 0, or tiny positive norms among fewer than 120
+            if (__builtin_expect(Braw < 2 && !fill, 0)) { if (tid == 0) to_fallback(task); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RT_SYNC(); continue; }   // a threshold in or next to bin 0, or tiny positive norms among fewer than 120
             const int B = fill ? 0 : Braw;
             // ---- a crowded threshold bin: a second histogram inside it ----
             // Descriptors of extracted prints lie near a common manifold: a pair's norm keys then crowd into an octave or less, and the threshold bin alone (1/16 octave) can hold
@@ -807,19 +804,14 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             uint32_t edge = fill ? 0x80000001u + kKeySlack : 0x80000000u | ((uint32_t)(B + kBinBase) << 19);     // fill: every positive key
             if (!fill) {
                 const int above = (int)sm.hist[B], inbin = (int)sm.hist[B - 1] - above;     // uniform (after the scan hist[b] = the entries in the bins above b)
-                if (above + inbin > kCandCap - 32 && B < kSelBins - 1) {                 // (the top bin also holds everything above it: its keys' lower bits say nothing)
+                if (__builtin_expect(above + inbin > kCandCap - 32 && B < kSelBins - 1, 0)) {                 // (the top bin also holds everything above it: its keys' lower bits say nothing)
                     uint32_t* const h2 = reinterpret_cast<uint32_t*>(sm.cand);             // the composites' array is free until the candidates are keyed
                     if (tid < 256) h2[tid] = 0u;
                     RT_SYNC();
                     const uint32_t bin_bits = edge >> 19;
-#pragma unroll
-                    for (int t = 0; t < 32; ++t) {
-                        const bool inb = (rk[t] >> 19) == bin_bits;
-                        atomicAdd(inb ? &h2[(rk[t] >> 11) & 255u] : &sm.sink[lane], 1u);
-                    }
-                    if (S == 4 && n_rows > 32) {
-                        const float cs2 = sm.colsum[cj];
-                        for (int t = 32; t < my_rows; ++t) {
+                    {   // (keys recomputed from the matrix: see the fill path above)
+                        const float cs2 = my_rows > 0 ? sm.colsum[cj] : 0.0f;
+                        for (int t = 0; t < my_rows; ++t) {
                             const int i = cr + R * t;
                             const uint32_t key = approx_norm_key(sm.simi[i * ld + cj], sm.rowsum[i], cs2);
                             if ((key >> 19) == bin_bits) atomicAdd(&h2[(key >> 11) & 255u], 1u);
@@ -960,11 +952,11 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
     PHASE_FLUSH();
 }
 
-template <int S>
-static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int32_t* work, int32_t* ctl, unsigned long long* diag, int ref_tie_order, hipStream_t stream)
+template <int S, int REF>
+static hipError_t launch_rt_class_t(const QueryDev& q, const GalleryDev& g, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int32_t* work, int32_t* ctl, unsigned long long* diag, hipStream_t stream)
 {
     // opt-in to > 64 KB of dynamic LDS: a per-device function attribute, set on every launch (cheap) rather than cached per process
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands_rt<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RtSmem<S>));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_minu_cands_rt<S, REF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RtSmem<S>));
     if (e != hipSuccess) return e;
     const int per_cu = 4 / S;                                                      // 4 / 2 / 1 workgroups (16 waves) per CU, persistent: rolled templates are drawn from ctl[4 + class]
 #ifndef AFIS_RT_GRID_CAP
@@ -972,8 +964,13 @@ static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCa
 #endif
     const int full = (AFIS_RT_GRID_CAP > 0 && S == 1) ? AFIS_RT_GRID_CAP : 256 * per_cu;
     const int grid = g.G < full ? g.G : full;
-    hipLaunchKernelGGL(k_minu_cands_rt<S>, dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag, ref_tie_order);
+    hipLaunchKernelGGL((k_minu_cands_rt<S, REF>), dim3(grid), dim3(256 * S), sizeof(RtSmem<S>), stream, q, g, q.lm_frag, g.minu_frag, cands, cand_n, fallback, work, ctl, diag);
     return hipGetLastError();
+}
+template <int S>
+static hipError_t launch_rt_class(const QueryDev& q, const GalleryDev& g, MinuCand* cands, int32_t* cand_n, int32_t* fallback, int32_t* work, int32_t* ctl, unsigned long long* diag, int ref_tie_order, hipStream_t stream)
+{
+    return ref_tie_order ? launch_rt_class_t<S, 1>(q, g, cands, cand_n, fallback, work, ctl, diag, stream) : launch_rt_class_t<S, 0>(q, g, cands, cand_n, fallback, work, ctl, diag, stream);
 }
 
 hipError_t launch_minu_cands(const QueryDev& q, const GalleryDev& g, float* scratch, size_t scratch_floats_per_wg, int n_wg,
