@@ -250,3 +250,22 @@ def test_scores_stay_inside_the_tolerance_under_every_accumulation_order(oracle,
             n_bits += int((s1.view(np.uint32) != s0.view(np.uint32)).sum())
     assert all(v <= 1e-3 * 2 * gal.G for v in n_far.values()), n_far     # >= 99.9 % of the 1600 pairs inside the tolerance, for every order (the 96 000-pair sweeps: 99.997 %)
     assert n_pos > 600 and n_bits > 0          # the orders DO differ in the last bits of many scores: the test is not vacuous
+
+
+def test_rank_list_orders(oracle):
+    """orc_rank_list (matcher.cpp:306-309, the rank list of -l): with the stable order it is the lexsort by (score descending, index ascending) that afis_search's top-k and the
+    CLI's default produce; with std::sort it is a permutation in non-increasing score order that agrees with the stable one wherever scores are distinct, and IS the stable one up
+    to 16 entries (libstdc++ insertion-sorts those) — and is NOT for a longer list with a tied tail (what `match -l -tie` reproduces)."""
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 16, 17, 66, 1000):
+        s = np.zeros(n, np.float32)
+        k = max(1, n // 4)
+        s[rng.choice(n, k, replace=False)] = rng.random(k).astype(np.float32) * 100
+        st = oracle.rank_list(s, False); sd = oracle.rank_list(s, True)
+        assert np.array_equal(st, np.lexsort((np.arange(n), -s.astype(np.float64))))
+        assert sorted(sd.tolist()) == list(range(n)) and (np.diff(s[sd]) <= 0).all()
+        assert np.array_equal(sd[:k], st[:k])                                   # the distinct positive scores lead both lists
+        if n <= 16: assert np.array_equal(sd, st)
+    s = np.zeros(66, np.float32); s[[5, 9, 40]] = [3, 7, 1]
+    assert not np.array_equal(oracle.rank_list(s, True)[:24], oracle.rank_list(s, False)[:24])
+
