@@ -269,3 +269,33 @@ def test_rank_list_orders(oracle):
     s = np.zeros(66, np.float32); s[[5, 9, 40]] = [3, 7, 1]
     assert not np.array_equal(oracle.rank_list(s, True)[:24], oracle.rank_list(s, False)[:24])
 
+
+def test_where_the_reference_sort_order_moves_scores(oracle, codebook_bytes):
+    """The oracle's site-wise tie modes on structured templates (host/synth_structured.py), the CPU side of option ref_tie_order: a MATED pair keeps dozens of correspondences whose
+    S9 scores tie exactly, so std::sort at S3 alone (mode 4 = ref_tie_order 1) does not give the reference binary's score (mode 0) for the mates, std::sort at S3 + S8 + S9 (mode 9 =
+    ref_tie_order 2) does; and a pair with a tiny latent template (lists filled with tied zero norms) differs already at S3 (mode 4 != mode 1)."""
+    SS = importlib.import_module("msu-latentafis_amd.host.synth_structured")
+    cb = T.Codebook.from_bytes(codebook_bytes)
+    rng = np.random.default_rng(905)
+    SS.IDENTITY_WEIGHT = 1.0
+    try:
+        lats = [SS.make_structured_latent(rng, sigma=0.0095, n_tex_lo=200, n_tex_hi=260) for _ in range(3)]
+        tiny = SS.make_structured_latent(rng, sigma=0.0095, n_tex_lo=200, n_tex_hi=260, n_minu_lo=3, n_minu_hi=6)
+        gal = [SS.make_structured_mate(rng, cb, L, frac=0.6, sigma=0.0095, n_minu=int(rng.integers(40, 120)), n_tex=320) for L in lats]
+        while len(gal) < 40: gal.append(SS.make_structured_rolled(rng, cb, sigma=0.0095, n_minu=int(rng.integers(20, 128)), n_tex=300))
+    finally:
+        SS.IDENTITY_WEIGHT = 0.3
+    ocb = oracle.codebook(codebook_bytes)
+    hl, hr = cases.to_orc(oracle, ocb, lats + [tiny], gal)
+    bits = lambda a: a.view(np.uint32)
+    mates_moved = 0
+    for qi in range(3):
+        sc = {m: oracle.search(ocb, hl[qi], hr, tie_mode=m)[1] for m in (0, 1, 4, 9)}
+        assert np.array_equal(bits(sc[9]), bits(sc[0])), qi                         # S7's order does not matter on this set
+        mates_moved += int(bits(sc[4])[qi] != bits(sc[0])[qi])
+        rest = np.arange(len(gal)) != qi
+        assert (np.abs(sc[4][rest] - sc[0][rest]) <= 1e-3 * np.maximum(1, np.abs(sc[0][rest]))).all()
+    assert mates_moved >= 2, mates_moved
+    s1 = oracle.search(ocb, hl[3], hr, tie_mode=1)[1]; s4 = oracle.search(ocb, hl[3], hr, tie_mode=4)[1]; s0 = oracle.search(ocb, hl[3], hr, tie_mode=0)[1]
+    assert not np.array_equal(bits(s1), bits(s4)) and int((bits(s4) != bits(s0)).sum()) <= int((bits(s1) != bits(s0)).sum())
+
