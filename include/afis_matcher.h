@@ -142,7 +142,7 @@ int64_t afis_gallery_size(const afis_ctx* ctx);
  *   status      [n_q] or NULL    : AFIS_QUERY_*
  *   k, topk_idx [n_q][k], topk_score [n_q][k] : rank list, score descending, ties by ascending index
  *                                  (the reference's tie order is unspecified, matcher.cpp:306-309 — a caller that wants the
- *                                  binary's order of EQUAL scores runs std::sort on the score column, as match -l -tie does); padded with
+ *                                  binary's order of EQUAL scores passes the score column to afis_rank_list(..., ref_order 1), as match -l -tie does); padded with
  *                                  idx -1 when k > G.  k = 0 skips it. */
 int afis_search(afis_ctx* ctx, const afis_template_view* queries, int n_q,
                 float* scores, float* parts, int32_t* status,
@@ -191,6 +191,12 @@ int afis_gallery_file_names(const char* path, int64_t first, int64_t count, char
  *   rolled_status [G] or NULL : 0, or 2 = rolled template empty (the reference returns 2 before scoring, :350-353)
  *   query_status  NULL or out : AFIS_QUERY_LATENT_EMPTY when the latent has no template at all (:345-348) */
 int afis_match_all_templates(afis_ctx* ctx, const afis_template_view* query, float* scores, int32_t* rolled_status, int32_t* query_status);
+
+/* The rank list of One2List_matching, matcher.cpp:306-309, from a score column (host memory, no device work): idx[0 .. k) / sc[0 .. k) = the k best of scores[0 .. n), score descending.
+ * ref_order 0: equal scores by ascending index (what afis_search's own top-k delivers); 1: the reference's statement itself — std::sort of the indices 0 .. n-1 on the non-strict
+ * comparator scores[a] > scores[b], with this library's libstdc++ — so that equal scores (the zero scores at the tail of a small gallery's list) come out in the order the reference
+ * binary leaves them.  k > n: the rest is padded with idx -1, sc 0.  sc may be NULL. */
+int afis_rank_list(const float* scores, int64_t n, int ref_order, int k, int64_t* idx, float* sc);
 
 /* PQ encoder — replaces TrainedPQEncoder.encode_multi (extraction/descriptor_PQ.py:19-27, scipy.cluster.vq.vq per
  * sub-space): codes[i][m] = index of the codeword of sub-quantizer m nearest (squared L2, fp32, first minimum) to

@@ -1,6 +1,8 @@
 // afis_api.cpp — context life cycle, device identity, timing and options of the C ABI in include/afis_matcher.h.  The gallery side is afis_gallery.cpp, the search
 // side afis_search.cpp, the parity taps (test library only) afis_taps.cpp; device code lives in adc*.hip, minu.hip, graph.hip and pq_encode.hip.  Host C++ only.
 #include "afis_ctx.h"
+#include <algorithm>
+#include <vector>
 
 using namespace afis;
 
@@ -129,6 +131,24 @@ int afis_get_timing2(const afis_ctx* ctx, afis_timing* out, size_t struct_size)
     memcpy(out, &ctx->timing, std::min(struct_size, sizeof(afis_timing)));
     return AFIS_OK;
 }
+
+int afis_rank_list(const float* scores, int64_t n, int ref_order, int k, int64_t* idx, float* sc)
+{
+    if (n < 0 || k < 0 || (n > 0 && !scores) || (k > 0 && !idx)) return fail(nullptr, AFIS_EINVAL, "afis_rank_list: null argument or negative size");
+    if (n > 0x7fffffff) return fail(nullptr, AFIS_EINVAL, "afis_rank_list: more than 2^31 - 1 scores");
+    std::vector<int> ind((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ind[(size_t)i] = (int)i;
+    auto by_score = [scores](const int& a, const int& b) { return scores[a] > scores[b]; };     // matcher.cpp:306-308
+    if (ref_order) std::sort(ind.begin(), ind.end(), by_score);
+    else std::stable_sort(ind.begin(), ind.end(), by_score);
+    for (int j = 0; j < k; ++j) {
+        const bool in = j < n;
+        idx[j] = in ? ind[(size_t)j] : -1;
+        if (sc) sc[j] = in ? scores[ind[(size_t)j]] : 0.0f;
+    }
+    return AFIS_OK;
+}
+
 
 int afis_get_option(const afis_ctx* ctx, const char* name, int64_t* value)
 {

@@ -317,16 +317,13 @@ int main(int argc, char** argv)
         std::vector<int64_t> idx(kk); std::vector<float> sc(kk); int32_t status = 0;
         t_s = StageClock::now();
         // -tie >= 1, one rank: the rank list as the reference binary makes it — libstdc++'s std::sort of the gallery indices on the non-strict score comparator (matcher.cpp:306-309), called
-        // here on the score column itself: equal scores (the zero scores of a small gallery's tail) come out in ITS order, not by ascending index.  (Several ranks: the per-shard lists are
+        // (afis_rank_list) on the score column itself: equal scores (the zero scores of a small gallery's tail) come out in ITS order, not by ascending index.  (Several ranks: the per-shard lists are
         // merged by ascending index, as without the flag.)
         const bool ref_rank_order = tie_level >= 1 && !job.multi;
         std::vector<float> column(ref_rank_order ? rolled.size() : 0);
         if ((ret = job.agree(api(afis_search(ctx, &L.view, 1, ref_rank_order ? column.data() : nullptr, nullptr, &status, kk, idx.data(), sc.data()), "afis_search"))) != 0) return finish(ret);   // padded with -1 beyond the shard
         if (ref_rank_order && status != AFIS_QUERY_LATENT_EMPTY) {
-            std::vector<int> ind(rolled.size());
-            for (size_t i = 0; i < ind.size(); ++i) ind[i] = (int)i;
-            std::sort(ind.begin(), ind.end(), [&column](const int& a, const int& b) { return column[a] > column[b]; });
-            for (int j = 0; j < k; ++j) { idx[j] = ind[j]; sc[j] = column[ind[j]]; }
+            if ((ret = api(afis_rank_list(column.data(), (int64_t)column.size(), 1, k, idx.data(), sc.data()), "afis_rank_list")) != 0) return finish(ret);
         }
         g_clock.search += StageClock::now() - t_s;
         if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; return finish(1); }

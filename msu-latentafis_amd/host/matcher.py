@@ -48,7 +48,7 @@ class Timing(C.Structure):
 
 EXPORTS = ["afis_create", "afis_create_from_codebook", "afis_device_info", "afis_destroy", "afis_last_error", "afis_gallery_add", "afis_gallery_add_dat", "afis_gallery_add_dat_batch", "afis_gallery_reserve",
            "afis_gallery_add_packed", "afis_gallery_commit", "afis_gallery_size", "afis_gallery_save", "afis_gallery_load",
-           "afis_gallery_file_info", "afis_gallery_file_names", "afis_search", "afis_search_dat", "afis_queries_upload",
+           "afis_gallery_file_info", "afis_gallery_file_names", "afis_rank_list", "afis_search", "afis_search_dat", "afis_queries_upload",
            "afis_search_resident", "afis_queries_free", "afis_correspondences", "afis_match_all_templates", "afis_pq_encode", "afis_encode_rolled_dat", "afis_get_timing", "afis_get_timing2", "afis_set_option", "afis_get_option"]
 # include/afis_matcher_taps.h: exported by libafis_hip_test.so only
 TAP_EXPORTS = ["afis_debug_lut", "afis_debug_texture_rowmax", "afis_debug_stage_list", "afis_debug_phase_cycles", "afis_debug_atan2_grid", "afis_debug_graph_arith", "afis_debug_refine_stats"]
@@ -63,6 +63,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.afis_create_from_codebook.argtypes = [C.POINTER(vp), C.c_char_p, C.c_size_t, C.c_int]
     lib.afis_destroy.argtypes = [vp]; lib.afis_destroy.restype = None
     lib.afis_last_error.argtypes = [vp]; lib.afis_last_error.restype = C.c_char_p
+    lib.afis_rank_list.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
     lib.afis_gallery_add.argtypes = [vp, C.POINTER(TemplateView), C.c_int]
     lib.afis_gallery_add_dat.argtypes = [vp, C.c_char_p, C.c_size_t, i32p]
     lib.afis_gallery_reserve.argtypes = [vp, C.c_int64]
@@ -287,6 +288,14 @@ class Matcher:
         self._chk(self.lib.afis_search_dat(self.ctx, arr, lens, n, *args))
         return {"scores": scores, "parts": parts, "status": status, "topk_idx": ti, "topk_score": ts}
 
+    def rank_list(self, scores, k: int = 24, ref_order: bool = False):
+        """afis_rank_list (matcher.cpp:306-309): the k best of a score column, score descending; ref_order: equal scores in the order the reference binary's std::sort leaves them
+        (else by ascending index, as the search's own top-k)."""
+        s = np.ascontiguousarray(scores, np.float32).reshape(-1)
+        idx = np.full(max(k, 1), -1, np.int64); sc = np.zeros(max(k, 1), np.float32)
+        self._chk(self.lib.afis_rank_list(_ptr(s, C.c_float) if len(s) else None, C.c_int64(len(s)), C.c_int(int(ref_order)), C.c_int(k), _ptr(idx, C.c_int64), _ptr(sc, C.c_float)))
+        return idx[:k], sc[:k]
+
     def upload_queries(self, latents: Sequence[FPTemplate]):
         v = _Views(latents)
         h = C.c_void_p()
@@ -422,11 +431,14 @@ class Matcher:
         if r["status"][0] == 1:
             return 1
         k = min(top, self.gallery_size)
-        idx = [int(r["topk_idx"][0, j]) for j in range(k)]
+        idx = [int(r["topk_idx"][0, j]) for j in range(k)]; top_sc = [r["topk_score"][0, j] for j in range(k)]
+        if self.get_option("ref_tie_order") >= 1:             # the reference binary's own order of equal scores (std::sort on the score column), as `match -l -tie`
+            ri, rs = self.rank_list(r["scores"][0], k, ref_order=True)
+            idx = [int(g) for g in ri]; top_sc = list(rs)
         with open(score_path + stem + ".csv", "w") as out:
             out.write("filename,score\n")
             for j, g in enumerate(idx):
-                out.write(f'{j + 1}"{self.gallery_files[g]}",{_cxx_float(r["topk_score"][0, j])}\n')
+                out.write(f'{j + 1}"{self.gallery_files[g]}",{_cxx_float(top_sc[j])}\n')
         # correspondence files of the ranked templates (matcher.cpp:311-328, :497-505); the reference's hard-coded
         # /LatentAFIS/scores/ prefix becomes the score directory, as in the `match` CLI
         _, latent = read_latent(buf)

@@ -1603,6 +1603,12 @@ def test_candidate_ties_in_the_reference_sort_order(codebook_bytes, cb, oracle, 
         rows = (tmp_path / out_dir / "L3.csv").read_text().splitlines()[1:]
         got = [int(os.path.basename(r.split('"')[1])[1:4]) for r in rows]
         assert got == want, (flags, got, want)
+    # host/matcher.py's One2List_matching under the option: the file the CLI writes with -tie 2 (afis_rank_list behind both)
+    (tmp_path / "o6").mkdir()
+    m5 = M.Matcher(codebook_bytes); m5.load_gallery_dir(str(tmp_path / "gal3")); m5.set_option("ref_tie_order", 2)
+    assert m5.One2List_matching(str(tmp_path / "lat3" / "L3.dat"), str(tmp_path / "o6") + "/") == 0
+    assert (tmp_path / "o6" / "L3.csv").read_bytes() == (tmp_path / "o4" / "L3.csv").read_bytes()
+    m5.close()
 
 
 def test_texture_top200_with_row_maxima_of_both_signs(codebook_bytes, cb, oracle):

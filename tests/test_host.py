@@ -476,3 +476,25 @@ def test_stdsort_order_equals_libstdcxx(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-o", str(exe), os.path.join(ROOT, "tools", "stdsort_check.cpp")], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and " 0 mismatches" in out.stdout, out.stdout + out.stderr
+
+
+def test_rank_list_entry_point_is_the_reference_sort(oracle):
+    """afis_rank_list (include/afis_matcher.h; host only: no device needed): matcher.cpp:306-309's rank list from a score column.  ref_order 1 = std::sort on the reference's
+    comparator — the oracle's orc_rank_list calls the same libstdc++ routine —, ref_order 0 = equal scores by ascending index; k beyond n pads with -1."""
+    import ctypes as C
+    lib = M.load_library()
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 16, 17, 66, 5000):
+        s = np.zeros(n, np.float32)
+        if n: s[rng.choice(n, max(1, n // 5), replace=False)] = (rng.random(max(1, n // 5)) * 50).astype(np.float32)
+        if n > 20: s[3] = s[7] = 12.5                                                  # a tie among positive scores as well
+        for ref in (0, 1):
+            k = 24
+            idx = np.full(k, 99, np.int64); sc = np.full(k, 9.0, np.float32)
+            rc = lib.afis_rank_list(s.ctypes.data_as(C.POINTER(C.c_float)) if n else None, C.c_int64(n), C.c_int(ref), C.c_int(k), idx.ctypes.data_as(C.POINTER(C.c_int64)), sc.ctypes.data_as(C.POINTER(C.c_float)))
+            assert rc == 0
+            want = oracle.rank_list(s, bool(ref))[:k] if n else np.zeros(0, np.int32)
+            m = min(k, n)
+            assert np.array_equal(idx[:m], want[:m]) and np.array_equal(sc[:m], s[want[:m]]) and (idx[m:] == -1).all() and (sc[m:] == 0).all(), (n, ref)
+    assert lib.afis_rank_list(None, C.c_int64(5), C.c_int(0), C.c_int(3), None, None) != 0
+
