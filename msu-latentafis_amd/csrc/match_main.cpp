@@ -14,7 +14,7 @@
 //   * the same stdout lines (gallery size, template counts, rank table, total duration).
 // Differences, all deliberate: the gallery is parsed once and kept in HBM instead of being re-read for every pair
 // (matcher.cpp:173/:278); rank ties are broken by ascending gallery index (the reference's std::sort leaves them unspecified,
-// matcher.cpp:306-309; with -tie 1|2 on one rank the list is std::sort's own, as the reference binary's); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
+// matcher.cpp:306-309; with -tie 1|2 the list is std::sort's own, as the reference binary's — with several ranks on the gathered score column); the correspondence CSVs of the top 24, which the reference writes to the hard-coded
 // /LatentAFIS/scores/corr<latent>_<rolled>_<i>.csv (matcher.cpp:325-327, :405, :497-505), go to <score dir>/corr<latent>_<rolled>_<i>.csv
 // (or to the prefix given with -corr).
 // Multi-GPU: started once per GPU with RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT in the environment
@@ -316,18 +316,29 @@ int main(int argc, char** argv)
         constexpr int kk = 24;                                                   // fixed-size per-rank block of the exchange
         std::vector<int64_t> idx(kk); std::vector<float> sc(kk); int32_t status = 0;
         t_s = StageClock::now();
-        // -tie >= 1, one rank: the rank list as the reference binary makes it — libstdc++'s std::sort of the gallery indices on the non-strict score comparator (matcher.cpp:306-309), called
-        // (afis_rank_list) on the score column itself: equal scores (the zero scores of a small gallery's tail) come out in ITS order, not by ascending index.  (Several ranks: the per-shard lists are
-        // merged by ascending index, as without the flag.)
-        const bool ref_rank_order = tie_level >= 1 && !job.multi;
-        std::vector<float> column(ref_rank_order ? rolled.size() : 0);
+        // -tie >= 1: the rank list as the reference binary makes it — libstdc++'s std::sort of the gallery indices on the non-strict score comparator (matcher.cpp:306-309), run
+        // (afis_rank_list) on the score column itself: equal scores (the zero scores of a small gallery's tail) come out in ITS order, not by ascending index.  Several ranks:
+        // the shards' score columns are gathered (the exchange of -ldir, one latent) and every rank sorts the same whole column.
+        const bool ref_rank_order = tie_level >= 1;
+        const size_t G = rolled.size(), Gl = (size_t)(job.hi - job.lo), Gm = (size_t)job.g_max;
+        std::vector<float> column(ref_rank_order ? (job.multi ? std::max<size_t>(Gl, 1) : G) : 0);
         if ((ret = job.agree(api(afis_search(ctx, &L.view, 1, ref_rank_order ? column.data() : nullptr, nullptr, &status, kk, idx.data(), sc.data()), "afis_search"))) != 0) return finish(ret);   // padded with -1 beyond the shard
         if (ref_rank_order && status != AFIS_QUERY_LATENT_EMPTY) {
+            if (job.multi) {
+                std::vector<float> block(std::max<size_t>(Gm, 1), -1.0f), all((size_t)job.w.world * block.size()), whole(G);
+                memcpy(block.data(), column.data(), Gl * sizeof(float));
+                if (!xchg(block.data(), all.data(), block.size() * sizeof(float))) return finish(2);
+                for (int r = 0; r < job.w.world; ++r) {
+                    const size_t lo = (size_t)job.bounds[(size_t)r].first, n = (size_t)(job.bounds[(size_t)r].second - job.bounds[(size_t)r].first);
+                    memcpy(&whole[lo], &all[(size_t)r * block.size()], n * sizeof(float));
+                }
+                column.swap(whole);
+            }
             if ((ret = api(afis_rank_list(column.data(), (int64_t)column.size(), 1, k, idx.data(), sc.data()), "afis_rank_list")) != 0) return finish(ret);
         }
         g_clock.search += StageClock::now() - t_s;
         if (status == AFIS_QUERY_LATENT_EMPTY) { std::cout << "Matching failed: latent template is empty. Exiting." << std::endl; return finish(1); }
-        if (job.multi) {                                                         // the exchange step: per-shard top-24 -> merged top-24
+        if (job.multi && !ref_rank_order) {                                      // the exchange step: per-shard top-24 -> merged top-24
             std::vector<int64_t> all_i((size_t)job.w.world * kk); std::vector<float> all_s((size_t)job.w.world * kk);
             if (!xchg(idx.data(), all_i.data(), kk * sizeof(int64_t)) || !xchg(sc.data(), all_s.data(), kk * sizeof(float))) return finish(2);
             merge_topk(all_i, all_s, job.w.world, kk, kk, idx, sc);

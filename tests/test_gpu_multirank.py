@@ -120,7 +120,8 @@ def _files(path):
 
 def test_match_two_ranks_equal_one_rank(match_case):
     exe, d = match_case
-    for mode, extra in (("ldir", ["-ldir", str(d / "lat")]), ("l", ["-l", str(d / "lat" / "L0.dat")])):
+    # (-tie 2: option ref_tie_order and, for -l, the rank list by std::sort on the gathered score column — every rank sorts the same whole column)
+    for mode, extra in (("ldir", ["-ldir", str(d / "lat")]), ("l", ["-l", str(d / "lat" / "L0.dat")]), ("ltie", ["-l", str(d / "lat" / "L0.dat"), "-tie", "2"]), ("ldirtie", ["-ldir", str(d / "lat"), "-tie", "2"])):
         outs = {}
         for world in (1, 2):
             sd = d / f"out_{mode}_{world}"
@@ -132,10 +133,10 @@ def test_match_two_ranks_equal_one_rank(match_case):
                 assert res[1][1] == ""                                   # rank 1 is silent on stdout; rank 0 speaks for the job
                 assert "Gallery size: 22" in res[0][1]
             outs[world] = _files(sd)
-        assert set(outs[1]) == set(outs[2]) and len(outs[1]) >= (3 if mode == "ldir" else 2), (mode, sorted(outs[1]), sorted(outs[2]))
+        assert set(outs[1]) == set(outs[2]) and len(outs[1]) >= (3 if mode.startswith("ldir") else 2), (mode, sorted(outs[1]), sorted(outs[2]))
         for f in outs[1]:
             assert outs[1][f] == outs[2][f], (mode, f)
-        if mode == "l":
+        if mode in ("l", "ltie"):
             assert any(f.startswith("corrL0_") and len(outs[1][f]) > 0 for f in outs[1])      # correspondence files came from both shards' owners
 
 
