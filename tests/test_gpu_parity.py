@@ -631,6 +631,15 @@ def test_golden_vectors(codebook_bytes):
     diff = got.view(np.uint32) != want.view(np.uint32)           # the committed vectors are reproduced bit for bit
     assert not diff.any(), (np.argwhere(diff), got[diff], want[diff])
     assert list(res["topk_idx"][0]) == [0, 1, 2] and list(res["topk_idx"][1]) == [3, 4, 5]
+    # ... and with option ref_tie_order 2 the OTHER committed set: tie_mode 0, std::sort at every site — the order the reference binary executes (six of the 24 pairs differ between the sets)
+    m.set_option("ref_tie_order", 2)
+    res = m.search_dat([gold[f"latent_{i}"].tobytes() for i in range(2)], k=3, want_parts=True)
+    got = np.concatenate([res["parts"], res["scores"][..., None]], axis=-1)
+    want0 = gold["parts"][0]
+    assert int((want0.view(np.uint32) != want.view(np.uint32)).any(axis=-1).sum()) >= 4
+    diff = got.view(np.uint32) != want0.view(np.uint32)
+    assert not diff.any(), (np.argwhere(diff), got[diff], want0[diff])
+    m.close()
 
 
 # ---- size-independent properties at a larger scale --------------------------------------------------------------------------
