@@ -913,16 +913,8 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
                     MinuCand cd; cd.sim = sm.simi[ci * ld + cj2]; cd.li = (short)ci; cd.ri = (short)cj2;
                     cands[(size_t)task * kTopMinu + r] = cd;
                 }
-                if (ref_tie_order && r <= kTopMinu) {                                // (uniform flag, the option only) equal POSITIVE norms in or at the end of the list — one list in 10^5 — are ordered by
-                    // libstdc++'s sort as well: the same walk counting the strictly larger NORMS; a difference = a candidate of the same norm and a lower element index in front of this one
-                    const u64 mine_top = mine | 0xffffull;
-                    int gcount = lo;
-                    for (int k = lo; k < hi; k += 8) {
-                        const ulonglong2 k0 = c2[(k >> 1)], k1 = c2[(k >> 1) + 1], k2 = c2[(k >> 1) + 2], k3 = c2[(k >> 1) + 3];
-                        gcount += (int)(k0.x > mine_top) + (int)(k0.y > mine_top) + (int)(k1.x > mine_top) + (int)(k1.y > mine_top) + (int)(k2.x > mine_top) + (int)(k2.y > mine_top) + (int)(k3.x > mine_top) + (int)(k3.y > mine_top);
-                    }
-                    if (gcount != r) sm.pad_[1] = 1;
-                }
+                if (ref_tie_order && r <= kTopMinu) sm.cand_e[r] = ke;               // (the option's instantiation only) the norm keys in rank order, one beyond the list: equal neighbours = equal POSITIVE norms in
+                                                                                     // or at the end of the list, which libstdc++'s sort orders its own way (cand_e[] is dead: its entries were read before the composites were written)
             }
             if (fill && wave == 0) {                                                 // ranks n_c .. 119: the first zero similarities in element order (n >= 512 entries, fewer than 120 of them positive: there are enough)
                 int rank = n_c;
@@ -940,7 +932,11 @@ __global__ __launch_bounds__(256 * S, 4) void k_minu_cands_rt(QueryDev q, Galler
             ++n_done;
 #if AFIS_MC_ABLATE != 3                                                  // (3: timing experiment only — no barrier at the end of a task: what dropping it could give at most)
             RT_SYNC();
-            if (ref_tie_order && tid == 0 && sm.pad_[1] != 0) { sm.pad_[1] = 0; to_fallback(task); }   // the any-shape kernel redoes this list in the reference's sort order (it runs after this kernel, on the same stream)
+            if (ref_tie_order) {                                                     // one list in 10^5: two equal positive norms among the first 121 -> the any-shape kernel redoes the list in the reference's
+                if (tid + 1 < min(n_c, kTopMinu + 1) && sm.cand_e[tid] == sm.cand_e[tid + 1]) sm.pad_[1] = 1;   // sort order (it runs after this kernel, on the same stream)
+                RT_SYNC();
+                if (tid == 0 && sm.pad_[1] != 0) { sm.pad_[1] = 0; to_fallback(task); }
+            }
 #endif
             PHASE(20);
         }
